@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json:
+
+    loci/sec ols_iter_with_kinship, 200 pools x 10M loci, 1/2/4/8 MI355X
+
+One "step" = one full pass of the hot path over the resident genotype matrix: partial kinship
+(fp64 MFMA) -> [all-reduce over ranks] -> n x n eigen step + basis (host, replicated) -> per-locus
+OLS sweep.  Inputs are synthetic and resident in HBM before the timed region.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), loci sharded contiguously,
+total work fixed (strong scaling, as the metric is quoted on 10M loci in total).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, fp64 matrix (not in the local guide)
+
+
+def cpu_baseline(G_sample_host: np.ndarray, Y: np.ndarray, var_explained: float, force_m: int):
+    """The oracle (a port of the reference algorithm), timed on this box's host cores."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    o = oracle_lib.load()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    probe = min(20000, G_sample_host.shape[0])
+    t0 = time.perf_counter()
+    o.ols_with_covariate(G_sample_host[:probe], Y, var_explained, force_m, threads=cores)
+    t_probe = time.perf_counter() - t0
+    target = 12.0
+    s = int(min(G_sample_host.shape[0], max(probe, probe * target / max(t_probe, 1e-6))))
+    t0 = time.perf_counter()
+    o.ols_with_covariate(G_sample_host[:s], Y, var_explained, force_m, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": s / dt, "unit": "loci/s", "cores": cores, "kind": "port",
+            "sample": f"first {s} of the same synthetic loci (n={G_sample_host.shape[1]}), kinship + eig + "
+                      f"per-locus LU fits, OpenMP over loci, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pools", type=int, default=200)
+    ap.add_argument("--loci", type=int, default=10_000_000, help="TOTAL loci over all GPUs")
+    ap.add_argument("--var-explained", type=float, default=0.75)
+    ap.add_argument("--force-m", type=int, default=-1, help=">=0 forces the number of kinship PCs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1_500_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from poolgen_amd import Engine, synth
+    from poolgen_amd.distributed import ols_with_covariate_sharded, shard_range
+
+    n, p_total, k = args.pools, args.loci, 1
+    lo, hi = shard_range(p_total, rank, world)
+    p_local = hi - lo
+    eng = Engine(local_rank)
+    G = synth.genotype_matrix(p_local, n, dev, start=lo)
+    # phenotype: 10 causal loci spread over the WHOLE matrix; any rank can regenerate any locus
+    causal = [(p_total * (2 * i + 1)) // 20 for i in range(10)]
+    Gc = torch.cat([synth.genotype_matrix(1, n, dev, start=c) for c in causal], dim=0)
+    rng = np.random.default_rng(synth.SEED)
+    gval = Gc[:, :n].T.cpu().numpy() @ rng.normal(size=10)
+    Y = (gval + rng.normal(size=n) * np.sqrt(gval.var())).reshape(n, 1)   # h2 = 0.5
+    out = torch.empty((3, p_local, k), dtype=torch.float64, device=dev)
+
+    def step():
+        return ols_with_covariate_sharded(eng, G, p_total, Y, args.var_explained, args.force_m, n, out)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    m = -1
+    for _ in range(args.warmup):
+        m = step()[0]
+    eng.profile(True)
+    eng.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m = step()[0]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kin_ms, kin_n = eng.profile_get("kinship")
+    red_ms, red_n = eng.profile_get("kinship_reduce")
+    sw_ms, sw_n = eng.profile_get("sweep")
+    eng.profile(False)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = p_total / (dt / args.steps)
+        kin_avg = kin_ms / max(kin_n, 1)
+        sw_avg = sw_ms / max(sw_n, 1)
+        sweep_bytes = (8.0 * n + 24.0 * k) * p_local       # 8n read + 24k written per locus
+        kin_flops = 2.0 * n * n * p_local                   # reference computes the full product
+        sweep_gbs = sweep_bytes / (sw_avg * 1e-3) / 1e9 if sw_avg > 0 else 0.0
+        kin_tflops = kin_flops / (kin_avg * 1e-3) / 1e12 if kin_avg > 0 else 0.0
+        traffic = None
+        tfile = ROOT / "profiles" / "pmc_traffic.json"
+        if tfile.exists():
+            try:
+                tj = json.loads(tfile.read_text())
+                key = "kinship" if kin_avg >= sw_avg else "sweep"
+                if tj.get("workload") == f"{n}x{p_local}":
+                    traffic = tj.get(key + "_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        if kin_avg >= sw_avg:
+            roof = {"kernel": "k_kinship_syrk", "bound": "mfma", "achieved": kin_tflops,
+                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kin_tflops / FP64_MFMA_PEAK_TFLOPS,
+                    "traffic": traffic, "avg_ms": kin_avg, "launches": kin_n}
+        else:
+            roof = {"kernel": "k_ols_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": sw_avg,
+                    "launches": sw_n}
+        rec = {
+            "metric": "loci/sec ols_iter_with_kinship, 200 pools x 10M loci",
+            "value": value, "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ols_iter_with_kinship {n} pools x {p_total} loci (BASELINE configs[2])",
+                       "pools": n, "loci_total": p_total, "loci_per_gpu": p_local, "traits": k,
+                       "xxt_eigen_variance_explained": args.var_explained, "n_eigenvecs": m,
+                       "parallelism": f"locus-sharded x{world}, 1 all-reduce of {n}x{n} fp64"},
+            "roofline": roof,
+            "kernels": {
+                "k_kinship_syrk": {"avg_ms": kin_avg, "tflops_algorithmic": kin_tflops,
+                                   "frac_of_fp64_mfma_peak": kin_tflops / FP64_MFMA_PEAK_TFLOPS},
+                "k_kinship_reduce": {"avg_ms": red_ms / max(red_n, 1)},
+                "k_ols_sweep": {"avg_ms": sw_avg, "gbs_algorithmic": sweep_gbs,
+                                "frac_of_hbm_peak": sweep_gbs / HBM_PEAK_GBS},
+                "host_eig_and_glue_ms": ms_per_step - kin_avg - sw_avg - red_ms / max(red_n, 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            s = min(args.cpu_sample, p_local)
+            rec["cpu_baseline"] = cpu_baseline(G[:s, :n].cpu().numpy(), Y, args.var_explained, args.force_m)
+        print(json.dumps(rec))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

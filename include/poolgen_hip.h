@@ -1,0 +1,181 @@
+/*
+ * poolgen_hip.h -- C ABI of libpoolgen_hip.so: the MI355X (gfx950) implementation of poolgen's
+ * per-locus regression hot path.  This is the drop-in boundary: plain pointers and sizes, no
+ * C++/torch types.  Each entry point cites the reference interface (file:line relative to the
+ * poolgen source tree) it replaces; INTEGRATION.md shows the Rust `extern "C"` binding a
+ * poolgen maintainer would add.
+ *
+ * Conventions
+ *  - All floating point is fp64.  Integer/index outputs are bit-exact w.r.t. the reference.
+ *  - Genotype matrices are LOCUS-MAJOR: G[l * ld + i] = allele frequency of pool i at column
+ *    (locus/allele) l, ld >= n, ld even (16-byte aligned rows).  The reference stores
+ *    `intercept_and_allele_frequencies` pool-major n x (1+p) (base/structs_and_traits.rs:144);
+ *    the intercept column is implicit here.
+ *  - Phenotypes Y are n x k row-major on the HOST (the reference's Array2<f64>, :145).
+ *  - `*_dev` pointers are device (HBM) addresses on the context's GPU; everything else is host.
+ *  - Return value: 0 on success, negative pg_status on failure; pg_last_error() gives text.
+ *    A single bad locus never fails a batch: it is reported per locus (None -> n_alleles = 0,
+ *    regression failure -> NaN) exactly like the reference operators (gwas/ols.rs:210-253,
+ *    :358-369).
+ *  - One in-flight call per pg_ctx; contexts are independent (one per GPU / per process rank).
+ *  - There is NO CPU fallback: without a usable gfx950 device every compute call fails.
+ */
+#ifndef POOLGEN_HIP_H
+#define POOLGEN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pg_ctx pg_ctx;
+
+enum pg_status {
+    PG_OK = 0,
+    PG_ERR_INVALID = -1,   /* bad shape / argument */
+    PG_ERR_HIP = -2,       /* HIP runtime error (text in pg_last_error) */
+    PG_ERR_NO_DEVICE = -3, /* no gfx950 device */
+    PG_ERR_STATE = -4,     /* call order violated (e.g. sweep before covariates) */
+    PG_ERR_UNSUPPORTED = -5
+};
+
+/* FilterStats subset used by the sync-derived operators (base/structs_and_traits.rs:68-78,
+ * filled from the CLI flags at main.rs:202-211). */
+typedef struct {
+    int32_t remove_ns;            /* !--keep-ns */
+    int32_t reserved;
+    uint64_t min_coverage_depth;  /* --min-coverage-depth */
+    double min_allele_frequency;  /* --min-allele-frequency */
+    double max_missingness_rate;  /* --max-missingness-rate */
+} pg_filter;
+
+/* Per-locus output of the sync-derived batch operators (struct-of-arrays, device or host).
+ * PG_MAX_OUT alleles per locus: 6 sync columns minus the one dropped. */
+#define PG_MAX_OUT 5
+
+/* ---------------------------------------------------------------------------------------
+ * context
+ * ------------------------------------------------------------------------------------- */
+/* device: HIP ordinal.  stream: a hipStream_t owned by the caller (e.g. torch's current
+ * stream) or NULL for the context's own stream. */
+int pg_create(pg_ctx **out, int device, void *stream);
+void pg_destroy(pg_ctx *ctx);
+const char *pg_last_error(const pg_ctx *ctx);
+const char *pg_version(void);
+int pg_synchronize(pg_ctx *ctx);
+/* Per-kernel HIP-event timing (used by bench.py for the roofline record). */
+enum pg_kernel_id { PG_K_KINSHIP = 0, PG_K_KINSHIP_REDUCE = 1, PG_K_SWEEP = 2, PG_K_OLS_ITER = 3,
+                    PG_K_PEARSON = 4, PG_K_CHISQ = 5, PG_K_GP_XXT = 6, PG_K_GP_BETA = 7,
+                    PG_K_COUNT = 8 };
+int pg_profile_enable(pg_ctx *ctx, int on);
+int pg_profile_reset(pg_ctx *ctx);
+/* Synchronises, then returns total milliseconds and launch count of one kernel id. */
+int pg_profile_get(pg_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+
+/* ---------------------------------------------------------------------------------------
+ * ols_iter_with_kinship   == gwas::ols_with_covariate (gwas/ols.rs:278-436, numeric core
+ * :291-370; CLI main.rs:280-298).  Staged so that loci can be sharded over GPUs:
+ *   1. pg_kinship_partial_dev : S_r = G_r^T-contraction over this rank's loci (unscaled)
+ *   2. (multi-GPU) all-reduce(sum) of S over ranks -- RCCL via the caller
+ *   3. pg_kinship_set        : K = S / p_total, eigen-decomposition, n_eigenvecs rule,
+ *                               orthonormal basis of [1 | C], projected phenotypes
+ *   4. pg_ols_sweep_dev      : per-column fit of y ~ [1 | C | g], last coefficient
+ * pg_ols_kinship_dev runs 1,3,4 on one GPU.
+ * ------------------------------------------------------------------------------------- */
+/* S_dev: n x n fp64, row-major, full symmetric sum_l g_l g_l^T over this call's p columns. */
+int pg_kinship_partial_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
+                           double *S_dev);
+/* S_dev: the (all-reduced) sum.  force_m < 0 => m by the cumulative-variance rule
+ * (ols.rs:297-311) on eigenvalues sorted descending (the reference's stated intent, :296);
+ * force_m >= 0 overrides it.  Y (host, n x k row-major) must have no NaN (remove_missing is the
+ * caller's job, ols.rs:287).  Outputs (host, optional): m_out, K_out n x n, evals_out n. */
+int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total, int n, const double *Y,
+                   int k, double var_explained, int force_m, int *m_out, double *K_out,
+                   double *evals_out);
+/* Same as pg_kinship_set but with caller-provided covariates C (host, n x m row-major) instead
+ * of kinship eigenvectors; m = 0 gives plain y ~ [1 | g]. */
+int pg_covariates_set(pg_ctx *ctx, int n, const double *C, int m, const double *Y, int k);
+/* beta/var/pval: p x k row-major on the device; NaN where the reference's fit fails. */
+int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
+                     double *beta_dev, double *var_dev, double *pval_dev);
+int pg_ols_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
+                       const double *Y, int k, double var_explained, int force_m, int *m_out,
+                       double *K_out, double *beta_dev, double *var_dev, double *pval_dev);
+/* Host-buffer form (PCIe inclusive): G, beta, var, pval on the host; G is streamed to the GPU in
+ * slabs (two passes over G: kinship, then sweep). */
+int pg_ols_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, const double *Y,
+                   int k, double var_explained, int force_m, int *m_out, double *K_out,
+                   double *beta, double *var, double *pval);
+
+/* ---------------------------------------------------------------------------------------
+ * Sync-derived per-locus operators.  The reference calls these once per text line through
+ * ChunkyReadAnalyseWrite::read_analyse_write (base/structs_and_traits.rs:245-265,
+ * base/sync.rs:864, :674); here one call handles a batch of L parsed loci.
+ * counts: L x n x 6 uint32, locus-major, sync column order A,T,C,G,N,D (base/sync.rs:134).
+ * pool_sizes: host, n (normalised or not -- only ratios are used, sync.rs:266-268).
+ * Outputs are struct-of-arrays with L leading:
+ *   n_out[L]            int32  rows emitted per trait (0 = locus dropped = None)
+ *   allele_ids[L*5]     int32  index into "ATCGND"
+ *   mean_freq[L*5]      double
+ *   stat[L*5*k], pval[L*5*k] double  ([allele][trait])
+ * ------------------------------------------------------------------------------------- */
+/* gwas::ols_iterate (gwas/ols.rs:201-276): stat = beta. */
+int pg_ols_iter_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n,
+                          const double *pool_sizes, const pg_filter *filter, const double *Y, int k,
+                          int32_t *n_out_dev, int32_t *allele_ids_dev, double *mean_freq_dev,
+                          double *stat_dev, double *pval_dev);
+/* gwas::correlation (gwas/correlation_test.rs:73-129): stat = Pearson r (rounded to 7 dp as the
+ * reference's pearsons_correlation returns it, :70). */
+int pg_pearson_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n,
+                         const double *pool_sizes, const pg_filter *filter, const double *Y, int k,
+                         int32_t *n_out_dev, int32_t *allele_ids_dev, double *mean_freq_dev,
+                         double *stat_dev, double *pval_dev);
+/* tables::chisq (tables/chisq_test.rs:5-47): n_out = number of alleles kept (all are listed in
+ * allele_ids), chi2[L], pval[L]. */
+int pg_chisq_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n,
+                       const double *pool_sizes, const pg_filter *filter, int32_t *n_out_dev,
+                       int32_t *allele_ids_dev, double *chi2_dev, double *pval_dev);
+/* Host-buffer forms of the three batch operators (H2D/D2H inside). */
+int pg_ols_iter_batch(pg_ctx *ctx, const uint32_t *counts, int64_t L, int n,
+                      const double *pool_sizes, const pg_filter *filter, const double *Y, int k,
+                      int32_t *n_out, int32_t *allele_ids, double *mean_freq, double *stat,
+                      double *pval);
+int pg_pearson_batch(pg_ctx *ctx, const uint32_t *counts, int64_t L, int n,
+                     const double *pool_sizes, const pg_filter *filter, const double *Y, int k,
+                     int32_t *n_out, int32_t *allele_ids, double *mean_freq, double *stat,
+                     double *pval);
+int pg_chisq_batch(pg_ctx *ctx, const uint32_t *counts, int64_t L, int n, const double *pool_sizes,
+                   const pg_filter *filter, int32_t *n_out, int32_t *allele_ids, double *chi2,
+                   double *pval);
+
+/* ---------------------------------------------------------------------------------------
+ * Genomic prediction: gp::ols (gp/ols.rs:8-101) for the n < p case, b = X^T pinv(X X^T) y,
+ * with X = [1 | G^T] (intercept implicit).  beta_dev: (1+p) x k row-major, row 0 = intercept.
+ * row_idx: host, training rows (the reference's `row_idx: &Vec<usize>`).
+ * pg_gp_xxt_dev exposes the full-data X X^T (n x n, incl. intercept) so that every training
+ * subset's X X^T can be taken as a principal sub-block without another pass over G.
+ * ------------------------------------------------------------------------------------- */
+int pg_gp_xxt_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, double *XXt_dev);
+int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
+                  int k, const int64_t *row_idx, int n_rows, const double *XXt_host_or_null,
+                  double *beta_dev);
+
+/* ---------------------------------------------------------------------------------------
+ * Host-side pieces of the path (O(n^3), n = pools): exported so that they can be validated
+ * without a GPU and reused by a host integration.
+ * ------------------------------------------------------------------------------------- */
+/* Symmetric eigen-decomposition standing in for `kinship.eig()` (gwas/ols.rs:296): eigenvalues
+ * DESCENDING, eigenvectors in the columns of V (n x n row-major; V may be NULL). */
+int pg_host_sym_eig(const double *A, int n, double *evals, double *V);
+/* n_eigenvecs from the cumulative-variance rule, literal (gwas/ols.rs:297-311). */
+int pg_host_n_eigenvecs(const double *evals, int n, double var_explained);
+/* Moore-Penrose pseudo-inverse of a symmetric matrix with the reference tolerance
+ * eps * len(s) * max(s) (base/helpers.rs:463-482). */
+int pg_host_pinv_sym(const double *A, int n, double *out);
+/* Two-sided Student-t p-value for integer df, evaluated by the same finite series the device
+ * code uses (stands in for 2 * (1 - StudentsT::cdf(|t|)), gwas/ols.rs:153). */
+double pg_host_t_two_sided_p(double t_abs, int df);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1145 @@
+/*
+ * poolgen_oracle.c -- CPU restatement of the poolgen per-locus regression hot path.
+ * TEST INFRASTRUCTURE ONLY (see poolgen_oracle.h).  Plain C, sequential arithmetic in the
+ * reference's operation order; compiled with -ffp-contract=off so that no FMA is formed.
+ * Citations are file:line relative to /root/reference.
+ */
+#include "poolgen_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_EPS DBL_EPSILON /* f64::EPSILON */
+
+/* ======================================================================================
+ * statrs 0.16.0 special functions (source not under /root/reference; restated from the
+ * published crate: src/function/gamma.rs, src/function/beta.rs, src/distribution/
+ * {students_t,chi_squared,gamma}.rs).  Pinned by correlation_test.rs:139 and chisq_test.rs:57.
+ * ====================================================================================== */
+static const double GAMMA_R = 10.900511;
+static const double GAMMA_DK[11] = {
+    2.48574089138753565546e-5, 1.05142378581721974210,  -3.45687097222016235469,
+    4.51227709466894823700,    -2.98285225323576655721, 1.05639711577126713077,
+    -1.95428773191645869583e-1, 1.70970543404441224307e-2, -5.71926117404305781283e-4,
+    4.63399473359905636708e-6, -2.71994908488607703910e-9};
+static const double LN_PI = 1.1447298858494001741434273513530587116472948129153;
+static const double LN_2_SQRT_E_OVER_PI = 0.6207822376352452223455184457816472122518527279025978;
+
+/* statrs::function::gamma::ln_gamma (Lanczos, g = 10.900511, n = 11) */
+double orc_ln_gamma(double x) {
+    if (x < 0.5) {
+        double s = GAMMA_DK[0];
+        for (int i = 1; i < 11; i++) s += GAMMA_DK[i] / ((double)i - x);
+        return LN_PI - log(sin(M_PI * x)) - log(s) - LN_2_SQRT_E_OVER_PI -
+               (0.5 - x) * log((0.5 - x + GAMMA_R) / M_E);
+    } else {
+        double s = GAMMA_DK[0];
+        for (int i = 1; i < 11; i++) s += GAMMA_DK[i] / (x + (double)i - 1.0);
+        return log(s) + LN_2_SQRT_E_OVER_PI + (x - 0.5) * log((x - 0.5 + GAMMA_R) / M_E);
+    }
+}
+
+/* approx ulps_eq!(x, 1.0) of the `approx` crate defaults (epsilon = f64::EPSILON, max_ulps 4) */
+static int ulps_eq_one(double x) {
+    if (fabs(x - 1.0) <= ORC_EPS) return 1;
+    int64_t a, b;
+    double one = 1.0;
+    memcpy(&a, &x, 8);
+    memcpy(&b, &one, 8);
+    if ((a < 0) != (b < 0)) return 0;
+    int64_t d = a > b ? a - b : b - a;
+    return d <= 4;
+}
+
+/* statrs::function::beta::checked_beta_reg (modified Lentz continued fraction, <=140 iterations) */
+double orc_beta_reg(double a, double b, double x) {
+    if (!(a > 0.0) || !(b > 0.0) || !(x >= 0.0 && x <= 1.0)) return NAN;
+    double bt;
+    if (x == 0.0 || ulps_eq_one(x)) {
+        bt = 0.0;
+    } else {
+        bt = exp(orc_ln_gamma(a + b) - orc_ln_gamma(a) - orc_ln_gamma(b) + a * log(x) +
+                 b * log(1.0 - x));
+    }
+    int symm = x >= (a + 1.0) / (a + b + 2.0);
+    const double eps = 1.1102230246251565e-16; /* prec::F64_PREC */
+    const double fpmin = DBL_MIN / eps;
+    if (symm) {
+        double swap = a;
+        x = 1.0 - x;
+        a = b;
+        b = swap;
+    }
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0;
+    double d = 1.0 - qab * x / qap;
+    if (fabs(d) < fpmin) d = fpmin;
+    d = 1.0 / d;
+    double h = d;
+    for (int mi = 1; mi < 141; mi++) {
+        double m = (double)mi;
+        double m2 = m * 2.0;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < fpmin) d = fpmin;
+        c = 1.0 + aa / c;
+        if (fabs(c) < fpmin) c = fpmin;
+        d = 1.0 / d;
+        h = h * d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < fpmin) d = fpmin;
+        c = 1.0 + aa / c;
+        if (fabs(c) < fpmin) c = fpmin;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) <= eps) break;
+    }
+    return symm ? 1.0 - bt * h / a : bt * h / a;
+}
+
+/* statrs StudentsT{0,1,nu}.cdf (students_t.rs): h = nu/(nu+x^2), ib = 0.5*I_h(nu/2, 1/2) */
+double orc_students_t_cdf(double x, double freedom) {
+    if (isinf(freedom)) return 0.5 * erfc(-x / M_SQRT2);
+    double k = x;
+    double h = freedom / (freedom + k * k);
+    double ib = 0.5 * orc_beta_reg(freedom / 2.0, 0.5, h);
+    return x <= 0.0 ? ib : 1.0 - ib;
+}
+
+static int almost_eq(double a, double b, double acc) { return fabs(a - b) < acc; }
+
+/* statrs::function::gamma::checked_gamma_lr (Cephes igam/igamc port) */
+double orc_gamma_lr(double a, double x) {
+    if (isnan(a) || isnan(x)) return NAN;
+    if (a <= 0.0 || isinf(a)) return NAN;
+    if (x <= 0.0 || isinf(x)) return NAN;
+    const double eps = 0.000000000000001;
+    const double big = 4503599627370496.0;
+    const double big_inv = 2.22044604925031308085e-16;
+    if (almost_eq(a, 0.0, 1e-15)) return 1.0;
+    if (almost_eq(x, 0.0, 1e-15)) return 0.0;
+    double ax = a * log(x) - x - orc_ln_gamma(a);
+    if (ax < -709.78271289338399) return a < x ? 1.0 : 0.0;
+    if (x <= 1.0 || x <= a) {
+        double r2 = a, c2 = 1.0, ans2 = 1.0;
+        for (;;) {
+            r2 += 1.0;
+            c2 *= x / r2;
+            ans2 += c2;
+            if (c2 / ans2 <= eps) break;
+        }
+        return exp(ax) * ans2 / a;
+    }
+    double y = 1.0 - a;
+    double z = x + y + 1.0;
+    int c = 0;
+    double p3 = 1.0, q3 = x, p2 = x + 1.0, q2 = z * x;
+    double ans = p2 / q2;
+    for (;;) {
+        y += 1.0;
+        z += 2.0;
+        c += 1;
+        double yc = y * (double)c;
+        double p = p2 * z - p3 * yc;
+        double q = q2 * z - q3 * yc;
+        p3 = p2; p2 = p; q3 = q2; q2 = q;
+        if (fabs(p) > big) { p3 *= big_inv; p2 *= big_inv; q3 *= big_inv; q2 *= big_inv; }
+        if (q != 0.0) {
+            double nextans = p / q;
+            double error = fabs((ans - nextans) / nextans);
+            ans = nextans;
+            if (error <= eps) break;
+        }
+    }
+    return 1.0 - exp(ax) * ans;
+}
+
+/* statrs ChiSquared{df}.cdf = Gamma{shape df/2, rate 1/2}.cdf(x) = gamma_lr(df/2, x/2) */
+double orc_chisq_cdf(double x, double freedom) {
+    if (x <= 0.0) return 0.0;
+    if (isinf(x)) return 1.0;
+    return orc_gamma_lr(freedom / 2.0, x * 0.5);
+}
+
+/* ======================================================================================
+ * helpers.rs
+ * ====================================================================================== */
+/* sensible_round (helpers.rs:103-108): (x * 10^d).round() / 10^d, round = half away from zero */
+double orc_sensible_round(double x, int n_digits) {
+    char tmp[16];
+    snprintf(tmp, sizeof tmp, "1e%d", n_digits);
+    double factor = strtod(tmp, NULL);
+    return round(x * factor) / factor;
+}
+
+/* Rust `impl Display for f64`: shortest round-trip digits, positional (never exponent) */
+int orc_fmt_display(double x, char *buf, int cap) {
+    if (isnan(x)) return snprintf(buf, cap, "NaN");
+    if (isinf(x)) return snprintf(buf, cap, x > 0 ? "inf" : "-inf");
+    if (x == 0.0) return snprintf(buf, cap, signbit(x) ? "-0" : "0");
+    char e[40];
+    int prec;
+    for (prec = 1; prec <= 17; prec++) {
+        snprintf(e, sizeof e, "%.*e", prec - 1, x);
+        if (strtod(e, NULL) == x) break;
+    }
+    /* e = [-]d[.ddd]e[+-]XX */
+    char digits[24];
+    int nd = 0, neg = 0;
+    const char *s = e;
+    if (*s == '-') { neg = 1; s++; }
+    while (*s && *s != 'e') {
+        if (*s != '.') digits[nd++] = *s;
+        s++;
+    }
+    int exp10 = atoi(s + 1);
+    while (nd > 1 && digits[nd - 1] == '0') nd--;
+    char out[400];
+    int o = 0;
+    if (neg) out[o++] = '-';
+    if (exp10 >= 0) {
+        for (int i = 0; i <= exp10; i++) out[o++] = i < nd ? digits[i] : '0';
+        if (nd > exp10 + 1) {
+            out[o++] = '.';
+            for (int i = exp10 + 1; i < nd; i++) out[o++] = digits[i];
+        }
+    } else {
+        out[o++] = '0';
+        out[o++] = '.';
+        for (int i = 0; i < -exp10 - 1; i++) out[o++] = '0';
+        for (int i = 0; i < nd; i++) out[o++] = digits[i];
+    }
+    out[o] = 0;
+    return snprintf(buf, cap, "%s", out);
+}
+
+/* parse_f64_roundup_and_own (helpers.rs:111-117) */
+int orc_parse_f64_roundup_and_own(double x, int n_digits, char *buf, int cap) {
+    char s[400];
+    int len = orc_fmt_display(x, s, sizeof s);
+    if (len < n_digits) return snprintf(buf, cap, "%s", s);
+    return orc_fmt_display(orc_sensible_round(x, n_digits), buf, cap);
+}
+
+/* ndarray 0.15 `sum()` on a contiguous slice: numeric_util::unrolled_fold (8 lanes) */
+double orc_ndarray_sum(const double *x, int64_t len) {
+    double acc = 0.0, p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t i = 0;
+    while (len - i >= 8) {
+        for (int j = 0; j < 8; j++) p[j] = p[j] + x[i + j];
+        i += 8;
+    }
+    acc = acc + (p[0] + p[4]);
+    acc = acc + (p[1] + p[5]);
+    acc = acc + (p[2] + p[6]);
+    acc = acc + (p[3] + p[7]);
+    for (; i < len; i++) acc = acc + x[i];
+    return acc;
+}
+
+/* ndarray 0.15 1-D dot: numeric_util::unrolled_dot */
+static double unrolled_dot(const double *x, const double *y, int64_t len) {
+    double sum = 0.0, p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t i = 0;
+    while (len - i >= 8) {
+        for (int j = 0; j < 8; j++) p[j] = p[j] + x[i + j] * y[i + j];
+        i += 8;
+    }
+    sum = sum + (p[0] + p[4]);
+    sum = sum + (p[1] + p[5]);
+    sum = sum + (p[2] + p[6]);
+    sum = sum + (p[3] + p[7]);
+    for (; i < len; i++) sum = sum + x[i] * y[i];
+    return sum;
+}
+
+/* mean_array1_ignore_nan (helpers.rs:258-264) */
+double orc_mean_ignore_nan(const double *x, int64_t len, int64_t stride) {
+    double sum = 0.0, cnt = 0.0;
+    for (int64_t i = 0; i < len; i++) {
+        double a = x[i * stride];
+        if (!isnan(a)) { sum = sum + a; cnt += 1.0; }
+    }
+    return sum / cnt;
+}
+
+/* ======================================================================================
+ * dense linear algebra standing in for ndarray-linalg 0.16 / LAPACK
+ * ====================================================================================== */
+/* LU with partial pivoting (dgetf2 order: first max |a| in the column).  Returns 0, or k+1 for
+ * an exactly zero pivot at step k (LAPACK info>0, which makes `.inv()` return Err). */
+static int lu_factor(double *a, int n, int *piv, int *sign) {
+    *sign = 1;
+    int info = 0;
+    for (int k = 0; k < n; k++) {
+        int pi = k;
+        double pm = fabs(a[k * n + k]);
+        for (int i = k + 1; i < n; i++) {
+            double v = fabs(a[i * n + k]);
+            if (v > pm) { pm = v; pi = i; }
+        }
+        piv[k] = pi;
+        if (a[pi * n + k] != 0.0) {
+            if (pi != k) {
+                for (int j = 0; j < n; j++) {
+                    double t = a[k * n + j]; a[k * n + j] = a[pi * n + j]; a[pi * n + j] = t;
+                }
+                *sign = -*sign;
+            }
+            double inv = 1.0 / a[k * n + k];
+            for (int i = k + 1; i < n; i++) a[i * n + k] *= inv;
+        } else if (info == 0) {
+            info = k + 1;
+        }
+        for (int i = k + 1; i < n; i++) {
+            double l = a[i * n + k];
+            if (l != 0.0)
+                for (int j = k + 1; j < n; j++) a[i * n + j] -= l * a[k * n + j];
+        }
+    }
+    return info;
+}
+
+/* `.inv()` (dgetrf + dgetri): Err when a pivot is exactly zero (gwas/ols.rs:68-71, 77-80) */
+int orc_lu_inverse(const double *a, int n, double *inv) {
+    double *lu = (double *)malloc(sizeof(double) * n * n);
+    int *piv = (int *)malloc(sizeof(int) * n);
+    int sign;
+    memcpy(lu, a, sizeof(double) * n * n);
+    int info = lu_factor(lu, n, piv, &sign);
+    if (info != 0) { free(lu); free(piv); return -1; }
+    /* solve A X = I column by column: P A = L U */
+    double *col = (double *)malloc(sizeof(double) * n);
+    for (int c = 0; c < n; c++) {
+        for (int i = 0; i < n; i++) col[i] = (i == c) ? 1.0 : 0.0;
+        for (int k = 0; k < n; k++) {
+            if (piv[k] != k) { double t = col[k]; col[k] = col[piv[k]]; col[piv[k]] = t; }
+        }
+        for (int i = 0; i < n; i++) {
+            double s = col[i];
+            for (int j = 0; j < i; j++) s -= lu[i * n + j] * col[j];
+            col[i] = s;
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = col[i];
+            for (int j = i + 1; j < n; j++) s -= lu[i * n + j] * col[j];
+            col[i] = s / lu[i * n + i];
+        }
+        for (int i = 0; i < n; i++) inv[i * n + c] = col[i];
+    }
+    free(col); free(lu); free(piv);
+    return 0;
+}
+
+/* `.det()`: product of U's diagonal times the permutation sign; singular factorisation -> 0 */
+double orc_lu_det(const double *a, int n) {
+    double *lu = (double *)malloc(sizeof(double) * n * n);
+    int *piv = (int *)malloc(sizeof(int) * n);
+    int sign;
+    memcpy(lu, a, sizeof(double) * n * n);
+    int info = lu_factor(lu, n, piv, &sign);
+    double d = 0.0;
+    if (info == 0) {
+        d = (double)sign;
+        for (int i = 0; i < n; i++) d *= lu[i * n + i];
+    }
+    free(lu); free(piv);
+    return d;
+}
+
+/* Cyclic Jacobi for a symmetric matrix; eigenvalues DESCENDING, eigenvectors = columns of v.
+ * The reference calls the general `.eig()` (dgeev) and assumes descending order
+ * (gwas/ols.rs:296 comment); LAPACK's actual order is build-dependent, so the oracle (and the
+ * product) implement the documented intent. */
+int orc_sym_eig(const double *a_in, int n, double *evals, double *v) {
+    double *a = (double *)malloc(sizeof(double) * n * n);
+    memcpy(a, a_in, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; i++) {
+            diag += a[i * n + i] * a[i * n + i];
+            for (int j = i + 1; j < n; j++) off += a[i * n + j] * a[i * n + j];
+        }
+        if (off <= 1e-32 * (diag + off) || off == 0.0) break;
+        for (int p = 0; p < n - 1; p++) {
+            for (int q = p + 1; q < n; q++) {
+                double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                double app = a[p * n + p], aqq = a[q * n + q];
+                double theta = (aqq - app) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq;
+                    a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk;
+                    a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s * vkq;
+                    v[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+    /* sort descending (selection sort, swapping columns) */
+    for (int i = 0; i < n; i++) evals[i] = a[i * n + i];
+    for (int i = 0; i < n - 1; i++) {
+        int mx = i;
+        for (int j = i + 1; j < n; j++)
+            if (evals[j] > evals[mx]) mx = j;
+        if (mx != i) {
+            double t = evals[i]; evals[i] = evals[mx]; evals[mx] = t;
+            for (int k = 0; k < n; k++) {
+                double u = v[k * n + i]; v[k * n + i] = v[k * n + mx]; v[k * n + mx] = u;
+            }
+        }
+    }
+    free(a);
+    return 0;
+}
+
+/* pinv (helpers.rs:463-482) for a symmetric PSD-ish input (X X^T or X^T X): for a symmetric
+ * matrix the SVD is U = V*sign, s = |lambda|; tolerance = eps * len(s) * max(s); singular values
+ * <= tolerance are zeroed. */
+int orc_pinv_sym(const double *a, int n, double *out) {
+    double *ev = (double *)malloc(sizeof(double) * n);
+    double *v = (double *)malloc(sizeof(double) * n * n);
+    orc_sym_eig(a, n, ev, v);
+    double smax = 0.0;
+    for (int i = 0; i < n; i++)
+        if (fabs(ev[i]) > smax) smax = fabs(ev[i]);
+    double tol = ORC_EPS * (double)n * smax;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) out[i * n + j] = 0.0;
+    for (int e = 0; e < n; e++) {
+        if (fabs(ev[e]) > tol) {
+            double w = 1.0 / ev[e];
+            for (int i = 0; i < n; i++) {
+                double vi = v[i * n + e] * w;
+                for (int j = 0; j < n; j++) out[i * n + j] += vi * v[j * n + e];
+            }
+        }
+    }
+    free(ev); free(v);
+    return 0;
+}
+
+/* ======================================================================================
+ * base/sync.rs
+ * ====================================================================================== */
+static const char ALLELES[6] = {'A', 'T', 'C', 'G', 'N', 'D'}; /* sync.rs:134 reader order */
+
+/* String::lparse -> LocusCounts (sync.rs:100-156) */
+int orc_parse_sync_line(const char *line_in, char *chrom, int chrom_cap, uint64_t *pos,
+                        uint64_t *counts, int max_pools) {
+    size_t len = strlen(line_in);
+    char *line = (char *)malloc(len + 1);
+    memcpy(line, line_in, len + 1);
+    if (len && line[len - 1] == '\n') { line[--len] = 0; if (len && line[len - 1] == '\r') line[--len] = 0; }
+    if (len == 0) { free(line); return -2; }
+    if (line[0] == '#') { free(line); return 0; }
+    int field = 0, n = 0, rc = 0;
+    char *p = line;
+    while (p) {
+        char *tab = strchr(p, '\t');
+        if (tab) *tab = 0;
+        if (field == 0) {
+            snprintf(chrom, chrom_cap, "%s", p);
+        } else if (field == 1) {
+            char *end;
+            if (*p == 0 || *p == '-' ) { rc = -3; break; }
+            *pos = strtoull(p, &end, 10);
+            if (*end != 0) { rc = -3; break; }
+        } else if (field >= 3) {
+            if (n >= max_pools) { rc = -4; break; }
+            char *q = p;
+            int j = 0;
+            while (q && j < 6) {
+                char *colon = strchr(q, ':');
+                if (colon) *colon = 0;
+                char *end;
+                if (*q == 0) { rc = -5; break; }
+                uint64_t v = strtoull(q, &end, 10);
+                if (*end != 0) { rc = -5; break; }
+                counts[n * 6 + j] = v;
+                j++;
+                q = colon ? colon + 1 : NULL;
+            }
+            if (rc) break;
+            if (j < 6) { rc = -5; break; }
+            n++;
+        }
+        field++;
+        p = tab ? tab + 1 : NULL;
+    }
+    free(line);
+    if (rc) return rc;
+    return n;
+}
+
+/* LocusCounts::to_frequencies (sync.rs:166-192) */
+void orc_to_frequencies(const uint64_t *counts, int n, int a, double *freq) {
+    for (int i = 0; i < n; i++) {
+        double rs = 0.0;
+        for (int j = 0; j < a; j++) rs = rs + (double)counts[i * a + j];
+        for (int j = 0; j < a; j++)
+            freq[i * a + j] = (rs == 0.0) ? NAN : (double)counts[i * a + j] / rs;
+    }
+}
+
+/* LocusCounts::filter (sync.rs:195-303) */
+int orc_filter_locus(const uint64_t *counts, int n, const double *pool_sizes, const orc_filter *f,
+                     int *allele_ids, uint64_t *out_counts) {
+    int ids[6], a = 0;
+    for (int j = 0; j < 6; j++)
+        if (!(f->remove_ns && ALLELES[j] == 'N')) ids[a++] = j; /* :200-213 */
+    /* minimum coverage (:217-229) */
+    double min_cov = 0.0;
+    for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int j = 0; j < a; j++) s = s + (double)counts[i * 6 + ids[j]];
+        if (i == 0 || s < min_cov) min_cov = s;
+    }
+    if (min_cov < (double)f->min_coverage_depth) return 0;
+    /* frequencies over the remaining columns (:242-250) */
+    double *fr = (double *)malloc(sizeof(double) * n * 6);
+    for (int i = 0; i < n; i++) {
+        double rs = 0.0;
+        for (int j = 0; j < a; j++) rs = rs + (double)counts[i * 6 + ids[j]];
+        for (int j = 0; j < a; j++)
+            fr[i * 6 + j] = (rs == 0.0) ? NAN : (double)counts[i * 6 + ids[j]] / rs;
+    }
+    /* pool-size weighted allele frequency (:258-282); the weight is recomputed per term as
+     * pool_sizes[i] / sum(pool_sizes) exactly as written */
+    double total = 0.0;
+    for (int i = 0; i < n; i++) total = total + pool_sizes[i];
+    int keep[6], nk = 0;
+    for (int j = 0; j < a; j++) {
+        double q = 0.0;
+        for (int i = 0; i < n; i++) {
+            double v = fr[i * 6 + j];
+            q += isnan(v) ? 0.0 : v * (pool_sizes[i] / total);
+        }
+        if ((q < f->min_allele_frequency) | (q > (1.00 - f->min_allele_frequency))) continue;
+        keep[nk++] = j;
+    }
+    if (nk < 2) { free(fr); return 0; } /* :284-286 */
+    int n_missing = 0;                  /* :288-299, first remaining allele */
+    for (int i = 0; i < n; i++)
+        if (isnan(fr[i * 6 + keep[0]])) n_missing++;
+    free(fr);
+    if (n_missing == n) return 0;
+    if (((double)n_missing / (double)n) > f->max_missingness_rate) return 0;
+    for (int j = 0; j < nk; j++) allele_ids[j] = ids[keep[j]];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < nk; j++) out_counts[i * nk + j] = counts[i * 6 + ids[keep[j]]];
+    return nk;
+}
+
+/* LocusFrequencies::sort_by_allele_freq (sync.rs:477-506): stable sort of the columns on the
+ * NaN-ignoring column sums */
+void orc_sort_by_allele_freq(double *freq, int n, int a, int *allele_ids, int decreasing) {
+    double cs[6];
+    int idx[6];
+    for (int j = 0; j < a; j++) {
+        double s = 0.0;
+        for (int i = 0; i < n; i++)
+            if (!isnan(freq[i * a + j])) s = s + freq[i * a + j];
+        cs[j] = s;
+        idx[j] = j;
+    }
+    for (int i = 1; i < a; i++) { /* stable insertion sort */
+        int t = idx[i], j = i - 1;
+        while (j >= 0 && (decreasing ? cs[idx[j]] < cs[t] : cs[idx[j]] > cs[t])) {
+            idx[j + 1] = idx[j];
+            j--;
+        }
+        idx[j + 1] = t;
+    }
+    double *tmp = (double *)malloc(sizeof(double) * n * a);
+    int ids2[6];
+    for (int j = 0; j < a; j++) {
+        ids2[j] = allele_ids[idx[j]];
+        for (int i = 0; i < n; i++) tmp[i * a + j] = freq[i * a + idx[j]];
+    }
+    memcpy(freq, tmp, sizeof(double) * n * a);
+    memcpy(allele_ids, ids2, sizeof(int) * a);
+    free(tmp);
+}
+
+/* ======================================================================================
+ * gwas/ols.rs
+ * ====================================================================================== */
+/* estimate_effects / estimate_variances / estimate_significance (ols.rs:58-160) */
+int orc_ols_fit(const double *X, const double *y, int n, int P, double *b, double *v_b, double *t,
+                double *pval) {
+    int rc = 0;
+    double *e = (double *)malloc(sizeof(double) * n);
+    if (n < P) {
+        /* ols.rs:67-75: inv(X X^T); b = (X^T inv) y */
+        double *xxt = (double *)malloc(sizeof(double) * n * n);
+        double *inv = (double *)malloc(sizeof(double) * n * n);
+        double *m = (double *)malloc(sizeof(double) * P * n);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                double s = 0.0;
+                for (int c = 0; c < P; c++) s = s + X[i * P + c] * X[j * P + c];
+                xxt[i * n + j] = s;
+            }
+        if (orc_lu_inverse(xxt, n, inv) != 0 || orc_lu_det(inv, n) == 0.0) {
+            rc = -1;
+        } else {
+            for (int c = 0; c < P; c++)
+                for (int j = 0; j < n; j++) {
+                    double s = 0.0;
+                    for (int i = 0; i < n; i++) s = s + X[i * P + c] * inv[i * n + j];
+                    m[c * n + j] = s;
+                }
+            for (int c = 0; c < P; c++) b[c] = unrolled_dot(&m[c * n], y, n);
+            for (int i = 0; i < n; i++) e[i] = y[i] - unrolled_dot(&X[i * P], b, P);
+            double ve = unrolled_dot(e, e, n) / ((double)n - (double)P); /* ols.rs:103 */
+            /* vcv = ve * X^T inv inv X (ols.rs:105-109); only the diagonal is used */
+            double *m2 = (double *)malloc(sizeof(double) * P * n);
+            for (int c = 0; c < P; c++)
+                for (int j = 0; j < n; j++) {
+                    double s = 0.0;
+                    for (int i = 0; i < n; i++) s = s + m[c * n + i] * inv[i * n + j];
+                    m2[c * n + j] = s;
+                }
+            for (int c = 0; c < P; c++) {
+                double s = 0.0;
+                for (int i = 0; i < n; i++) s = s + m2[c * n + i] * X[i * P + c];
+                v_b[c] = ve * s;
+            }
+            free(m2);
+        }
+        free(xxt); free(inv); free(m);
+    } else {
+        /* ols.rs:77-84: inv(X^T X); b = (inv X^T) y */
+        double *xtx = (double *)malloc(sizeof(double) * P * P);
+        double *inv = (double *)malloc(sizeof(double) * P * P);
+        double *m = (double *)malloc(sizeof(double) * P * n);
+        for (int r = 0; r < P; r++)
+            for (int c = 0; c < P; c++) {
+                double s = 0.0;
+                for (int i = 0; i < n; i++) s = s + X[i * P + r] * X[i * P + c];
+                xtx[r * P + c] = s;
+            }
+        if (orc_lu_inverse(xtx, P, inv) != 0 || orc_lu_det(inv, P) == 0.0) {
+            rc = -1;
+        } else {
+            for (int r = 0; r < P; r++)
+                for (int i = 0; i < n; i++) {
+                    double s = 0.0;
+                    for (int c = 0; c < P; c++) s = s + inv[r * P + c] * X[i * P + c];
+                    m[r * n + i] = s;
+                }
+            for (int r = 0; r < P; r++) b[r] = unrolled_dot(&m[r * n], y, n);
+            for (int i = 0; i < n; i++) e[i] = y[i] - unrolled_dot(&X[i * P], b, P);
+            double ve = unrolled_dot(e, e, n) / ((double)n - (double)P); /* ols.rs:102-103 */
+            for (int r = 0; r < P; r++) v_b[r] = ve * inv[r * P + r];      /* ols.rs:111-116 */
+        }
+        free(xtx); free(inv); free(m);
+    }
+    free(e);
+    if (rc) return rc;
+    /* ols.rs:139-158: df = n - 1 */
+    for (int i = 0; i < P; i++) {
+        t[i] = (fabs(b[i]) <= ORC_EPS) ? 0.0 : b[i] / sqrt(v_b[i]);
+        if (fabs(t[i]) <= ORC_EPS) pval[i] = 1.0;
+        else if (isnan(t[i])) pval[i] = 1.0;
+        else pval[i] = 2.00 * (1.00 - orc_students_t_cdf(fabs(t[i]), (double)n - 1.0));
+    }
+    return 0;
+}
+
+/* remove_missing (sync.rs:508-549): indices of pools whose phenotype row mean is not NaN */
+static int pools_with_phenotypes(const double *Y, int n, int k, int *idx) {
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int j = 0; j < k; j++) s = s + Y[i * k + j];
+        if (!isnan(s / (double)k)) idx[m++] = i;
+    }
+    return m;
+}
+
+/* ols_iterate (ols.rs:201-276), numeric part */
+int orc_ols_iterate_locus(const uint64_t *counts, int n, const double *Y, int k,
+                          const double *pool_sizes, const orc_filter *f, orc_locus_hdr *hdr,
+                          double *beta, double *pval) {
+    hdr->n_alleles = 0;
+    int *idx = (int *)malloc(sizeof(int) * n);
+    int n2 = pools_with_phenotypes(Y, n, k, idx);
+    if (n2 != n) {
+        /* quirk: the reference shrinks the counts matrix but not FilterStats.pool_sizes, so the
+         * assert at sync.rs:254-257 panics the worker; the restatement reports it as "dropped". */
+        free(idx);
+        return -1;
+    }
+    free(idx);
+    int ids[6];
+    uint64_t *fc = (uint64_t *)malloc(sizeof(uint64_t) * n * 6);
+    int a = orc_filter_locus(counts, n, pool_sizes, f, ids, fc);
+    if (a == 0) { free(fc); return 0; }
+    double *fr = (double *)malloc(sizeof(double) * n * a);
+    orc_to_frequencies(fc, n, a, fr);
+    orc_sort_by_allele_freq(fr, n, a, ids, 1); /* ols.rs:222 */
+    int P = a;                                 /* intercept + (a-1) alleles, ols.rs:227-246 */
+    double *X = (double *)malloc(sizeof(double) * n * P);
+    for (int i = 0; i < n; i++) {
+        X[i * P] = 1.0;
+        for (int j = 1; j < P; j++) X[i * P + j] = fr[i * a + j];
+    }
+    double *b = (double *)malloc(sizeof(double) * P * 4);
+    double *y = (double *)malloc(sizeof(double) * n);
+    int ok = 1;
+    for (int j = 0; j < k && ok; j++) { /* ols(), ols.rs:163-199 */
+        for (int i = 0; i < n; i++) y[i] = Y[i * k + j];
+        if (orc_ols_fit(X, y, n, P, b, b + P, b + 2 * P, b + 3 * P) != 0) { ok = 0; break; }
+        for (int i = 1; i < P; i++) {
+            beta[(i - 1) * k + j] = b[i];
+            pval[(i - 1) * k + j] = b[3 * P + i];
+        }
+    }
+    if (ok) {
+        hdr->n_alleles = P - 1;
+        for (int i = 1; i < P; i++) {
+            hdr->allele_ids[i - 1] = ids[i];
+            double s = 0.0; /* x_matrix.column(i).mean() (ols.rs:266): sequential sum / n */
+            for (int r = 0; r < n; r++) s = s + X[r * P + i];
+            hdr->mean_freq[i - 1] = s / (double)n;
+        }
+    }
+    free(fc); free(fr); free(X); free(b); free(y);
+    return ok ? P - 1 : 0;
+}
+
+/* CSV fragment of ols_iterate (ols.rs:255-275) */
+int orc_ols_iterate_csv(const char *chrom, uint64_t pos, const uint64_t *counts, int n,
+                        const double *Y, int k, const double *pool_sizes, const orc_filter *f,
+                        char *out, int cap) {
+    orc_locus_hdr h;
+    double *beta = (double *)malloc(sizeof(double) * 5 * k * 2);
+    double *pv = beta + 5 * k;
+    int na = orc_ols_iterate_locus(counts, n, Y, k, pool_sizes, f, &h, beta, pv);
+    int o = 0;
+    if (na > 0) {
+        char s1[400], s2[400], s3[400];
+        for (int i = 0; i < na; i++)
+            for (int j = 0; j < k; j++) {
+                orc_parse_f64_roundup_and_own(h.mean_freq[i], 8, s1, sizeof s1);
+                orc_parse_f64_roundup_and_own(beta[i * k + j], 6, s2, sizeof s2);
+                orc_parse_f64_roundup_and_own(pv[i * k + j], 12, s3, sizeof s3);
+                o += snprintf(out + o, cap - o, "%s,%llu,%c,%s,Pheno_%d,%s,%s\n", chrom,
+                              (unsigned long long)pos, ALLELES[h.allele_ids[i]], s1, j, s2, s3);
+            }
+    }
+    free(beta);
+    return na > 0 ? o : 0;
+}
+
+/* n_eigenvecs rule (ols.rs:297-311), literal, on eigenvalues in the given order */
+int orc_n_eigenvecs_rule(const double *ev, int n, double threshold) {
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) sum = sum + ev[i];
+    double *cum = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) cum[i] = ev[i] / sum;
+    int m = n;
+    for (int i = 1; i < n; i++) {
+        cum[i] = cum[i - 1] + cum[i];
+        if ((cum[i - 1] >= threshold) & (i - 1 < m)) m = i - 1;
+    }
+    free(cum);
+    return m;
+}
+
+/* kinship = G G^T / p (ols.rs:291-295).  G locus-major (p x n, ld). */
+void orc_kinship(const double *G, int64_t p, int n, int64_t ld, double *K, int n_threads) {
+    int nt = 1;
+#ifdef _OPENMP
+    nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+#endif
+    (void)n_threads;
+    double *part = (double *)calloc((size_t)nt * n * n, sizeof(double));
+#pragma omp parallel num_threads(nt)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double *kp = part + (size_t)tid * n * n;
+#pragma omp for schedule(static)
+        for (int64_t l = 0; l < p; l++) {
+            const double *g = G + l * ld;
+            for (int i = 0; i < n; i++) {
+                double gi = g[i];
+                double *row = kp + (size_t)i * n;
+                for (int j = 0; j < n; j++) row[j] += gi * g[j];
+            }
+        }
+    }
+    for (int i = 0; i < n * n; i++) {
+        double s = 0.0;
+        for (int t = 0; t < nt; t++) s += part[(size_t)t * n * n + i];
+        K[i] = s / (double)p;
+    }
+    free(part);
+}
+
+/* ols_with_covariate numeric core (ols.rs:291-370) */
+int orc_ols_with_covariate(const double *G, int64_t p, int n, int64_t ld, const double *Y, int k,
+                           double var_explained, int force_m, const double *covariate_in,
+                           double *K_out, double *evals_out, double *cov_out, double *beta,
+                           double *var, double *pval, int n_threads) {
+    int m;
+    double *C = NULL;
+    if (covariate_in && force_m >= 0) {
+        m = force_m;
+        C = (double *)malloc(sizeof(double) * n * (m > 0 ? m : 1));
+        memcpy(C, covariate_in, sizeof(double) * n * m);
+    } else {
+        double *K = (double *)malloc(sizeof(double) * n * n);
+        double *ev = (double *)malloc(sizeof(double) * n);
+        double *V = (double *)malloc(sizeof(double) * n * n);
+        orc_kinship(G, p, n, ld, K, n_threads);
+        orc_sym_eig(K, n, ev, V);
+        m = force_m >= 0 ? force_m : orc_n_eigenvecs_rule(ev, n, var_explained);
+        C = (double *)malloc(sizeof(double) * n * (m > 0 ? m : 1));
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < m; j++) C[i * m + j] = V[i * n + j]; /* ols.rs:312-315 */
+        if (K_out) memcpy(K_out, K, sizeof(double) * n * n);
+        if (evals_out) memcpy(evals_out, ev, sizeof(double) * n);
+        free(K); free(ev); free(V);
+    }
+    if (cov_out) memcpy(cov_out, C, sizeof(double) * n * m);
+    int P = m + 2;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+#endif
+#pragma omp parallel num_threads(nt)
+    {
+        double *X = (double *)malloc(sizeof(double) * n * P);
+        double *y = (double *)malloc(sizeof(double) * n);
+        double *r = (double *)malloc(sizeof(double) * P * 4);
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < p; i++) {
+            for (int j = 0; j < k; j++) { /* one cell (i, j), ols.rs:345-370 */
+                for (int i_ = 0; i_ < n; i_++) {
+                    X[i_ * P] = 1.0;
+                    for (int j_ = 1; j_ < m + 1; j_++) X[i_ * P + j_] = C[i_ * m + j_ - 1];
+                    X[i_ * P + m + 1] = G[i * ld + i_];
+                    y[i_] = Y[i_ * k + j];
+                }
+                if (orc_ols_fit(X, y, n, P, r, r + P, r + 2 * P, r + 3 * P) == 0) {
+                    beta[i * k + j] = r[m + 1];
+                    var[i * k + j] = r[P + m + 1];
+                    pval[i * k + j] = r[3 * P + m + 1];
+                } else {
+                    beta[i * k + j] = NAN; var[i * k + j] = NAN; pval[i * k + j] = NAN;
+                }
+            }
+        }
+        free(X); free(y); free(r);
+    }
+    free(C);
+    return m;
+}
+
+/* ======================================================================================
+ * gwas/correlation_test.rs
+ * ====================================================================================== */
+/* pearsons_correlation (correlation_test.rs:7-71), method = "sensible_corr" */
+void orc_pearsons_correlation(const double *x, int64_t sx, const double *y, int64_t sy, int n,
+                              double *r_out, double *p_out) {
+    double *xf = (double *)malloc(sizeof(double) * (n > 0 ? n : 1) * 4);
+    double *yf = xf + n, *xx = xf + 2 * n, *yy = xf + 3 * n;
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        double a = x[i * sx], b = y[i * sy];
+        if (!isnan(a) && !isnan(b)) { xf[m] = a; yf[m] = b; m++; }
+    }
+    double mu_x = orc_mean_ignore_nan(xf, m, 1), mu_y = orc_mean_ignore_nan(yf, m, 1);
+    for (int i = 0; i < m; i++) {
+        double dx = xf[i] - mu_x, dy = yf[i] - mu_y;
+        xx[i] = dx * dx; yy[i] = dy * dy; xf[i] = dx * dy;
+    }
+    double numerator = orc_ndarray_sum(xf, m);
+    double denominator = sqrt(orc_ndarray_sum(xx, m)) * sqrt(orc_ndarray_sum(yy, m));
+    free(xf);
+    double r = numerator / denominator;
+    if (isnan(r)) { *r_out = NAN; *p_out = NAN; return; }
+    double sden = (1.0 - r * r) / ((double)n - 2.0);
+    if (sden <= 0.0) { *r_out = r; *p_out = ORC_EPS; return; }
+    double t = r / sqrt(sden);
+    double pv = (n > 2) ? 2.00 * (1.00 - orc_students_t_cdf(fabs(t), (double)n - 2.0)) : NAN;
+    *r_out = orc_sensible_round(r, 7);
+    *p_out = pv;
+}
+
+/* correlation operator (correlation_test.rs:73-129), numeric part */
+int orc_correlation_locus(const uint64_t *counts, int n, const double *Y, int k,
+                          const double *pool_sizes, const orc_filter *f, orc_locus_hdr *hdr,
+                          double *corr, double *pval) {
+    hdr->n_alleles = 0;
+    int ids[6];
+    uint64_t *fc = (uint64_t *)malloc(sizeof(uint64_t) * n * 6);
+    int a = orc_filter_locus(counts, n, pool_sizes, f, ids, fc);
+    if (a == 0) { free(fc); return 0; }
+    double *fr = (double *)malloc(sizeof(double) * n * a);
+    orc_to_frequencies(fc, n, a, fr);
+    int p = a >= 2 ? a - 1 : a; /* drop the LAST column, unsorted (:95-98) */
+    for (int i = 0; i < p; i++) {
+        hdr->allele_ids[i] = ids[i];
+        double s = 0.0;
+        for (int r = 0; r < n; r++) s = s + fr[r * a + i];
+        hdr->mean_freq[i] = s / (double)n;
+        for (int j = 0; j < k; j++)
+            orc_pearsons_correlation(fr + i, a, Y + j, k, n, &corr[i * k + j], &pval[i * k + j]);
+    }
+    hdr->n_alleles = p;
+    free(fc); free(fr);
+    return p;
+}
+
+int orc_correlation_csv(const char *chrom, uint64_t pos, const uint64_t *counts, int n,
+                        const double *Y, int k, const double *pool_sizes, const orc_filter *f,
+                        char *out, int cap) {
+    orc_locus_hdr h;
+    double *c = (double *)malloc(sizeof(double) * 5 * k * 2);
+    double *pv = c + 5 * k;
+    int na = orc_correlation_locus(counts, n, Y, k, pool_sizes, f, &h, c, pv);
+    int o = 0;
+    char s1[400], s2[400], s3[400];
+    for (int i = 0; i < na; i++)
+        for (int j = 0; j < k; j++) {
+            orc_fmt_display(h.mean_freq[i], s1, sizeof s1);
+            orc_parse_f64_roundup_and_own(c[i * k + j], 6, s2, sizeof s2);
+            orc_fmt_display(pv[i * k + j], s3, sizeof s3);
+            o += snprintf(out + o, cap - o, "%s,%llu,%c,%s,Pheno_%d,%s,%s\n", chrom,
+                          (unsigned long long)pos, ALLELES[h.allele_ids[i]], s1, j, s2, s3);
+        }
+    free(c);
+    return o;
+}
+
+/* ======================================================================================
+ * tables/chisq_test.rs
+ * ====================================================================================== */
+int orc_chisq_locus(const uint64_t *counts, int n, const double *pool_sizes, const orc_filter *f,
+                    int *allele_ids, double *chi2_out, double *pval_out) {
+    uint64_t *fc = (uint64_t *)malloc(sizeof(uint64_t) * n * 6);
+    int a = orc_filter_locus(counts, n, pool_sizes, f, allele_ids, fc);
+    if (a == 0) { free(fc); return 0; }
+    double *fr = (double *)malloc(sizeof(double) * n * a);
+    orc_to_frequencies(fc, n, a, fr);
+    double t = (double)(n * a);                 /* :17 */
+    double total = orc_ndarray_sum(fr, (int64_t)n * a); /* matrix.sum(), :18 */
+    double rs[1], *row_sums = (double *)malloc(sizeof(double) * n);
+    (void)rs;
+    double cs[6];
+    for (int i = 0; i < n; i++) row_sums[i] = orc_ndarray_sum(fr + i * a, a); /* lane.sum() */
+    for (int j = 0; j < a; j++) cs[j] = 0.0;
+    for (int i = 0; i < n; i++) /* sum_axis(Axis(0)): res = res + row */
+        for (int j = 0; j < a; j++) cs[j] = cs[j] + fr[i * a + j];
+    double chi2 = 0.0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < a; j++) {
+            double observed = fr[i * a + j];
+            double expected = (row_sums[i] * cs[j]) / total;
+            double d = observed - expected;
+            chi2 += (d * d) / expected;
+        }
+    *chi2_out = chi2;
+    *pval_out = 1.00 - orc_chisq_cdf(chi2, t - 1.0); /* :33-35 */
+    free(fc); free(fr); free(row_sums);
+    return a;
+}
+
+int orc_chisq_csv(const char *chrom, uint64_t pos, const uint64_t *counts, int n,
+                  const double *pool_sizes, const orc_filter *f, char *out, int cap) {
+    int ids[6];
+    double chi2, pv;
+    int a = orc_chisq_locus(counts, n, pool_sizes, f, ids, &chi2, &pv);
+    if (a == 0) return 0;
+    char al[8], s1[400], s2[400];
+    for (int j = 0; j < a; j++) al[j] = ALLELES[ids[j]];
+    al[a] = 0;
+    orc_parse_f64_roundup_and_own(chi2, 6, s1, sizeof s1);
+    orc_fmt_display(pv, s2, sizeof s2);
+    return snprintf(out, cap, "%s,%llu,%s,%s,%s\n", chrom, (unsigned long long)pos, al, s1, s2);
+}
+
+/* ======================================================================================
+ * gp: helpers.rs:151-255, gp/ols.rs:8-101, gp/penalise.rs:248-357
+ * ====================================================================================== */
+void orc_multiply_views_xx(const double *a, int a_ld, const double *b, int b_ld,
+                           const int64_t *a_rows, int n_a_rows, const int64_t *a_cols,
+                           const int64_t *b_rows, int n_inner, const int64_t *b_cols, int n_b_cols,
+                           double *out) {
+    for (int i = 0; i < n_a_rows; i++)
+        for (int j = 0; j < n_b_cols; j++) {
+            double x = 0.0;
+            for (int k = 0; k < n_inner; k++)
+                x += a[a_rows[i] * a_ld + a_cols[k]] * b[b_rows[k] * b_ld + b_cols[j]];
+            out[i * n_b_cols + j] = x;
+        }
+}
+
+void orc_multiply_views_xtx(const double *a, int a_ld, const double *b, int b_ld,
+                            const int64_t *a_rows, int n_inner, const int64_t *a_cols, int n_a_cols,
+                            const int64_t *b_rows, const int64_t *b_cols, int n_b_cols, double *out) {
+    for (int i = 0; i < n_a_cols; i++)
+        for (int j = 0; j < n_b_cols; j++) {
+            double x = 0.0;
+            for (int k = 0; k < n_inner; k++)
+                x += a[a_rows[k] * a_ld + a_cols[i]] * b[b_rows[k] * b_ld + b_cols[j]];
+            out[i * n_b_cols + j] = x;
+        }
+}
+
+void orc_multiply_views_xxt(const double *a, int a_ld, const double *b, int b_ld,
+                            const int64_t *a_rows, int n_a_rows, const int64_t *a_cols, int n_inner,
+                            const int64_t *b_rows, int n_b_rows, const int64_t *b_cols, double *out) {
+    for (int i = 0; i < n_a_rows; i++)
+        for (int j = 0; j < n_b_rows; j++) {
+            double x = 0.0;
+            for (int k = 0; k < n_inner; k++)
+                x += a[a_rows[i] * a_ld + a_cols[k]] * b[b_rows[j] * b_ld + b_cols[k]];
+            out[i * n_b_rows + j] = x;
+        }
+}
+
+/* gp::ols (gp/ols.rs:8-101).  Reference layout is X[n x P] row-major; here the transposed
+ * (locus-major) storage Xt[P x n] is used, i.e. X[(i, j)] = Xt[j * ld + i]. */
+int orc_gp_ols(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
+               const int64_t *row_idx, int n_rows, double *beta, int n_threads) {
+    double s0 = 0.0;
+    for (int i = 0; i < n; i++) s0 = s0 + Xt[i];
+    if (s0 < (double)n) return -1; /* gp/ols.rs:26-31 */
+    int nt = 1;
+#ifdef _OPENMP
+    nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+#endif
+    (void)n_threads;
+    int r = n_rows;
+    if ((int64_t)n < P) {
+        /* X X^T over the selected rows (multiply_views_xxt, helpers.rs:222-255) */
+        double *xxt = (double *)calloc((size_t)r * r, sizeof(double));
+#pragma omp parallel for num_threads(nt) schedule(static)
+        for (int a = 0; a < r; a++)
+            for (int b = 0; b < r; b++) {
+                double x = 0.0;
+                for (int64_t c = 0; c < P; c++) x += Xt[c * ld + row_idx[a]] * Xt[c * ld + row_idx[b]];
+                xxt[a * r + b] = x;
+            }
+        double *pinv = (double *)malloc(sizeof(double) * r * r);
+        orc_pinv_sym(xxt, r, pinv);
+        /* (X^T pinv) y evaluated as the reference does: T = X^T pinv (P x r), b = T y */
+#pragma omp parallel for num_threads(nt) schedule(static)
+        for (int64_t c = 0; c < P; c++) {
+            double *trow = (double *)malloc(sizeof(double) * r);
+            for (int b = 0; b < r; b++) {
+                double x = 0.0;
+                for (int a = 0; a < r; a++) x += Xt[c * ld + row_idx[a]] * pinv[a * r + b];
+                trow[b] = x;
+            }
+            for (int j = 0; j < k; j++) {
+                double x = 0.0;
+                for (int a = 0; a < r; a++) x += trow[a] * Y[row_idx[a] * k + j];
+                beta[c * k + j] = x;
+            }
+            free(trow);
+        }
+        free(xxt); free(pinv);
+    } else {
+        int Pi = (int)P;
+        double *xtx = (double *)calloc((size_t)Pi * Pi, sizeof(double));
+        for (int a = 0; a < Pi; a++)
+            for (int b = 0; b < Pi; b++) {
+                double x = 0.0;
+                for (int i = 0; i < r; i++) x += Xt[a * ld + row_idx[i]] * Xt[b * ld + row_idx[i]];
+                xtx[a * Pi + b] = x;
+            }
+        double *pinv = (double *)malloc(sizeof(double) * Pi * Pi);
+        orc_pinv_sym(xtx, Pi, pinv);
+        double *T = (double *)malloc(sizeof(double) * Pi * r); /* pinv X^T (P x r) */
+        for (int a = 0; a < Pi; a++)
+            for (int i = 0; i < r; i++) {
+                double x = 0.0;
+                for (int b = 0; b < Pi; b++) x += pinv[a * Pi + b] * Xt[b * ld + row_idx[i]];
+                T[a * r + i] = x;
+            }
+        for (int a = 0; a < Pi; a++)
+            for (int j = 0; j < k; j++) {
+                double x = 0.0;
+                for (int i = 0; i < r; i++) x += T[a * r + i] * Y[row_idx[i] * k + j];
+                beta[a * k + j] = x;
+            }
+        free(xtx); free(pinv); free(T);
+    }
+    return 0;
+}
+
+/* expand_and_contract (gp/penalise.rs:248-357) */
+void orc_expand_and_contract(const double *b_in, const double *b_proxy, int64_t P, int k,
+                             double alpha, double lambda, double *out) {
+    memcpy(out, b_in, sizeof(double) * P * k);
+    int64_t q = P - 1;
+    double *normed = (double *)malloc(sizeof(double) * (q > 0 ? q : 1) * 2);
+    double *nprox = normed + q;
+    for (int j = 0; j < k; j++) {
+        double intercept = out[j];
+        for (int64_t i = 0; i < q; i++) {
+            double v = out[(i + 1) * k + j], w = b_proxy[(i + 1) * k + j];
+            normed[i] = ((1.00 - alpha) * (v * v) / 1.00) + (alpha * fabs(v));
+            nprox[i] = ((1.00 - alpha) * (w * w) / 1.00) + (alpha * fabs(w));
+        }
+        double mx = nprox[0];
+        for (int64_t i = 0; i < q; i++)
+            if (nprox[i] > mx) mx = nprox[i];
+        double sub_pen = 0.0, add_pen = 0.0, sub_dep = 0.0, add_dep = 0.0;
+        for (int64_t i = 0; i < q; i++) {
+            if (!(nprox[i] / mx < lambda)) continue;
+            double *bv = &out[(i + 1) * k + j];
+            if (*bv >= 0.0) {
+                if ((*bv - normed[i]) < 0.0) { sub_pen += *bv; *bv = 0.0; }
+                else { sub_pen += normed[i]; *bv -= normed[i]; }
+            } else {
+                if ((*bv + normed[i]) > 0.0) { add_pen += fabs(*bv); *bv = 0.0; }
+                else { add_pen += normed[i]; *bv += normed[i]; }
+            }
+        }
+        for (int64_t i = 0; i < q; i++) {
+            if (!(nprox[i] / mx >= lambda)) continue;
+            if (out[(i + 1) * k + j] >= 0.0) sub_dep += normed[i];
+            else add_dep += normed[i];
+        }
+        if ((sub_pen > 0.0) & (sub_dep == 0.0)) { add_pen -= sub_pen; sub_pen = 0.0; }
+        else if ((add_pen > 0.0) & (add_dep == 0.0)) { sub_pen -= add_pen; add_pen = 0.0; }
+        for (int64_t i = 0; i < q; i++) {
+            if (!(nprox[i] / mx >= lambda)) continue;
+            double *bv = &out[(i + 1) * k + j];
+            if (*bv >= 0.0) *bv += sub_pen * (normed[i] / sub_dep);
+            else *bv -= add_pen * (normed[i] / add_dep);
+        }
+        out[j] = intercept;
+    }
+    free(normed);
+}

@@ -1,0 +1,153 @@
+/*
+ * poolgen_oracle.h -- CPU restatement ("oracle") of the poolgen per-locus regression hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under poolgen_amd/ (the product) may include, link or
+ * execute this code; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and there only as the checker / reported CPU baseline, never as the thing measured or shipped.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it follows.
+ * The reference is Rust and cannot be built here (no cargo/rustc, crates not vendored), so this
+ * restatement is pinned by the reference's own known-answer tests (tests/test_oracle_golden.py):
+ *   - statrs StudentsT / ChiSquared cdf values       correlation_test.rs:138-141, chisq_test.rs:57
+ *   - sync parse / filter / frequencies / sort        base/sync.rs:1435-1535, 1611-1616
+ *   - phenotype parse                                 base/phen.rs:221-236
+ *   - rounding / formatting                           base/helpers.rs:505-509
+ *   - multiply_views_* products                       base/helpers.rs:525-540
+ *   - gp::ols fit property                            gp/ols.rs:245-246
+ *   - expand_and_contract vectors                     gp/penalise.rs:709-720
+ * `ols_with_covariate` (kinship + eig + m rule) and `ols_iterate`'s CSV have NO live reference
+ * test or expected-output file: for those two the status is "parity unpinned" beyond the pinned
+ * building blocks above (fit kernel via the commented golden gwas/ols.rs:534 for beta only).
+ *
+ * Third-party arithmetic restated here because its source is not under /root/reference
+ * (Cargo.toml:6-18, no lockfile): statrs 0.16.0 (beta_reg, ln_gamma, gamma_lr),
+ * ndarray 0.15.6 (sum = 8-way unrolled fold), ndarray-linalg 0.16.0 / LAPACK (inv = LU with
+ * partial pivoting, det, eig, svd).
+ */
+#ifndef POOLGEN_ORACLE_H
+#define POOLGEN_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* FilterStats (base/structs_and_traits.rs:68-78); pool_sizes passed separately. */
+typedef struct {
+    int remove_ns;                 /* !--keep-ns                       (main.rs:203) */
+    uint64_t min_coverage_depth;   /* --min-coverage-depth, default 1  (main.rs:50)  */
+    double min_allele_frequency;   /* --min-allele-frequency, 0.001    (main.rs:53)  */
+    double max_missingness_rate;   /* --max-missingness-rate, 0.0      (main.rs:56)  */
+} orc_filter;
+
+/* ---- statrs 0.16 special functions -------------------------------------------------- */
+double orc_ln_gamma(double x);
+double orc_beta_reg(double a, double b, double x);
+double orc_gamma_lr(double a, double x);
+double orc_students_t_cdf(double x, double freedom);   /* StudentsT::new(0,1,nu).cdf(x) */
+double orc_chisq_cdf(double x, double freedom);        /* ChiSquared::new(df).cdf(x)    */
+
+/* ---- helpers.rs ----------------------------------------------------------------------- */
+double orc_sensible_round(double x, int n_digits);                       /* helpers.rs:103-108 */
+int orc_fmt_display(double x, char *buf, int cap);                       /* Rust `{}` for f64  */
+int orc_parse_f64_roundup_and_own(double x, int n_digits, char *buf, int cap); /* :111-117 */
+double orc_ndarray_sum(const double *x, int64_t len);                    /* ndarray 0.15 sum() */
+double orc_mean_ignore_nan(const double *x, int64_t len, int64_t stride);/* helpers.rs:258-264 */
+
+/* ---- small dense linear algebra (ndarray-linalg restated) ------------------------------ */
+int orc_lu_inverse(const double *a, int n, double *inv);   /* .inv(): 0 ok, -1 singular */
+double orc_lu_det(const double *a, int n);                 /* .det(): singular -> 0.0  */
+/* symmetric eigen-decomposition (cyclic Jacobi), eigenvalues sorted DESCENDING, vectors in
+ * columns of v (row-major n x n).  Stands in for `.eig()` (gwas/ols.rs:296). */
+int orc_sym_eig(const double *a, int n, double *evals, double *v);
+/* Moore-Penrose pseudo-inverse via SVD, helpers.rs:463-482 (square symmetric input only). */
+int orc_pinv_sym(const double *a, int n, double *out);
+
+/* ---- sync.rs: parse / filter / frequencies / sort --------------------------------------- */
+/* Parse one sync line (sync.rs:100-156): returns n pools (>0), 0 for a comment line, <0 error.
+ * counts is n x 6 row-major in the reader's column order A,T,C,G,N,D. */
+int orc_parse_sync_line(const char *line, char *chrom, int chrom_cap, uint64_t *pos,
+                        uint64_t *counts, int max_pools);
+/* LocusCounts::filter (sync.rs:195-303).  Returns number of alleles kept (>=2) or 0 (= None).
+ * allele_ids[j] in 0..5 index "ATCGND"; out_counts is n x a row-major. */
+int orc_filter_locus(const uint64_t *counts, int n, const double *pool_sizes,
+                     const orc_filter *f, int *allele_ids, uint64_t *out_counts);
+void orc_to_frequencies(const uint64_t *counts, int n, int a, double *freq);   /* :166-192 */
+void orc_sort_by_allele_freq(double *freq, int n, int a, int *allele_ids, int decreasing); /* :477-506 */
+
+/* ---- gwas/ols.rs ---------------------------------------------------------------------- */
+/* UnivariateOrdinaryLeastSquares::estimate_{effects,variances,significance} (ols.rs:58-160).
+ * X is n x P row-major.  Returns 0, or -1 for "Non-invertible x_matrix". */
+int orc_ols_fit(const double *X, const double *y, int n, int P,
+                double *b, double *v_b, double *t, double *pval);
+
+#define ORC_MAX_OUT_ALLELES 5
+typedef struct {
+    int n_alleles;                       /* rows emitted per trait (P-1); 0 => None */
+    int allele_ids[ORC_MAX_OUT_ALLELES]; /* index into "ATCGND" */
+    double mean_freq[ORC_MAX_OUT_ALLELES];
+    /* beta/pval laid out [allele][trait], trait stride = k */
+} orc_locus_hdr;
+
+/* ols_iterate (ols.rs:201-276) on one locus.  Y is n x k row-major.  beta/pval: (P-1) x k.
+ * Returns number of emitted alleles (0 = None). */
+int orc_ols_iterate_locus(const uint64_t *counts, int n, const double *Y, int k,
+                          const double *pool_sizes, const orc_filter *f,
+                          orc_locus_hdr *hdr, double *beta, double *pval);
+/* CSV fragment exactly as ols.rs:255-275.  Returns bytes written (0 = None). */
+int orc_ols_iterate_csv(const char *chrom, uint64_t pos, const uint64_t *counts, int n,
+                        const double *Y, int k, const double *pool_sizes, const orc_filter *f,
+                        char *out, int cap);
+
+/* ols_with_covariate numeric core (ols.rs:291-370).  G locus-major p x n with leading dim ld.
+ * force_m < 0 => m from the cumulative-variance rule (ols.rs:297-311) on DESCENDING eigenvalues.
+ * covariate_in (n x m_in row-major) may be NULL; if given it replaces the eigenvectors.
+ * Outputs: K (n x n, may be NULL), evals (n, may be NULL), beta/var/pval p x k (row-major,
+ * NaN on per-fit failure, ols.rs:358-369). n_threads<=0 => all cores.  Returns m. */
+int orc_ols_with_covariate(const double *G, int64_t p, int n, int64_t ld, const double *Y, int k,
+                           double var_explained, int force_m, const double *covariate_in,
+                           double *K_out, double *evals_out, double *cov_out,
+                           double *beta, double *var, double *pval, int n_threads);
+int orc_n_eigenvecs_rule(const double *evals_in_order, int n, double threshold); /* :297-311 */
+void orc_kinship(const double *G, int64_t p, int n, int64_t ld, double *K, int n_threads); /* :291-295 */
+
+/* ---- gwas/correlation_test.rs ----------------------------------------------------------- */
+void orc_pearsons_correlation(const double *x, int64_t sx, const double *y, int64_t sy, int n,
+                              double *r, double *pval);                       /* :7-71 */
+int orc_correlation_locus(const uint64_t *counts, int n, const double *Y, int k,
+                          const double *pool_sizes, const orc_filter *f,
+                          orc_locus_hdr *hdr, double *corr, double *pval);   /* :73-129 */
+int orc_correlation_csv(const char *chrom, uint64_t pos, const uint64_t *counts, int n,
+                        const double *Y, int k, const double *pool_sizes, const orc_filter *f,
+                        char *out, int cap);
+
+/* ---- tables/chisq_test.rs ---------------------------------------------------------------- */
+int orc_chisq_locus(const uint64_t *counts, int n, const double *pool_sizes, const orc_filter *f,
+                    int *allele_ids, double *chi2, double *pval);             /* :5-47 */
+int orc_chisq_csv(const char *chrom, uint64_t pos, const uint64_t *counts, int n,
+                  const double *pool_sizes, const orc_filter *f, char *out, int cap);
+
+/* ---- gp ------------------------------------------------------------------------------------- */
+/* multiply_views_{xx,xtx,xxt} (helpers.rs:151-255), row-major dense inputs. */
+void orc_multiply_views_xx(const double *a, int a_ld, const double *b, int b_ld,
+                           const int64_t *a_rows, int n_a_rows, const int64_t *a_cols,
+                           const int64_t *b_rows, int n_inner, const int64_t *b_cols, int n_b_cols,
+                           double *out);
+void orc_multiply_views_xtx(const double *a, int a_ld, const double *b, int b_ld,
+                            const int64_t *a_rows, int n_inner, const int64_t *a_cols, int n_a_cols,
+                            const int64_t *b_rows, const int64_t *b_cols, int n_b_cols, double *out);
+void orc_multiply_views_xxt(const double *a, int a_ld, const double *b, int b_ld,
+                            const int64_t *a_rows, int n_a_rows, const int64_t *a_cols, int n_inner,
+                            const int64_t *b_rows, int n_b_rows, const int64_t *b_cols, double *out);
+/* gp::ols (gp/ols.rs:8-101), n<p branch: b = X^T pinv(X X^T) y on the selected rows.
+ * X locus-major: P x n with ld (column j of the reference matrix = row j here; row 0 = intercept).
+ * Returns 0 or -1 (missing intercept). beta is P x k row-major. */
+int orc_gp_ols(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
+               const int64_t *row_idx, int n_rows, double *beta, int n_threads);
+/* expand_and_contract (gp/penalise.rs:248-357). b_hat/proxy P x k row-major; out P x k. */
+void orc_expand_and_contract(const double *b_hat, const double *b_proxy, int64_t P, int k,
+                             double alpha, double lambda, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,74 @@
+// pg_common.h -- internal declarations shared by the libpoolgen_hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/poolgen_hip.h"
+
+#define PG_MAX_SWEEP_COLS 34 // Q columns (m+1) + traits handled by one sweep launch
+
+struct pg_event_pair { hipEvent_t a, b; int kid; };
+
+struct pg_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // profiling
+    bool prof = false;
+    std::vector<pg_event_pair> ev_pending;
+    std::vector<pg_event_pair> ev_free;
+    double prof_ms[PG_K_COUNT] = {0};
+    int64_t prof_n[PG_K_COUNT] = {0};
+    // generic device workspace (grown on demand, reused between calls)
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    // regression state set by pg_kinship_set / pg_covariates_set
+    int st_n = 0, st_m = -1, st_k = 0, st_cols = 0;
+    double *W_dev = nullptr;     // n x st_cols row-major: [Q_0..Q_m | ytilde_0..ytilde_{k-1}]
+    double *syy_dev = nullptr;   // k
+    double *tcoef_dev = nullptr; // t-distribution series coefficients for df = n - 1
+    int tcoef_df = 0, tcoef_len = 0;
+    size_t W_cap = 0;
+    double *S_dev = nullptr;     // n x n kinship sum of the single-GPU convenience path
+    int S_n = 0;
+    // small pinned host staging
+    void *pin = nullptr;
+    size_t pin_bytes = 0;
+};
+
+int pg_fail(pg_ctx *ctx, int code, const char *fmt, ...);
+#define PG_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return pg_fail(ctx, PG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                               \
+    } while (0)
+#define PG_CHECK(ctx, cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) return pg_fail(ctx, PG_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+int pg_ws_reserve(pg_ctx *ctx, size_t bytes);
+int pg_pin_reserve(pg_ctx *ctx, size_t bytes);
+void pg_prof_begin(pg_ctx *ctx, int kid);
+void pg_prof_end(pg_ctx *ctx);
+
+// host math (pg_hostmath.cpp)
+// symmetric eigen-decomposition: eigenvalues descending, eigenvectors in columns of V (row-major)
+int pg_sym_eig(const double *A, int n, double *evals, double *V, bool want_vectors);
+// thin Householder QR of Z (n x c row-major) -> Q (n x c row-major), returns numerical rank
+int pg_thin_qr(const double *Z, int n, int c, double *Q);
+// t-distribution finite-series coefficients (Abramowitz & Stegun 26.7.3/26.7.4)
+std::vector<double> pg_tdist_coef(int df);
+// symmetric pseudo-inverse with the reference's tolerance (helpers.rs:463-482)
+int pg_pinv_sym(const double *A, int n, double *out);
+
+// launchers (defined in the .hip files)
+int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
+                      bool add_intercept, int kid);

@@ -1,0 +1,286 @@
+// pg_hostmath.cpp -- small dense host-side linear algebra for the n x n (n = pools) problems
+// that sit between the two GPU passes: symmetric eigen-decomposition of the kinship matrix
+// (reference: `kinship.eig()`, gwas/ols.rs:296), an orthonormal basis of [1 | C], the
+// pseudo-inverse used by gp::ols (base/helpers.rs:463-482) and the t-distribution series
+// coefficients consumed by the device p-value code.  These are O(n^3) with n <= a few hundred;
+// the O(n^2 p) work lives in the HIP kernels.
+#include "pg_common.h"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace {
+
+// Householder reduction of a symmetric matrix to tridiagonal form.  On exit (want_q) `a` holds
+// the orthogonal transformation, d the diagonal, e the sub-diagonal (e[0] = 0).
+void tridiagonalise(std::vector<double> &a, int n, std::vector<double> &d, std::vector<double> &e,
+                    bool want_q) {
+    auto A = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0, scale = 0.0;
+        if (l > 0) {
+            for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
+            if (scale == 0.0) {
+                e[i] = A(i, l);
+            } else {
+                for (int k = 0; k <= l; ++k) {
+                    A(i, k) /= scale;
+                    h += A(i, k) * A(i, k);
+                }
+                double f = A(i, l);
+                double g = (f >= 0.0) ? -std::sqrt(h) : std::sqrt(h);
+                e[i] = scale * g;
+                h -= f * g;
+                A(i, l) = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    if (want_q) A(j, i) = A(i, j) / h;
+                    g = 0.0;
+                    for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
+                    for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
+                    e[j] = g / h;
+                    f += e[j] * A(i, j);
+                }
+                const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = A(i, j);
+                    e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) A(j, k) -= (f * e[k] + g * A(i, k));
+                }
+            }
+        } else {
+            e[i] = A(i, l);
+        }
+        d[i] = h;
+    }
+    if (want_q) d[0] = 0.0;
+    e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (want_q) {
+            const int l = i - 1;
+            if (d[i] != 0.0) {
+                for (int j = 0; j <= l; ++j) {
+                    double g = 0.0;
+                    for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
+                    for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
+                }
+            }
+            d[i] = A(i, i);
+            A(i, i) = 1.0;
+            for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
+        } else {
+            d[i] = A(i, i);
+        }
+    }
+}
+
+// Implicit-shift QL iteration on a symmetric tridiagonal matrix.  z (n x n, row-major) is
+// post-multiplied by the rotations when want_q.
+int ql_implicit(std::vector<double> &d, std::vector<double> &e, int n, std::vector<double> &z,
+                bool want_q) {
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 200) return -1;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    e[i + 1] = (r = std::hypot(f, g));
+                    if (r == 0.0) {
+                        d[i + 1] -= p;
+                        e[m] = 0.0;
+                        break;
+                    }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = c * r - b;
+                    if (want_q) {
+                        for (int k = 0; k < n; ++k) {
+                            double *zk = &z[(size_t)k * n];
+                            f = zk[i + 1];
+                            zk[i + 1] = s * zk[i] + c * f;
+                            zk[i] = c * zk[i] - s * f;
+                        }
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return 0;
+}
+
+} // namespace
+
+int pg_sym_eig(const double *A, int n, double *evals, double *V, bool want_vectors) {
+    std::vector<double> a(A, A + (size_t)n * n), d(n), e(n);
+    if (n == 1) {
+        evals[0] = A[0];
+        if (want_vectors) V[0] = 1.0;
+        return 0;
+    }
+    tridiagonalise(a, n, d, e, want_vectors);
+    if (ql_implicit(d, e, n, a, want_vectors) != 0) return -1;
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] > d[y]; });
+    for (int j = 0; j < n; ++j) evals[j] = d[order[j]];
+    if (want_vectors) {
+        for (int j = 0; j < n; ++j) {
+            const int src = order[j];
+            // fix the sign so that the result does not depend on rotation history: largest
+            // |component| positive (the regression only depends on the span).
+            double big = 0.0;
+            for (int i = 0; i < n; ++i)
+                if (std::fabs(a[(size_t)i * n + src]) > std::fabs(big)) big = a[(size_t)i * n + src];
+            const double sg = big < 0.0 ? -1.0 : 1.0;
+            for (int i = 0; i < n; ++i) V[(size_t)i * n + j] = sg * a[(size_t)i * n + src];
+        }
+    }
+    return 0;
+}
+
+// Orthonormal basis of the columns of Z by twice-iterated classical Gram-Schmidt.  Columns
+// that are numerically dependent on the previous ones (residual < 1e-10 of their norm) are
+// dropped; returns the number of basis vectors written to Q (n x c row-major, first `rank`
+// columns valid, the rest zero).
+int pg_thin_qr(const double *Z, int n, int c, double *Q) {
+    std::vector<double> v(n);
+    int rank = 0;
+    std::fill(Q, Q + (size_t)n * c, 0.0);
+    for (int j = 0; j < c; ++j) {
+        double norm0 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            v[i] = Z[(size_t)i * c + j];
+            norm0 += v[i] * v[i];
+        }
+        norm0 = std::sqrt(norm0);
+        if (norm0 == 0.0) continue;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int q = 0; q < rank; ++q) {
+                double dot = 0.0;
+                for (int i = 0; i < n; ++i) dot += Q[(size_t)i * c + q] * v[i];
+                for (int i = 0; i < n; ++i) v[i] -= dot * Q[(size_t)i * c + q];
+            }
+        }
+        double nrm = 0.0;
+        for (int i = 0; i < n; ++i) nrm += v[i] * v[i];
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 1e-10 * norm0)) continue;
+        for (int i = 0; i < n; ++i) Q[(size_t)i * c + rank] = v[i] / nrm;
+        ++rank;
+    }
+    return rank;
+}
+
+// Two-sided Student-t probability for INTEGER df as a finite trigonometric series
+// (Abramowitz & Stegun 26.7.3 / 26.7.4).  With theta = atan(|t|/sqrt(df)), c2 = cos^2(theta):
+//   df odd : A = 2/pi * (theta + sin*cos * sum_{j=0}^{(df-3)/2} coef[j] c2^j), coef[j] = prod (2i)/(2i+1)
+//   df even: A = sin * sum_{j=0}^{(df-2)/2} coef[j] c2^j,                    coef[j] = prod (2i-1)/(2i)
+// p = 1 - A.  The device evaluates the polynomial by Horner's rule from these coefficients.
+std::vector<double> pg_tdist_coef(int df) {
+    std::vector<double> c;
+    if (df < 1) return c;
+    if (df % 2 == 1) {
+        const int terms = (df - 1) / 2;
+        double v = 1.0;
+        for (int j = 0; j < terms; ++j) {
+            if (j > 0) v = v * (2.0 * j) / (2.0 * j + 1.0);
+            c.push_back(v);
+        }
+    } else {
+        const int terms = df / 2;
+        double v = 1.0;
+        for (int j = 0; j < terms; ++j) {
+            if (j > 0) v = v * (2.0 * j - 1.0) / (2.0 * j);
+            c.push_back(v);
+        }
+    }
+    return c;
+}
+
+// pinv of a symmetric matrix with the reference's SVD tolerance eps * len(s) * max(s)
+// (base/helpers.rs:463-482); for a symmetric matrix singular values are |eigenvalues|.
+int pg_pinv_sym(const double *A, int n, double *out) {
+    std::vector<double> ev(n), V((size_t)n * n);
+    if (pg_sym_eig(A, n, ev.data(), V.data(), true) != 0) return -1;
+    double smax = 0.0;
+    for (int i = 0; i < n; ++i) smax = std::max(smax, std::fabs(ev[i]));
+    const double tol = 2.220446049250313e-16 * (double)n * smax;
+    std::fill(out, out + (size_t)n * n, 0.0);
+    for (int e = 0; e < n; ++e) {
+        if (std::fabs(ev[e]) > tol) {
+            const double w = 1.0 / ev[e];
+            for (int i = 0; i < n; ++i) {
+                const double vi = V[(size_t)i * n + e] * w;
+                for (int j = 0; j < n; ++j) out[(size_t)i * n + j] += vi * V[(size_t)j * n + e];
+            }
+        }
+    }
+    return 0;
+}
+
+// ---- exported host utilities (include/poolgen_hip.h, "Host-side pieces of the path") ----------
+extern "C" int pg_host_sym_eig(const double *A, int n, double *evals, double *V) {
+    if (!A || !evals || n < 1) return PG_ERR_INVALID;
+    return pg_sym_eig(A, n, evals, V, V != nullptr) == 0 ? PG_OK : PG_ERR_INVALID;
+}
+
+extern "C" int pg_host_n_eigenvecs(const double *ev, int n, double var_explained) {
+    if (!ev || n < 1) return PG_ERR_INVALID;
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum = sum + ev[i];
+    std::vector<double> cum(n);
+    for (int i = 0; i < n; ++i) cum[i] = ev[i] / sum;
+    int m = n;
+    for (int i = 1; i < n; ++i) {
+        cum[i] = cum[i - 1] + cum[i];
+        if ((cum[i - 1] >= var_explained) & (i - 1 < m)) m = i - 1;
+    }
+    return m;
+}
+
+extern "C" int pg_host_pinv_sym(const double *A, int n, double *out) {
+    if (!A || !out || n < 1) return PG_ERR_INVALID;
+    return pg_pinv_sym(A, n, out) == 0 ? PG_OK : PG_ERR_INVALID;
+}
+
+extern "C" double pg_host_t_two_sided_p(double t_abs, int df) {
+    if (df < 1 || std::isnan(t_abs)) return NAN;
+    if (std::isinf(t_abs)) return 0.0;
+    const std::vector<double> coef = pg_tdist_coef(df);
+    const double nu = (double)df;
+    const double c2 = nu / (nu + t_abs * t_abs);
+    const double s = std::sqrt(1.0 - c2);
+    double poly = 0.0;
+    for (int j = (int)coef.size() - 1; j >= 0; --j) poly = std::fma(poly, c2, coef[j]);
+    double A;
+    if (df & 1) {
+        const double c = std::sqrt(c2);
+        A = 0.6366197723675814 * (std::atan2(s, c) + s * c * poly);
+    } else {
+        A = s * poly;
+    }
+    double p = 1.0 - A;
+    p = p < 0.0 ? 0.0 : p;
+    return p > 1.0 ? 1.0 : p;
+}

@@ -1,0 +1,282 @@
+// pg_kinship.hip -- S = sum_l g_l g_l^T over a slab of loci, fp64 MFMA (v_mfma_f64_16x16x4_f64).
+//
+// Reference: `kinship = g.dot(&g.t()) / p` (gwas/ols.rs:291-295) and the X X^T contraction of
+// gp::ols (gp/ols.rs:56, base/helpers.rs:222-255).  G is locus-major (p x n, ld), so both MFMA
+// operands of a 16x16 output tile are "4 loci x 16 pools" fragments of the SAME rows:
+//     A[i][k] = G[l0+k][a0+i]   (lane l: i = l&15, k = l>>4)
+//     B[k][j] = G[l0+k][b0+j]   (lane l: j = l&15, k = l>>4)
+// i.e. 16 consecutive lanes read 128 contiguous bytes of one locus row -- no transposition.
+//
+// Decomposition.  One 1024-thread workgroup (16 waves, 4 per SIMD) owns a contiguous slab of
+// loci and a pair (bi <= bj) of pool blocks (a block = up to `Tb` 16-pool tiles).  For
+// n <= 208 pools there is a single block: the workgroup holds the WHOLE upper triangle of S
+// (<= 91 tiles, <= 6 per wave, 4 fp64 accumulators per lane per tile) in registers while it
+// streams its loci once from HBM through a double-buffered LDS stage (16 loci per stage).
+// The contraction is MFMA-bound (intensity n/4 flop per byte); HBM traffic is the single read
+// of G.  Each workgroup finally writes its partial tiles to a slab; a second tiny kernel sums
+// the slabs in a fixed order (deterministic, no atomics) and mirrors the lower triangle.
+#include "pg_common.h"
+
+namespace {
+
+constexpr int KIN_THREADS = 1024;
+constexpr int KIN_WAVES = 16;
+constexpr int KIN_TPW = 6;  // max tiles per wave (ceil(91/16), ceil(81/16))
+constexpr int KIN_KC = 16;  // loci per LDS stage = 4 MFMA k-steps
+constexpr int KIN_PPT = 2;  // 16-byte staging pieces per thread per stage
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct KinParams {
+    const double *G;
+    int64_t p;
+    int64_t ld;
+    int64_t loci_per_wg;
+    double *slabs; // [gridDim.x][npad * npad]
+    int n, T, npad, Tb, nb;
+};
+
+__global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int fi = lane & 15; // pool within fragment / output column
+    const int kq = lane >> 4; // locus within k-step / output row group
+
+    // ---- which pair of pool blocks ------------------------------------------------------
+    int bi = 0, bj = 0;
+    {
+        int q = blockIdx.y;
+        for (bi = 0; bi < P.nb; ++bi) {
+            const int cnt = P.nb - bi;
+            if (q < cnt) { bj = bi + q; break; }
+            q -= cnt;
+        }
+    }
+    const bool diag = (bi == bj);
+    const int Ta = min(P.Tb, P.T - bi * P.Tb);
+    const int Tbb = min(P.Tb, P.T - bj * P.Tb);
+    const int colsA = Ta * 16;
+    const int colsB = diag ? 0 : Tbb * 16;
+    int ldsld = colsA + colsB;
+    if ((ldsld & 31) != 16) ldsld += 16; // rows 2 apart hit disjoint bank halves (ds_read_b64)
+    const int a0 = bi * P.Tb * 16;
+    const int b0 = bj * P.Tb * 16;
+    const int wa = min(colsA, P.n - a0);
+    const int wb = diag ? 0 : min(colsB, P.n - b0);
+    const int npa = (wa + 1) >> 1, npb = (wb + 1) >> 1;
+    const int npr = npa + npb; // 16-byte pieces per staged locus row
+
+    // ---- this wave's tiles ---------------------------------------------------------------
+    const int ntiles = diag ? Ta * (Ta + 1) / 2 : Ta * Tbb;
+    int acol[KIN_TPW], bcol[KIN_TPW], orow[KIN_TPW], ocol[KIN_TPW];
+    int my_nt = 0;
+#pragma unroll
+    for (int u = 0; u < KIN_TPW; ++u) {
+        const int t = wave + KIN_WAVES * u;
+        int ti = 0, tj = 0;
+        if (t < ntiles) {
+            my_nt = u + 1;
+            if (diag) {
+                int q = t;
+                for (ti = 0; ti < Ta; ++ti) {
+                    const int cnt = Ta - ti;
+                    if (q < cnt) { tj = ti + q; break; }
+                    q -= cnt;
+                }
+            } else {
+                ti = t / Tbb;
+                tj = t - ti * Tbb;
+            }
+        }
+        acol[u] = 16 * ti;
+        bcol[u] = diag ? 16 * tj : colsA + 16 * tj;
+        orow[u] = a0 + 16 * ti;
+        ocol[u] = b0 + 16 * tj;
+    }
+
+    // ---- staging assignment (constant over the stages) -------------------------------------
+    int st_loc[KIN_PPT], st_lcol[KIN_PPT];
+    int64_t st_goff[KIN_PPT];
+    bool st_on[KIN_PPT], st_two[KIN_PPT];
+#pragma unroll
+    for (int r = 0; r < KIN_PPT; ++r) {
+        const int t = tid + r * KIN_THREADS;
+        const int loc = t / npr;
+        const int q = t - loc * npr;
+        st_on[r] = loc < KIN_KC;
+        st_loc[r] = loc;
+        int gcol, lcol;
+        bool two;
+        if (q < npa) {
+            gcol = a0 + 2 * q; lcol = 2 * q; two = (2 * q + 1) < wa;
+        } else {
+            const int q2 = q - npa;
+            gcol = b0 + 2 * q2; lcol = colsA + 2 * q2; two = (2 * q2 + 1) < wb;
+        }
+        st_lcol[r] = lcol;
+        st_two[r] = two;
+        st_goff[r] = (int64_t)loc * P.ld + gcol;
+    }
+
+    const int64_t l_begin = (int64_t)blockIdx.x * P.loci_per_wg;
+    const int64_t l_end = min(P.p, l_begin + P.loci_per_wg);
+    const int nstages = (l_end > l_begin) ? (int)((l_end - l_begin + KIN_KC - 1) / KIN_KC) : 0;
+    const int bufsz = KIN_KC * ldsld;
+
+    // zero both buffers once: the padding columns must stay zero for the edge tiles
+    for (int i = tid; i < 2 * bufsz; i += KIN_THREADS) lds[i] = 0.0;
+    __syncthreads();
+
+    double2 stage_reg[KIN_PPT];
+    auto stage_load = [&](int c) {
+        const int64_t lbase = l_begin + (int64_t)c * KIN_KC;
+#pragma unroll
+        for (int r = 0; r < KIN_PPT; ++r) {
+            double2 v = make_double2(0.0, 0.0);
+            if (st_on[r] && (lbase + st_loc[r]) < l_end) {
+                const double *src = P.G + lbase * P.ld + st_goff[r];
+                v = *reinterpret_cast<const double2 *>(src);
+                if (!st_two[r]) v.y = 0.0;
+            }
+            stage_reg[r] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < KIN_PPT; ++r) {
+            if (st_on[r])
+                *reinterpret_cast<double2 *>(&lds[buf * bufsz + st_loc[r] * ldsld + st_lcol[r]]) =
+                    stage_reg[r];
+        }
+    };
+
+    double4_t acc[KIN_TPW];
+#pragma unroll
+    for (int u = 0; u < KIN_TPW; ++u) acc[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    if (nstages > 0) {
+        stage_load(0);
+        stage_store(0);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nstages; ++c) {
+        const bool more = (c + 1) < nstages;
+        if (more) stage_load(c + 1);
+        const double *buf = lds + (c & 1) * bufsz;
+#pragma unroll
+        for (int s = 0; s < KIN_KC / 4; ++s) {
+            const double *row = buf + (4 * s + kq) * ldsld + fi;
+#pragma unroll
+            for (int u = 0; u < KIN_TPW; ++u) {
+                if (u < my_nt) {
+                    const double a = row[acol[u]];
+                    const double b = row[bcol[u]];
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stage_store((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- write this workgroup's partial tiles ---------------------------------------------
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
+    double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
+#pragma unroll
+    for (int u = 0; u < KIN_TPW; ++u) {
+        if (u < my_nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = orow[u] + kq + 4 * r;
+                const int col = ocol[u] + fi;
+                slab[(size_t)row * P.npad + col] = acc[u][r];
+            }
+        }
+    }
+}
+
+// Sum the per-workgroup slabs in slab order and mirror: S[i][j] = S[j][i] = sum_w slab_w[i][j]
+// for i <= j (only upper-triangular tiles were written).
+__global__ void k_kinship_reduce(const double *__restrict__ slabs, int nslabs, int npad, int n,
+                                 double add_const, double *__restrict__ S) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= n || j >= n || i > j) return;
+    const size_t off = (size_t)i * npad + j;
+    const size_t stride = (size_t)npad * npad;
+    double s = 0.0;
+    for (int w = 0; w < nslabs; ++w) s += slabs[w * stride + off];
+    s += add_const;
+    S[(size_t)i * n + j] = s;
+    S[(size_t)j * n + i] = s;
+}
+
+} // namespace
+
+int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
+                      bool add_intercept, int kid) {
+    PG_CHECK(ctx, G && S, "kinship: null pointer");
+    PG_CHECK(ctx, p > 0 && n > 0, "kinship: need p > 0 and n > 0 (p=%lld n=%d)", (long long)p, n);
+    PG_CHECK(ctx, ld >= n && (ld % 2) == 0, "kinship: ld (%lld) must be even and >= n (%d)",
+             (long long)ld, n);
+    PG_CHECK(ctx, (reinterpret_cast<uintptr_t>(G) & 15) == 0, "kinship: G must be 16-byte aligned");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    PG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    KinParams P;
+    P.G = G; P.p = p; P.ld = ld; P.n = n;
+    P.T = (n + 15) / 16;
+    P.npad = P.T * 16;
+    if (P.T <= 13) { P.Tb = P.T; P.nb = 1; }
+    else { P.Tb = 8; P.nb = (P.T + 7) / 8; }
+    const int npairs = P.nb * (P.nb + 1) / 2;
+    int nslab = cus / npairs;
+    if (nslab < 1) nslab = 1;
+    const int64_t max_slabs = (p + KIN_KC - 1) / KIN_KC;
+    if (nslab > max_slabs) nslab = (int)max_slabs;
+    P.loci_per_wg = (p + nslab - 1) / nslab;
+    P.loci_per_wg = (P.loci_per_wg + KIN_KC - 1) / KIN_KC * KIN_KC;
+    nslab = (int)((p + P.loci_per_wg - 1) / P.loci_per_wg);
+
+    const size_t slab_bytes = (size_t)nslab * P.npad * P.npad * sizeof(double);
+    int rc = pg_ws_reserve(ctx, slab_bytes);
+    if (rc) return rc;
+    P.slabs = static_cast<double *>(ctx->ws);
+
+    // worst-case LDS row: two blocks of Tb tiles (+16 pad)
+    int ldsld = (P.nb == 1) ? P.Tb * 16 : 2 * P.Tb * 16;
+    if ((ldsld & 31) != 16) ldsld += 16;
+    const size_t shmem = (size_t)2 * KIN_KC * ldsld * sizeof(double);
+    PG_CHECK(ctx, KIN_KC * ((ldsld + 1) / 2) <= KIN_PPT * KIN_THREADS, "kinship: staging overflow");
+    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_kinship_syrk),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    // slabs for tiles of pairs are disjoint but padding rows/cols of unwritten tiles are never read
+    pg_prof_begin(ctx, kid);
+    hipLaunchKernelGGL(k_kinship_syrk, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
+    pg_prof_end(ctx);
+    PG_HIP(ctx, hipGetLastError());
+    pg_prof_begin(ctx, PG_K_KINSHIP_REDUCE);
+    hipLaunchKernelGGL(k_kinship_reduce, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream,
+                       P.slabs, nslab, P.npad, n, add_intercept ? 1.0 : 0.0, S);
+    pg_prof_end(ctx);
+    PG_HIP(ctx, hipGetLastError());
+    return PG_OK;
+}
+
+extern "C" int pg_kinship_partial_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
+                                      int64_t ld, double *S_dev) {
+    if (!ctx) return PG_ERR_INVALID;
+    return pg_launch_kinship(ctx, G_dev, p, n, ld, S_dev, false, PG_K_KINSHIP);
+}
+
+extern "C" int pg_gp_xxt_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
+                             double *XXt_dev) {
+    if (!ctx) return PG_ERR_INVALID;
+    // X = [1 | G^T]  =>  X X^T = 1 1^T + sum_l g_l g_l^T
+    return pg_launch_kinship(ctx, G_dev, p, n, ld, XXt_dev, true, PG_K_GP_XXT);
+}

@@ -1,0 +1,217 @@
+"""Engine: torch-facing wrapper over one pg_ctx (one GPU, one stream).
+
+Method names follow the reference operators they stand in for:
+  ols_with_covariate   gwas::ols_with_covariate      (gwas/ols.rs:278-436)
+  ols_iterate          gwas::ols_iterate             (gwas/ols.rs:201-276)
+  correlation          gwas::correlation             (gwas/correlation_test.rs:73-129)
+  chisq                tables::chisq                 (tables/chisq_test.rs:5-47)
+  gp_ols               gp::ols                       (gp/ols.rs:8-101)
+All heavy arguments are torch CUDA tensors (device memory owned by torch); results are
+torch CUDA tensors.  Everything is computed by libpoolgen_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from ._native import KERNEL_IDS, NativeError, PgFilter, load_library
+
+ALLELES = "ATCGND"  # base/sync.rs:134 reader order
+
+
+@dataclass
+class Filter:
+    """FilterStats subset (base/structs_and_traits.rs:68-78) with the CLI defaults (main.rs:44-58)."""
+    remove_ns: bool = True
+    min_coverage_depth: int = 1
+    min_allele_frequency: float = 0.001
+    max_missingness_rate: float = 0.0
+
+    def to_c(self) -> PgFilter:
+        return PgFilter(int(self.remove_ns), 0, int(self.min_coverage_depth),
+                        float(self.min_allele_frequency), float(self.max_missingness_rate))
+
+
+def _host_f64(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class Engine:
+    def __init__(self, device: int | None = None, use_torch_stream: bool = True):
+        self._lib = load_library()
+        if not torch.cuda.is_available():
+            raise NativeError("no GPU visible to torch: poolgen_amd needs an MI355X (gfx950) device")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        ctx = C.c_void_p()
+        rc = self._lib.pg_create(C.byref(ctx), self.device, C.c_void_p(stream))
+        if rc != 0:
+            raise NativeError(f"pg_create failed ({rc}): {self._lib.pg_last_error(None).decode()}")
+        self._ctx = ctx
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pg_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise NativeError(f"{what} failed ({rc}): {self._lib.pg_last_error(self._ctx).decode()}")
+
+    def _dev(self, t: torch.Tensor, dtype) -> int:
+        if not (t.is_cuda and t.dtype == dtype and t.is_contiguous() and t.device.index == self.device):
+            raise ValueError(f"expected a contiguous {dtype} tensor on cuda:{self.device}")
+        return t.data_ptr()
+
+    # ---- profiling ---------------------------------------------------------------------
+    def profile(self, on: bool = True):
+        self._check(self._lib.pg_profile_enable(self._ctx, int(on)), "pg_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.pg_profile_reset(self._ctx), "pg_profile_reset")
+
+    def profile_get(self, kernel: str):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.pg_profile_get(self._ctx, KERNEL_IDS[kernel], C.byref(ms), C.byref(n)),
+                    "pg_profile_get")
+        return ms.value, n.value
+
+    def synchronize(self):
+        self._check(self._lib.pg_synchronize(self._ctx), "pg_synchronize")
+
+    # ---- kinship path ---------------------------------------------------------------------
+    @staticmethod
+    def _g_dims(G: torch.Tensor, n: int | None):
+        p, ld = G.shape
+        return int(p), int(ld), int(ld if n is None else n)
+
+    def kinship_partial(self, G: torch.Tensor, n: int | None = None) -> torch.Tensor:
+        """Unscaled sum_l g_l g_l^T (n x n) over the loci of G (p x ld, locus-major)."""
+        p, ld, n = self._g_dims(G, n)
+        S = torch.empty((n, n), dtype=torch.float64, device=G.device)
+        self._check(self._lib.pg_kinship_partial_dev(self._ctx, self._dev(G, torch.float64), p, n, ld,
+                                                     self._dev(S, torch.float64)), "pg_kinship_partial_dev")
+        return S
+
+    def kinship_set(self, S: torch.Tensor, p_total: int, Y, var_explained: float = 0.75,
+                    force_m: int = -1):
+        """K = S / p_total, eigen rule, covariates, projected phenotypes.  Returns (m, K, evals)."""
+        n = S.shape[0]
+        Yh = _host_f64(Y).reshape(n, -1)
+        K = np.empty((n, n)); ev = np.empty(n); m = C.c_int()
+        self._check(self._lib.pg_kinship_set(self._ctx, self._dev(S, torch.float64), int(p_total), n,
+                                             Yh.ctypes.data, Yh.shape[1], float(var_explained),
+                                             int(force_m), C.byref(m), K.ctypes.data, ev.ctypes.data),
+                    "pg_kinship_set")
+        return m.value, K, ev
+
+    def covariates_set(self, n: int, Cmat, Y):
+        Yh = _host_f64(Y).reshape(n, -1)
+        if Cmat is None or np.size(Cmat) == 0:
+            m, cptr = 0, None
+        else:
+            Ch = _host_f64(Cmat).reshape(n, -1)
+            m, cptr = Ch.shape[1], Ch.ctypes.data
+        self._check(self._lib.pg_covariates_set(self._ctx, n, cptr, m, Yh.ctypes.data, Yh.shape[1]),
+                    "pg_covariates_set")
+        self._k = Yh.shape[1]
+
+    def ols_sweep(self, G: torch.Tensor, k: int, n: int | None = None, out=None):
+        p, ld, n = self._g_dims(G, n)
+        if out is None:
+            out = torch.empty((3, p, k), dtype=torch.float64, device=G.device)
+        self._check(self._lib.pg_ols_sweep_dev(self._ctx, self._dev(G, torch.float64), p, n, ld,
+                                               out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()),
+                    "pg_ols_sweep_dev")
+        return out[0], out[1], out[2]
+
+    def ols_with_covariate(self, G: torch.Tensor, Y, var_explained: float = 0.75, force_m: int = -1,
+                           n: int | None = None, out=None):
+        """Single-GPU ols_iter_with_kinship numeric core.  Returns (m, K, beta, var, pval)."""
+        p, ld, n = self._g_dims(G, n)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        if out is None:
+            out = torch.empty((3, p, k), dtype=torch.float64, device=G.device)
+        K = np.empty((n, n)); m = C.c_int()
+        self._check(self._lib.pg_ols_kinship_dev(self._ctx, self._dev(G, torch.float64), p, n, ld,
+                                                 Yh.ctypes.data, k, float(var_explained), int(force_m),
+                                                 C.byref(m), K.ctypes.data, out[0].data_ptr(),
+                                                 out[1].data_ptr(), out[2].data_ptr()),
+                    "pg_ols_kinship_dev")
+        return m.value, K, out[0], out[1], out[2]
+
+    # ---- sync-derived batch operators -------------------------------------------------------
+    def _batch(self, fn, name, counts: torch.Tensor, pool_sizes, flt: Filter, Y):
+        L, n, six = counts.shape
+        assert six == 6
+        ps = _host_f64(pool_sizes)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        dev = counts.device
+        n_out = torch.empty(L, dtype=torch.int32, device=dev)
+        ids = torch.empty((L, 5), dtype=torch.int32, device=dev)
+        mf = torch.empty((L, 5), dtype=torch.float64, device=dev)
+        stat = torch.empty((L, 5, k), dtype=torch.float64, device=dev)
+        pv = torch.empty((L, 5, k), dtype=torch.float64, device=dev)
+        f = flt.to_c()
+        self._check(fn(self._ctx, self._dev(counts, torch.int32) if counts.dtype == torch.int32
+                       else self._dev(counts, torch.uint32), L, n, ps.ctypes.data, C.byref(f),
+                       Yh.ctypes.data, k, n_out.data_ptr(), ids.data_ptr(), mf.data_ptr(),
+                       stat.data_ptr(), pv.data_ptr()), name)
+        return n_out, ids, mf, stat, pv
+
+    def ols_iterate(self, counts, pool_sizes, flt: Filter, Y):
+        return self._batch(self._lib.pg_ols_iter_batch_dev, "pg_ols_iter_batch_dev", counts,
+                           pool_sizes, flt, Y)
+
+    def correlation(self, counts, pool_sizes, flt: Filter, Y):
+        return self._batch(self._lib.pg_pearson_batch_dev, "pg_pearson_batch_dev", counts,
+                           pool_sizes, flt, Y)
+
+    def chisq(self, counts, pool_sizes, flt: Filter):
+        L, n, _ = counts.shape
+        ps = _host_f64(pool_sizes)
+        dev = counts.device
+        n_out = torch.empty(L, dtype=torch.int32, device=dev)
+        ids = torch.empty((L, 5), dtype=torch.int32, device=dev)
+        chi2 = torch.empty(L, dtype=torch.float64, device=dev)
+        pv = torch.empty(L, dtype=torch.float64, device=dev)
+        f = flt.to_c()
+        self._check(self._lib.pg_chisq_batch_dev(self._ctx, counts.data_ptr(), L, n, ps.ctypes.data,
+                                                 C.byref(f), n_out.data_ptr(), ids.data_ptr(),
+                                                 chi2.data_ptr(), pv.data_ptr()), "pg_chisq_batch_dev")
+        return n_out, ids, chi2, pv
+
+    # ---- genomic prediction -------------------------------------------------------------------
+    def gp_xxt(self, G: torch.Tensor, n: int | None = None) -> torch.Tensor:
+        p, ld, n = self._g_dims(G, n)
+        S = torch.empty((n, n), dtype=torch.float64, device=G.device)
+        self._check(self._lib.pg_gp_xxt_dev(self._ctx, self._dev(G, torch.float64), p, n, ld,
+                                            S.data_ptr()), "pg_gp_xxt_dev")
+        return S
+
+    def gp_ols(self, G: torch.Tensor, Y, row_idx, XXt=None, n: int | None = None):
+        p, ld, n = self._g_dims(G, n)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        ri = np.ascontiguousarray(np.asarray(row_idx, dtype=np.int64))
+        beta = torch.empty((p + 1, k), dtype=torch.float64, device=G.device)
+        xptr = None
+        if XXt is not None:
+            XXt = _host_f64(XXt)
+            xptr = XXt.ctypes.data
+        self._check(self._lib.pg_gp_ols_dev(self._ctx, self._dev(G, torch.float64), p, n, ld,
+                                            Yh.ctypes.data, k, ri.ctypes.data, len(ri), xptr,
+                                            beta.data_ptr()), "pg_gp_ols_dev")
+        return beta

