@@ -56,7 +56,8 @@ typedef struct {
  * context
  * ------------------------------------------------------------------------------------- */
 /* device: HIP ordinal.  stream: a hipStream_t owned by the caller (e.g. torch's current
- * stream) or NULL for the context's own stream. */
+ * stream); NULL = the device's default (null) stream.  All kernels and copies of this context
+ * are enqueued on that stream, so they are ordered with the caller's own work on it. */
 int pg_create(pg_ctx **out, int device, void *stream);
 void pg_destroy(pg_ctx *ctx);
 const char *pg_last_error(const pg_ctx *ctx);

@@ -51,17 +51,10 @@ extern "C" int pg_create(pg_ctx **out, int device, void *stream) {
     }
     pg_ctx *ctx = new pg_ctx();
     ctx->device = device;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
-        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-            delete ctx;
-            return PG_ERR_HIP;
-        }
-        ctx->own_stream = true;
-    }
+    // NULL = the device's default (null) stream, which is what torch hands out as cuda_stream 0;
+    // work is therefore always ordered with the caller's stream.
+    ctx->stream = (hipStream_t)stream;
+    ctx->own_stream = false;
     *out = ctx;
     return PG_OK;
 }

@@ -252,7 +252,8 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     int ldsld = (P.nb == 1) ? P.Tb * 16 : 2 * P.Tb * 16;
     if ((ldsld & 31) != 16) ldsld += 16;
     const size_t shmem = (size_t)2 * KIN_KC * ldsld * sizeof(double);
-    PG_CHECK(ctx, KIN_KC * ((ldsld + 1) / 2) <= KIN_PPT * KIN_THREADS, "kinship: staging overflow");
+    const int max_cols = (P.nb == 1) ? P.Tb * 16 : 2 * P.Tb * 16; // staged pools per locus row
+    PG_CHECK(ctx, KIN_KC * (max_cols / 2) <= KIN_PPT * KIN_THREADS, "kinship: staging overflow");
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_kinship_syrk),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     // slabs for tiles of pairs are disjoint but padding rows/cols of unwritten tiles are never read

