@@ -22,10 +22,14 @@ namespace {
 constexpr int KIN_THREADS = 1024;
 constexpr int KIN_WAVES = 16;
 constexpr int KIN_TPW = 6;  // max tiles per wave (ceil(91/16), ceil(81/16))
-constexpr int KIN_KC = 16;  // loci per LDS stage = 4 MFMA k-steps
-constexpr int KIN_PPT = 2;  // 16-byte staging pieces per thread per stage
+#ifndef KIN_KC_DEF
+#define KIN_KC_DEF 16
+#endif
+constexpr int KIN_KC = KIN_KC_DEF;  // loci per LDS stage (4 loci = one MFMA k-step)
+constexpr int KIN_PPT = (KIN_KC * 128 + KIN_THREADS - 1) / KIN_THREADS;  // 16-byte staging pieces per thread per stage
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
 struct KinParams {
     const double *G;
@@ -70,14 +74,16 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
 
     // ---- this wave's tiles ---------------------------------------------------------------
     const int ntiles = diag ? Ta * (Ta + 1) / 2 : Ta * Tbb;
+    // Every wave runs exactly KIN_TPW tile slots so that the k-loop is straight-line code; a slot
+    // beyond the tile list recomputes tile 0 into an accumulator that is never stored.
     int acol[KIN_TPW], bcol[KIN_TPW], orow[KIN_TPW], ocol[KIN_TPW];
-    int my_nt = 0;
+    bool live[KIN_TPW];
 #pragma unroll
     for (int u = 0; u < KIN_TPW; ++u) {
         const int t = wave + KIN_WAVES * u;
         int ti = 0, tj = 0;
+        live[u] = t < ntiles;
         if (t < ntiles) {
-            my_nt = u + 1;
             if (diag) {
                 int q = t;
                 for (ti = 0; ti < Ta; ++ti) {
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
 
     // ---- staging assignment (constant over the stages) -------------------------------------
     int st_loc[KIN_PPT], st_lcol[KIN_PPT];
-    int64_t st_goff[KIN_PPT];
+    int st_gcol[KIN_PPT];
     bool st_on[KIN_PPT], st_two[KIN_PPT];
 #pragma unroll
     for (int r = 0; r < KIN_PPT; ++r) {
@@ -117,7 +123,8 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         }
         st_lcol[r] = lcol;
         st_two[r] = two;
-        st_goff[r] = (int64_t)loc * P.ld + gcol;
+        st_gcol[r] = st_on[r] ? gcol : a0;
+        if (!st_on[r]) st_loc[r] = 0;
     }
 
     const int64_t l_begin = (int64_t)blockIdx.x * P.loci_per_wg;
@@ -129,26 +136,33 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     for (int i = tid; i < 2 * bufsz; i += KIN_THREADS) lds[i] = 0.0;
     __syncthreads();
 
-    double2 stage_reg[KIN_PPT];
-    auto stage_load = [&](int c) {
-        const int64_t lbase = l_begin + (int64_t)c * KIN_KC;
+    // Staging uses raw buffer loads over a descriptor that covers exactly this workgroup's slab:
+    // pieces of loci past the slab end are out of range and come back as zeros in hardware, so
+    // the loop carries no tail branches and the loads stay in flight across the MFMA block.
+    const uint64_t slab_bytes64 = (uint64_t)(l_end > l_begin ? l_end - l_begin : 0) * P.ld * 8;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(P.G + l_begin * P.ld), 0, (int)(uint32_t)slab_bytes64, 0x00020000);
+    uint4_t stage_reg[KIN_PPT];
+    uint32_t st_voff[KIN_PPT];
 #pragma unroll
-        for (int r = 0; r < KIN_PPT; ++r) {
-            double2 v = make_double2(0.0, 0.0);
-            if (st_on[r] && (lbase + st_loc[r]) < l_end) {
-                const double *src = P.G + lbase * P.ld + st_goff[r];
-                v = *reinterpret_cast<const double2 *>(src);
-                if (!st_two[r]) v.y = 0.0;
-            }
-            stage_reg[r] = v;
-        }
+    for (int r = 0; r < KIN_PPT; ++r)
+        st_voff[r] = st_on[r] ? (uint32_t)(((int64_t)st_loc[r] * P.ld + st_gcol[r]) * 8) : 0xFFFFFFF0u;
+    const uint32_t stage_stride = (uint32_t)(KIN_KC * P.ld * 8);
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < KIN_PPT; ++r)
+            // the whole offset goes through VGPR: the scalar offset is not range-checked on gfx9
+            stage_reg[r] = __builtin_amdgcn_raw_buffer_load_b128(
+                rsrc, st_on[r] ? st_voff[r] + (uint32_t)c * stage_stride : 0xFFFFFFF0u, 0, 0);
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < KIN_PPT; ++r) {
-            if (st_on[r])
-                *reinterpret_cast<double2 *>(&lds[buf * bufsz + st_loc[r] * ldsld + st_lcol[r]]) =
-                    stage_reg[r];
+            if (st_on[r]) {
+                uint4_t v = stage_reg[r];
+                if (!st_two[r]) { v.z = 0u; v.w = 0u; }
+                *reinterpret_cast<uint4_t *>(&lds[buf * bufsz + st_loc[r] * ldsld + st_lcol[r]]) = v;
+            }
         }
     };
 
@@ -164,22 +178,45 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
 
     for (int c = 0; c < nstages; ++c) {
         const bool more = (c + 1) < nstages;
+#ifndef KIN_EXP_NOSTAGE
         if (more) stage_load(c + 1);
+#endif
         const double *buf = lds + (c & 1) * bufsz;
+        // software pipeline: the fragments of k-step s+1 are requested before the MFMAs of
+        // k-step s are issued, so the LDS latency hides behind the 6 x 64-cycle MFMA block
+        double fa[2][KIN_TPW], fb[2][KIN_TPW];
+        const double *row0 = buf + kq * ldsld + fi;
+#pragma unroll
+        for (int u = 0; u < KIN_TPW; ++u) {
+            fa[0][u] = row0[acol[u]];
+#ifdef KIN_EXP_HALFREADS
+            fb[0][u] = fa[0][u];
+#else
+            fb[0][u] = row0[bcol[u]];
+#endif
+        }
 #pragma unroll
         for (int s = 0; s < KIN_KC / 4; ++s) {
-            const double *row = buf + (4 * s + kq) * ldsld + fi;
+            if (s + 1 < KIN_KC / 4) {
+                const double *row = buf + (4 * (s + 1) + kq) * ldsld + fi;
 #pragma unroll
-            for (int u = 0; u < KIN_TPW; ++u) {
-                if (u < my_nt) {
-                    const double a = row[acol[u]];
-                    const double b = row[bcol[u]];
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+                for (int u = 0; u < KIN_TPW; ++u) {
+                    fa[(s + 1) & 1][u] = row[acol[u]];
+#ifdef KIN_EXP_HALFREADS
+                    fb[(s + 1) & 1][u] = fa[(s + 1) & 1][u];
+#else
+                    fb[(s + 1) & 1][u] = row[bcol[u]];
+#endif
                 }
             }
+#pragma unroll
+            for (int u = 0; u < KIN_TPW; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s & 1][u], fb[s & 1][u], acc[u], 0, 0, 0);
         }
+#ifndef KIN_EXP_NOSTAGE
         if (more) stage_store((c + 1) & 1);
         __syncthreads();
+#endif
     }
 
     // ---- write this workgroup's partial tiles ---------------------------------------------
@@ -187,7 +224,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
 #pragma unroll
     for (int u = 0; u < KIN_TPW; ++u) {
-        if (u < my_nt) {
+        if (live[u]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = orow[u] + kq + 4 * r;
@@ -241,6 +278,9 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     if (nslab > max_slabs) nslab = (int)max_slabs;
     P.loci_per_wg = (p + nslab - 1) / nslab;
     P.loci_per_wg = (P.loci_per_wg + KIN_KC - 1) / KIN_KC * KIN_KC;
+    // a slab must be addressable with the 32-bit offsets of its buffer descriptor
+    const int64_t max_loci_per_wg = ((int64_t)0xFFFFFFF0 / (ld * 8)) / KIN_KC * KIN_KC - KIN_KC;
+    if (P.loci_per_wg > max_loci_per_wg) P.loci_per_wg = max_loci_per_wg;
     nslab = (int)((p + P.loci_per_wg - 1) / P.loci_per_wg);
 
     const size_t slab_bytes = (size_t)nslab * P.npad * P.npad * sizeof(double);
