@@ -104,14 +104,17 @@ class Engine:
         return S
 
     def kinship_set(self, S: torch.Tensor, p_total: int, Y, var_explained: float = 0.75,
-                    force_m: int = -1):
-        """K = S / p_total, eigen rule, covariates, projected phenotypes.  Returns (m, K, evals)."""
+                    force_m: int = -1, want_evals: bool = False):
+        """K = S / p_total, eigen rule, covariates, projected phenotypes.  Returns (m, K, evals);
+        evals is None unless want_evals (asking for them forces the full eigen-decomposition)."""
         n = S.shape[0]
         Yh = _host_f64(Y).reshape(n, -1)
-        K = np.empty((n, n)); ev = np.empty(n); m = C.c_int()
+        K = np.empty((n, n)); m = C.c_int()
+        ev = np.empty(n) if want_evals else None
         self._check(self._lib.pg_kinship_set(self._ctx, self._dev(S, torch.float64), int(p_total), n,
                                              Yh.ctypes.data, Yh.shape[1], float(var_explained),
-                                             int(force_m), C.byref(m), K.ctypes.data, ev.ctypes.data),
+                                             int(force_m), C.byref(m), K.ctypes.data,
+                                             ev.ctypes.data if want_evals else None),
                     "pg_kinship_set")
         return m.value, K, ev
 
@@ -165,8 +168,7 @@ class Engine:
         stat = torch.empty((L, 5, k), dtype=torch.float64, device=dev)
         pv = torch.empty((L, 5, k), dtype=torch.float64, device=dev)
         f = flt.to_c()
-        self._check(fn(self._ctx, self._dev(counts, torch.int32) if counts.dtype == torch.int32
-                       else self._dev(counts, torch.uint32), L, n, ps.ctypes.data, C.byref(f),
+        self._check(fn(self._ctx, self._dev(counts, torch.int32), L, n, ps.ctypes.data, C.byref(f),
                        Yh.ctypes.data, k, n_out.data_ptr(), ids.data_ptr(), mf.data_ptr(),
                        stat.data_ptr(), pv.data_ptr()), name)
         return n_out, ids, mf, stat, pv
@@ -188,7 +190,7 @@ class Engine:
         chi2 = torch.empty(L, dtype=torch.float64, device=dev)
         pv = torch.empty(L, dtype=torch.float64, device=dev)
         f = flt.to_c()
-        self._check(self._lib.pg_chisq_batch_dev(self._ctx, counts.data_ptr(), L, n, ps.ctypes.data,
+        self._check(self._lib.pg_chisq_batch_dev(self._ctx, self._dev(counts, torch.int32), L, n, ps.ctypes.data,
                                                  C.byref(f), n_out.data_ptr(), ids.data_ptr(),
                                                  chi2.data_ptr(), pv.data_ptr()), "pg_chisq_batch_dev")
         return n_out, ids, chi2, pv
