@@ -44,7 +44,7 @@ struct SweepDims {
 
 // One 32-pool chunk of a 64-locus tile: coalesced global loads -> wave-private LDS tile ->
 // lane-per-locus accumulation.  FULL = all 32 pools valid (compile-time trip count).
-template <int C, bool FULL>
+template <int C, bool FULL, bool SHIFT = true>
 __device__ __forceinline__ void sweep_chunk(const double *__restrict__ G,
                                             const double *__restrict__ Wp, double *tile,
                                             int64_t l0, int64_t p, int64_t ld, int pool0, int npool,
@@ -80,7 +80,7 @@ __device__ __forceinline__ void sweep_chunk(const double *__restrict__ G,
     __builtin_amdgcn_wave_barrier();
     // ---- lane = locus: walk the row; W is wave-uniform (scalar-cache operands) -----------------
     const double *row = tile + lane * SW_PITCH;
-    if (first) shift = row[0]; // any per-locus constant cancels because Z contains the intercept
+    if (SHIFT && first) shift = row[0]; // any per-locus constant cancels because Z contains the intercept
     if (FULL) {
 #pragma unroll
         for (int i = 0; i < SW_CH; i += 2) {
@@ -158,6 +158,41 @@ __global__ __launch_bounds__(SW_THREADS) void k_ols_sweep(
                 var[l * D.k + j] = vb;
                 pval[l * D.k + j] = pv;
             }
+        }
+    }
+}
+
+// gp::ols coefficient pass (gp/ols.rs:47-72): beta_l = sum_i G[l][i] * Z[i][j], the same
+// lane-per-locus streaming pass without the regression epilogue (Z = rows of pinv(X X^T) y
+// scattered to the training pools, zero elsewhere).
+template <int C>
+__global__ __launch_bounds__(SW_THREADS) void k_gp_beta(const double *__restrict__ G,
+                                                        const double *__restrict__ W,
+                                                        double *__restrict__ out, const SweepDims D) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double *tile = lds + wave * SW_TILE;
+    const int nfull = D.n / SW_CH;
+    const int ntail = D.n - nfull * SW_CH;
+    const int64_t wstride = (int64_t)gridDim.x * SW_WAVES;
+    for (int64_t t = (int64_t)blockIdx.x * SW_WAVES + wave; t < D.ntiles; t += wstride) {
+        const int64_t l0 = t * 64;
+        double acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0;
+        double s2 = 0.0, shift = 0.0;
+        for (int ch = 0; ch < nfull; ++ch)
+            sweep_chunk<C, true, false>(G, W + (size_t)ch * SW_CH * C, tile, l0, D.p, D.ld, ch * SW_CH, SW_CH,
+                                        lane, false, shift, s2, acc);
+        if (ntail)
+            sweep_chunk<C, false, false>(G, W + (size_t)nfull * SW_CH * C, tile, l0, D.p, D.ld, nfull * SW_CH,
+                                         ntail, lane, false, shift, s2, acc);
+        const int64_t l = l0 + lane;
+        if (l < D.p) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (c < D.k) out[l * D.k + c] = acc[c];
         }
     }
 }
@@ -445,4 +480,102 @@ extern "C" int pg_ols_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, in
     (void)hipFree(Gd);
     (void)hipFree(out);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gp::ols, n < p branch (gp/ols.rs:47-72): b = X^T pinv(X X^T) y over the training rows.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+static int launch_gp_beta(pg_ctx *ctx, const double *G, const double *W, double *out, const SweepDims &D, int grid) {
+    const size_t shmem = (size_t)SW_WAVES * SW_TILE * sizeof(double);
+    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gp_beta<C>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    pg_prof_begin(ctx, PG_K_GP_BETA);
+    hipLaunchKernelGGL(k_gp_beta<C>, dim3(grid), dim3(SW_THREADS), shmem, ctx->stream, G, W, out, D);
+    pg_prof_end(ctx);
+    PG_HIP(ctx, hipGetLastError());
+    return PG_OK;
+}
+
+extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
+                             int k, const int64_t *row_idx, int n_rows, const double *XXt_host_or_null,
+                             double *beta_dev) {
+    if (!ctx) return PG_ERR_INVALID;
+    PG_CHECK(ctx, G_dev && Y && row_idx && beta_dev && p > 0 && n >= 1 && k >= 1 && n_rows >= 1 && n_rows <= n,
+             "gp_ols: bad arguments");
+    PG_CHECK(ctx, ld >= n && (ld % 2) == 0, "gp_ols: ld must be even and >= n");
+    if ((int64_t)n >= p + 1)
+        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: tall design (n >= 1 + p) is not a GPU problem");
+    const int cols = round_cols(k);
+    if (cols < 0) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: at most %d traits per call", PG_MAX_SWEEP_COLS);
+    for (int a = 0; a < n_rows; ++a) PG_CHECK(ctx, row_idx[a] >= 0 && row_idx[a] < n, "gp_ols: row index out of range");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> full((size_t)n * n);
+    if (XXt_host_or_null) {
+        std::memcpy(full.data(), XXt_host_or_null, sizeof(double) * n * n);
+    } else {
+        if (ctx->S_n < n) {
+            PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->S_dev) PG_HIP(ctx, hipFree(ctx->S_dev));
+            ctx->S_dev = nullptr; ctx->S_n = 0;
+            PG_HIP(ctx, hipMalloc((void **)&ctx->S_dev, sizeof(double) * n * n));
+            ctx->S_n = n;
+        }
+        int rc = pg_launch_kinship(ctx, G_dev, p, n, ld, ctx->S_dev, true, PG_K_GP_XXT);
+        if (rc) return rc;
+        PG_HIP(ctx, hipMemcpyAsync(full.data(), ctx->S_dev, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // every training subset's X X^T is a principal sub-block of the full-data one
+    const int r = n_rows;
+    std::vector<double> A((size_t)r * r), Pi((size_t)r * r), V((size_t)r * k);
+    for (int a = 0; a < r; ++a)
+        for (int b = 0; b < r; ++b) A[(size_t)a * r + b] = full[(size_t)row_idx[a] * n + row_idx[b]];
+    if (pg_pinv_sym(A.data(), r, Pi.data()) != 0) return pg_fail(ctx, PG_ERR_INVALID, "gp_ols: pinv failed");
+    for (int a = 0; a < r; ++a)
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int b = 0; b < r; ++b) s += Pi[(size_t)a * r + b] * Y[(size_t)row_idx[b] * k + j];
+            V[(size_t)a * k + j] = s;
+        }
+    const int n_even = (n + 1) & ~1;
+    std::vector<double> Z((size_t)n_even * cols, 0.0), b0(k, 0.0);
+    for (int a = 0; a < r; ++a)
+        for (int j = 0; j < k; ++j) {
+            Z[(size_t)row_idx[a] * cols + j] = V[(size_t)a * k + j];
+            b0[j] += V[(size_t)a * k + j]; // intercept column of X is all ones
+        }
+    const size_t zbytes = Z.size() * sizeof(double);
+    if (zbytes > ctx->W_cap) {
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->W_dev) PG_HIP(ctx, hipFree(ctx->W_dev));
+        ctx->W_dev = nullptr; ctx->W_cap = 0;
+        PG_HIP(ctx, hipMalloc((void **)&ctx->W_dev, zbytes));
+        ctx->W_cap = zbytes;
+    }
+    ctx->st_m = -1; // the regression state in W_dev is gone
+    PG_HIP(ctx, hipMemcpyAsync(ctx->W_dev, Z.data(), zbytes, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(beta_dev, b0.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    hipDeviceProp_t prop;
+    PG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SweepDims D;
+    std::memset(&D, 0, sizeof D);
+    D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = k;
+    int64_t blocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
+    const int64_t cap = (int64_t)cus * 8;
+    const int grid = (int)(blocks < cap ? blocks : cap);
+    double *out = beta_dev + k; // rows 1..p
+    int rc;
+    switch (cols) {
+    case 2: rc = launch_gp_beta<2>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
+    case 3: rc = launch_gp_beta<3>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
+    case 4: rc = launch_gp_beta<4>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
+    case 6: rc = launch_gp_beta<6>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
+    case 8: rc = launch_gp_beta<8>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
+    default: return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: at most 8 traits per call");
+    }
+    if (rc) return rc;
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Z / b0 are stack-owned
+    return PG_OK;
 }

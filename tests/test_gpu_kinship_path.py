@@ -163,3 +163,23 @@ def test_full_size_properties(engine):
     gc = g - g.mean(dim=1, keepdim=True); yc = y - y.mean()
     bt = (gc @ yc) / (gc * gc).sum(dim=1)
     assert torch.allclose(b2[sl, 0], bt, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,p,k,rows", [(24, 3000, 1, None), (60, 5000, 2, "odd"), (200, 2500, 3, "fold")])
+def test_gp_ols_matches_oracle(engine, oracle, n, p, k, rows):
+    """gp::ols (gp/ols.rs:47-72): b = X^T pinv(X X^T) y on a training subset of the pools."""
+    G, Y = make(p, n, 43)
+    Y = np.hstack([Y, Y[:, :1] * 0.5 + 1.0])[:, :k]
+    idx = np.arange(n) if rows is None else (np.arange(1, n, 2) if rows == "odd" else np.array([i for i in range(n) if i % 10 != 3]))
+    beta = engine.gp_ols(G, Y, idx, n=n).cpu().numpy()
+    Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])
+    rc, ref = oracle.gp_ols(Xt, Y, idx, n=n)
+    assert rc == 0
+    scale = np.abs(ref).max()
+    assert np.allclose(beta, ref, rtol=1e-8, atol=1e-9 * scale)   # pinv of X X^T: cond ~1e6, see DESIGN.md
+    # the defining property tested by the reference (gp/ols.rs:245-246): the training rows are fitted
+    yhat = Xt.T[idx] @ beta
+    assert np.allclose(yhat, Y[idx], atol=1e-6 * np.abs(Y).max())
+    # and the precomputed full-data X X^T gives the same answer (principal sub-block reuse)
+    beta2 = engine.gp_ols(G, Y, idx, XXt=engine.gp_xxt(G, n).cpu().numpy(), n=n).cpu().numpy()
+    assert np.array_equal(beta, beta2)
