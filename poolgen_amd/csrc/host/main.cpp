@@ -1,0 +1,296 @@
+// main.cpp -- `poolgen` command line for the five hot subcommands, flag-compatible with the
+// reference CLI (src/main.rs:26-143): chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship
+// (and gp_ols as a plain coefficient dump).  Parsing/formatting/ordering follow the reference
+// (base/sync.rs:606-970, :972-1180; gwas/ols.rs:255-275, :372-433); all arithmetic on the loci
+// is done by libpoolgen_hip.so through its C ABI.  Anything else the reference CLI offers is out
+// of scope and reported as such.
+#include "host_util.h"
+#include "../../../include/poolgen_hip.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <numeric>
+#include <sstream>
+#include <stdexcept>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+using namespace pgh;
+
+struct Args {
+    std::string analysis, fname, output, phen_fname, phen_delim = ",";
+    double max_base_error_rate = 0.01, min_coverage_breadth = 1.0, min_allele_frequency = 0.001,
+           max_missingness_rate = 0.0, xxt = 0.75;
+    uint64_t min_coverage_depth = 1;
+    bool keep_ns = false, keep_p_minus_1 = false, generate_plots = false, sig_only = false;
+    int phen_name_col = 0, phen_pool_size_col = 1, n_threads = 1;
+    std::vector<int> phen_value_col{2};
+};
+
+static double parse_valid_freq(const std::string &v, const std::string &flag) { // helpers.rs:93-100
+    char *end = nullptr;
+    const double x = std::strtod(v.c_str(), &end);
+    if (v.empty() || *end != 0) throw std::runtime_error("`" + v + "` isn't a valid number (" + flag + ")");
+    if (x < 0.0 || x > 1.0) throw std::runtime_error("Value must be between 0.0 and 1.0, got `" + rust_display(x) + "` (" + flag + ")");
+    return x;
+}
+
+static Args parse_args(int argc, char **argv) {
+    Args a;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+        std::string k = argv[i], v;
+        auto eq = k.find('=');
+        bool has_v = false;
+        if (k.rfind("--", 0) == 0 && eq != std::string::npos) { v = k.substr(eq + 1); k = k.substr(0, eq); has_v = true; }
+        auto val = [&]() -> std::string {
+            if (has_v) return v;
+            if (i + 1 >= argc) throw std::runtime_error("missing value for " + k);
+            return argv[++i];
+        };
+        if (k == "-f" || k == "--fname") a.fname = val();
+        else if (k == "-o" || k == "--output") a.output = val();
+        else if (k == "-p" || k == "--phen-fname") a.phen_fname = val();
+        else if (k == "--phen-delim") a.phen_delim = val();
+        else if (k == "--phen-name-col") a.phen_name_col = std::stoi(val());
+        else if (k == "--phen-pool-size-col") a.phen_pool_size_col = std::stoi(val());
+        else if (k == "--phen-value-col") {
+            a.phen_value_col.clear();
+            std::stringstream ss(val());
+            std::string t;
+            while (std::getline(ss, t, ',')) a.phen_value_col.push_back(std::stoi(t));
+        } else if (k == "--n-threads") a.n_threads = std::stoi(val());
+        else if (k == "--max-base-error-rate") a.max_base_error_rate = parse_valid_freq(val(), k);
+        else if (k == "--min-coverage-breadth") a.min_coverage_breadth = parse_valid_freq(val(), k);
+        else if (k == "--min-coverage-depth") a.min_coverage_depth = std::stoull(val());
+        else if (k == "--min-allele-frequency") a.min_allele_frequency = parse_valid_freq(val(), k);
+        else if (k == "--max-missingness-rate") a.max_missingness_rate = parse_valid_freq(val(), k);
+        else if (k == "-x" || k == "--xxt-eigen-variance-explained") a.xxt = parse_valid_freq(val(), k);
+        else if (k == "--keep-ns") a.keep_ns = true;
+        else if (k == "--keep-p-minus-1") a.keep_p_minus_1 = true;
+        else if (k == "--generate-plots") a.generate_plots = true;
+        else if (k == "--output-sig-snps-only") a.sig_only = true;
+        else if (k == "--keep-lowercase-reference") { /* pileup only */ }
+        else if (k.rfind("-", 0) == 0) throw std::runtime_error("unknown flag " + k);
+        else pos.push_back(k);
+    }
+    if (pos.size() != 1) throw std::runtime_error("usage: poolgen <analysis> -f <sync> -p <phen.csv> [flags]");
+    a.analysis = pos[0];
+    if (a.fname.empty() || a.phen_fname.empty()) throw std::runtime_error("-f/--fname and -p/--phen-fname are required");
+    return a;
+}
+
+static std::string basename_no_ext(const std::string &f) { // sync.rs:889-902
+    const auto p = f.rfind('.');
+    return p == std::string::npos ? std::string() : f.substr(0, p);
+}
+
+static std::string unix_time_string() {
+    const double t = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    return rust_display(t);
+}
+
+// OpenOptions::create_new: refuse to overwrite (sync.rs:906, :942-947; ols.rs:285, :402-407)
+static FILE *create_new(const std::string &path) {
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0644);
+    if (fd < 0) throw std::runtime_error("Unable to create file: " + path + " (it must not exist)");
+    return fdopen(fd, "w");
+}
+
+struct Ctx {
+    pg_ctx *c = nullptr;
+    Ctx() {
+        if (pg_create(&c, 0, nullptr) != PG_OK) throw std::runtime_error(std::string("GPU: ") + pg_last_error(nullptr));
+    }
+    ~Ctx() { pg_destroy(c); }
+    void ok(int rc, const char *what) {
+        if (rc != PG_OK) throw std::runtime_error(std::string(what) + ": " + pg_last_error(c));
+    }
+};
+
+// pools with a missing phenotype are removed before the locus operators (remove_missing,
+// sync.rs:508-549).  The reference forgets to shrink FilterStats.pool_sizes and panics in that
+// case; here the pool sizes are subset consistently.
+static std::vector<int> complete_pools(const Phen &ph) {
+    std::vector<int> idx;
+    for (int i = 0; i < ph.n; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < ph.k; ++j) s += ph.phen[(size_t)i * ph.k + j];
+        if (!std::isnan(s)) idx.push_back(i);
+    }
+    return idx;
+}
+
+static int run(int argc, char **argv) {
+    const Args a = parse_args(argc, argv);
+    const std::map<std::string, int> known{{"chisq_test", 0}, {"pearson_corr", 1}, {"ols_iter", 2},
+                                           {"ols_iter_with_kinship", 3}};
+    if (!known.count(a.analysis))
+        throw std::runtime_error("Invalid analysis utility for this build: `" + a.analysis +
+                                 "` (available: chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship)");
+    if (a.generate_plots || a.sig_only)
+        throw std::runtime_error("--generate-plots / --output-sig-snps-only call the reference's python scripts and are out of scope here");
+    Phen ph = parse_phen(a.phen_fname, a.phen_delim, a.phen_name_col, a.phen_pool_size_col, a.phen_value_col);
+    SyncBatch sb = parse_sync_file(a.fname, a.n_threads);
+    if (sb.size() == 0) throw std::runtime_error("no loci in " + a.fname);
+    if (sb.n != ph.n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
+    pg_filter flt{};
+    flt.remove_ns = a.keep_ns ? 0 : 1;
+    flt.min_coverage_depth = a.min_coverage_depth;
+    flt.min_allele_frequency = a.min_allele_frequency;
+    flt.max_missingness_rate = a.max_missingness_rate;
+    const int n = sb.n, k = ph.k;
+    const int64_t L = sb.size();
+    const int mode = known.at(a.analysis);
+    Ctx gpu;
+
+    if (mode <= 2) {
+        std::string out = a.output;
+        if (out.empty()) out = basename_no_ext(a.fname) + "-" + unix_time_string() + "-" + a.analysis + ".csv"; // sync.rs:903
+        // probe, as the reference does before any work (sync.rs:906)
+        { FILE *t = create_new(out); fclose(t); ::unlink(out.c_str()); }
+        std::vector<int32_t> n_out(L), ids((size_t)L * PG_MAX_OUT);
+        std::vector<double> mf((size_t)L * PG_MAX_OUT), stat, pv;
+        std::string header;
+        if (mode == 0) {
+            stat.resize(L); pv.resize(L);
+            gpu.ok(pg_chisq_batch(gpu.c, sb.counts.data(), L, n, ph.pool_sizes.data(), &flt, n_out.data(), ids.data(),
+                                  stat.data(), pv.data()), "chisq_test");
+            header = "#chr,pos,alleles,statistic,pvalue\n"; // sync.rs:766
+        } else {
+            // pearson_corr keeps every pool (pairwise-complete inside); ols_iter drops incomplete pools first
+            std::vector<uint32_t> counts2;
+            std::vector<double> Y = ph.phen, ps = ph.pool_sizes;
+            int n2 = n;
+            const uint32_t *cptr = sb.counts.data();
+            if (mode == 2) {
+                const std::vector<int> keep = complete_pools(ph);
+                if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
+                if ((int)keep.size() != n) {
+                    std::cerr << "warning: " << n - keep.size() << " pools without phenotype removed (pool sizes subset accordingly)\n";
+                    n2 = (int)keep.size();
+                    counts2.resize((size_t)L * n2 * 6);
+                    for (int64_t l = 0; l < L; ++l)
+                        for (int i = 0; i < n2; ++i)
+                            std::memcpy(&counts2[((size_t)l * n2 + i) * 6], &sb.counts[((size_t)l * n + keep[i]) * 6], 24);
+                    Y.clear(); ps.clear();
+                    for (int i : keep) { ps.push_back(ph.pool_sizes[i]); for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]); }
+                    cptr = counts2.data();
+                }
+            }
+            stat.resize((size_t)L * PG_MAX_OUT * k); pv.resize((size_t)L * PG_MAX_OUT * k);
+            if (mode == 1)
+                gpu.ok(pg_pearson_batch(gpu.c, cptr, L, n2, ps.data(), &flt, Y.data(), k, n_out.data(), ids.data(),
+                                        mf.data(), stat.data(), pv.data()), "pearson_corr");
+            else
+                gpu.ok(pg_ols_iter_batch(gpu.c, cptr, L, n2, ps.data(), &flt, Y.data(), k, n_out.data(), ids.data(),
+                                         mf.data(), stat.data(), pv.data()), "ols_iter");
+            header = "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n"; // sync.rs:950
+        }
+        FILE *fo = create_new(out);
+        fputs(header.c_str(), fo);
+        std::string line;
+        for (int64_t l = 0; l < L; ++l) {
+            if (n_out[l] <= 0) continue;
+            line.clear();
+            if (mode == 0) { // chisq_test.rs:37-45
+                std::string al;
+                for (int j = 0; j < n_out[l] && j < PG_MAX_OUT; ++j) al.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + j]]);
+                line = sb.chrom[l] + "," + std::to_string(sb.pos[l]) + "," + al + "," + roundup_own(stat[l], 6) + "," +
+                       rust_display(pv[l]) + "\n";
+            } else {
+                for (int i = 0; i < n_out[l]; ++i)
+                    for (int j = 0; j < k; ++j) {
+                        const size_t e = ((size_t)l * PG_MAX_OUT + i) * k + j;
+                        const double f = mf[(size_t)l * PG_MAX_OUT + i];
+                        line += sb.chrom[l] + "," + std::to_string(sb.pos[l]) + "," + ALLELES[ids[(size_t)l * PG_MAX_OUT + i]] + ",";
+                        if (mode == 2) // ols.rs:263-271
+                            line += roundup_own(f, 8) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
+                                    roundup_own(pv[e], 12) + "\n";
+                        else // correlation_test.rs:117-124
+                            line += rust_display(f) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
+                                    rust_display(pv[e]) + "\n";
+                    }
+            }
+            fputs(line.c_str(), fo);
+        }
+        fclose(fo);
+        std::cout << out << "\n"; // main.rs:507
+        return 0;
+    }
+
+    // ---------------- ols_iter_with_kinship (main.rs:280-298) -------------------------------------
+    FilterStats fs;
+    fs.remove_ns = !a.keep_ns;
+    fs.min_coverage_depth = a.min_coverage_depth;
+    fs.min_allele_frequency = a.min_allele_frequency;
+    fs.max_missingness_rate = a.max_missingness_rate;
+    fs.pool_sizes = ph.pool_sizes;
+    // load(): filter + frequencies per locus, then sort by (chromosome, position) (sync.rs:1092-1101)
+    std::vector<int64_t> order(L);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        const int c = sb.chrom[x].compare(sb.chrom[y]);
+        return c != 0 ? c < 0 : sb.pos[x] < sb.pos[y];
+    });
+    // labels carry the leading "intercept" entry of the reference matrix (sync.rs:1121-1126)
+    std::vector<std::string> lab_chr{"intercept"}, lab_al{"intercept"};
+    std::vector<uint64_t> lab_pos{0};
+    const std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
+    if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
+    const int n2 = (int)keep.size();
+    const int64_t ld = n2 + (n2 & 1);
+    std::vector<double> G, freq;
+    for (int64_t oi = 0; oi < L; ++oi) {
+        const int64_t l = order[oi];
+        const std::vector<int> al = filter_to_frequencies(&sb.counts[(size_t)l * n * 6], n, fs, a.keep_p_minus_1, freq);
+        const int na = (int)al.size();
+        for (int j = 0; j < na; ++j) {
+            lab_chr.push_back(sb.chrom[l]); lab_pos.push_back(sb.pos[l]); lab_al.push_back(std::string(1, ALLELES[al[j]]));
+            const size_t base = G.size();
+            G.resize(base + ld, 0.0);
+            for (int i = 0; i < n2; ++i) G[base + i] = freq[(size_t)keep[i] * na + j];
+        }
+    }
+    const int64_t p = (int64_t)lab_chr.size() - 1;
+    if (p <= 0) throw std::runtime_error("no loci passed the filters");
+    std::vector<double> Y;
+    for (int i : keep) for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]);
+    if (!a.output.empty()) { FILE *t = create_new(a.output); fclose(t); ::unlink(a.output.c_str()); } // ols.rs:285
+    std::vector<double> beta((size_t)p * k), var((size_t)p * k), pval((size_t)p * k);
+    int m = 0;
+    gpu.ok(pg_ols_kinship(gpu.c, G.data(), p, n2, ld, Y.data(), k, a.xxt, -1, &m, nullptr, beta.data(), var.data(),
+                          pval.data()), "ols_iter_with_kinship");
+    std::string out = a.output;
+    if (out.empty()) // ols.rs:393-398
+        out = basename_no_ext(a.fname) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";
+    FILE *fo = create_new(out);
+    fputs("#chr,pos,alleles,phenotype,statistic,pvalue\n", fo); // ols.rs:409
+    for (int j = 0; j < k; ++j)
+        for (int64_t i = 0; i < p; ++i) {
+            // the reference labels coefficient i with entry i of the (1+p)-long label vectors, i.e.
+            // shifted by the intercept entry (ols.rs:421-425) -- reproduced as is
+            const std::string line = lab_chr[i] + "," + std::to_string(lab_pos[i]) + "," + lab_al[i] + ",Pheno_" +
+                                     std::to_string(j) + "," + rust_display(beta[(size_t)i * k + j]) + "," +
+                                     rust_display(pval[(size_t)i * k + j]) + "\n";
+            fputs(line.c_str(), fo);
+        }
+    fclose(fo);
+    std::cout << out << "\n";
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    try {
+        return run(argc, argv);
+    } catch (const std::exception &e) {
+        std::cerr << "poolgen: " << e.what() << "\n";
+        return 1;
+    }
+}

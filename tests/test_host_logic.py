@@ -1,0 +1,92 @@
+"""CPU tests of the CLI's host logic (C++): Rust-compatible formatting, phenotype parser, sync
+parser and the locus filter/loader, against the oracle and the reference's literals."""
+import json
+import random
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+HC = ROOT / "poolgen_amd" / "csrc" / "hostcheck"
+GOLD = Path(__file__).parent / "golden"
+LIT = json.loads((GOLD / "reference_literals.json").read_text())
+
+
+def run(*args, stdin=None):
+    if not HC.exists():
+        subprocess.check_call(["make", "-C", str(HC.parent), "hostcheck", "-s"])
+    return subprocess.run([str(HC), *map(str, args)], input=stdin, capture_output=True, text=True, check=True).stdout
+
+
+def test_formatting_matches_oracle(oracle):
+    random.seed(3)
+    xs = [0.3, 4.0, 1e-7, 1.5e22, 0.1 + 0.2, -0.0, 0.0, 5e-324, 0.420000012435, 0.690000012435, float("nan"), float("inf")]
+    xs += [random.choice([random.random(), random.gauss(0, 50), random.random() * 1e-9, random.random() * 1e12,
+                          round(random.random(), 3), float(random.randint(-9, 9)) + 0.5]) for _ in range(20000)]
+    nds = [random.choice([4, 6, 7, 8, 12]) for _ in xs]
+    out = run("fmt", stdin="".join(f"{x!r} {nd}\n" for x, nd in zip(xs, nds))).splitlines()
+    assert len(out) == len(xs)
+    for x, nd, line in zip(xs, nds, out):
+        d, r = line.split(" ")
+        assert d == oracle.fmt(x), x
+        assert r == oracle.round_own(x, nd), (x, nd)
+
+
+def test_phen_parser_reference_literals():
+    g = LIT["phen"]  # base/phen.rs:221-236
+    rows = [l.split(" ") for l in run("phen", GOLD / "test.csv", ",", 0, 1, "2,3").splitlines()]
+    assert [r[0] for r in rows] == g["pool_names"]
+    assert [float(r[1]) for r in rows] == g["pool_sizes"]
+    assert [float(r[2]) for r in rows] == g["phen_matrix_by_trait"][0]
+    assert [float(r[3]) for r in rows] == g["phen_matrix_by_trait"][1]
+
+
+def test_phen_parser_missing_values(tmp_path):
+    f = tmp_path / "p.tsv"
+    f.write_text("#h\nA\t10\tNA\t1.5\r\nB\t30\t 2.5 \t\nC\t60\tnan\t-1e3\n")
+    rows = [l.split(" ") for l in run("phen", f, "\t", 0, 1, "2,3").splitlines()]
+    assert [r[1] for r in rows] == ["0.1", "0.3", "0.6"]          # phen.rs:83-84
+    assert [r[2] for r in rows] == ["NaN", "2.5", "NaN"] and [r[3] for r in rows] == ["1.5", "NaN", "-1000"]
+
+
+def _loader_check(oracle, threads, keep1, **kw):
+    f = oracle.filt(kw.get("remove_ns", True), kw.get("min_cov", 1), kw.get("maf", 0.001), kw.get("miss", 0.0))
+    ps = [20.0, 20.0, 20.0, 20.0, 20.0]
+    out = run("load", GOLD / "test.sync", threads, int(keep1), int(kw.get("remove_ns", True)), kw.get("min_cov", 1),
+              kw.get("maf", 0.001), kw.get("miss", 0.0), ",".join(map(str, ps))).splitlines()
+    L, n = map(int, out[0].split())
+    lines = [l for l in (GOLD / "test.sync").read_text().splitlines() if not l.startswith("#")]
+    assert (L, n) == (len(lines), 5) == (6674, 5)
+    for line, got in zip(lines, out[1:]):
+        _, chrom, pos, counts = oracle.parse_sync_line(line)
+        parts = got.split(" ")
+        assert parts[0] == chrom and int(parts[1]) == pos                      # file order kept across threads
+        res = oracle.filter_locus(counts, ps, f)
+        if res is None:
+            assert parts[2] == "" and len(parts) == 3
+            continue
+        ids, fc = res
+        fr = oracle.to_frequencies(fc)
+        if keep1:
+            fr, ids = oracle.sort_by_allele_freq(fr, ids, True)
+            fr, ids = fr[:, 1:], ids[1:]
+        assert parts[2] == "".join("ATCGND"[i] for i in ids)
+        vals = np.array([float.fromhex(x) for x in parts[3:]]).reshape(5, len(ids))
+        assert np.array_equal(vals, fr)                                           # bit-exact frequencies
+    return out
+
+
+def test_loader_matches_oracle_bit_exact(oracle):
+    _loader_check(oracle, 1, False)
+    _loader_check(oracle, 3, True)
+    _loader_check(oracle, 2, True, min_cov=10, maf=0.01)
+    _loader_check(oracle, 2, False, remove_ns=False, maf=0.0)
+
+
+def test_loader_first_locus_reference_literal(oracle):
+    g = LIT["loaded_first_locus"]  # base/sync.rs:1516-1535, 1616
+    out = run("load", GOLD / "test.sync", 2, 1, 1, 1, 0.005, 0.0, "20,20,20,20,20").splitlines()
+    parts = out[1].split(" ")
+    assert (parts[0], int(parts[1]), parts[2]) == (g["chromosome"], g["position"], g["alleles"])
+    assert [float.fromhex(x) for x in parts[3:]] == g["freq"]
