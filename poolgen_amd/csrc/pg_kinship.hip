@@ -176,47 +176,55 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     }
     __syncthreads();
 
+    // Rolling software pipeline over the (k-step, tile-slot) sequence of a stage: the fragment pair
+    // of item q + D is requested before the MFMA of item q is issued (ring of D + 1 pairs in
+    // registers).  The stage barrier sits D items before the end of the stage, so every wave still
+    // holds D MFMAs' worth of operands when it arrives: the barrier's arrival skew and the first LDS
+    // round trip of the next stage hide behind them.
+    constexpr int KS = KIN_KC / 4;
+    constexpr int NQ = KS * KIN_TPW; // items per stage
+    constexpr int D = 3, R = 4;
+    double fa[R], fb[R];
+    auto frag_load = [&](const double *buf, int q) {
+        const int s = q / KIN_TPW, u = q % KIN_TPW;
+        const double *row = buf + (4 * s + kq) * ldsld + fi;
+        fa[q & (R - 1)] = row[acol[u]];
+#ifdef KIN_EXP_HALFREADS
+        fb[q & (R - 1)] = fa[q & (R - 1)];
+#else
+        fb[q & (R - 1)] = row[bcol[u]];
+#endif
+    };
+    auto mfma_item = [&](int q) {
+        const int u = q % KIN_TPW;
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q & (R - 1)], fb[q & (R - 1)], acc[u], 0, 0, 0);
+    };
+    static_assert(NQ % R == 0 && NQ > 2 * D, "ring indexing assumes the stage length is a multiple of the ring");
+    if (nstages > 0) {
+#pragma unroll
+        for (int q = 0; q < D; ++q) frag_load(lds, q);
+    }
     for (int c = 0; c < nstages; ++c) {
         const bool more = (c + 1) < nstages;
 #ifndef KIN_EXP_NOSTAGE
         if (more) stage_load(c + 1);
 #endif
         const double *buf = lds + (c & 1) * bufsz;
-        // software pipeline: the fragments of k-step s+1 are requested before the MFMAs of
-        // k-step s are issued, so the LDS latency hides behind the 6 x 64-cycle MFMA block
-        double fa[2][KIN_TPW], fb[2][KIN_TPW];
-        const double *row0 = buf + kq * ldsld + fi;
+        const double *nbuf = lds + ((c + 1) & 1) * bufsz;
 #pragma unroll
-        for (int u = 0; u < KIN_TPW; ++u) {
-            fa[0][u] = row0[acol[u]];
-#ifdef KIN_EXP_HALFREADS
-            fb[0][u] = fa[0][u];
-#else
-            fb[0][u] = row0[bcol[u]];
-#endif
-        }
-#pragma unroll
-        for (int s = 0; s < KIN_KC / 4; ++s) {
-            if (s + 1 < KIN_KC / 4) {
-                const double *row = buf + (4 * (s + 1) + kq) * ldsld + fi;
-#pragma unroll
-                for (int u = 0; u < KIN_TPW; ++u) {
-                    fa[(s + 1) & 1][u] = row[acol[u]];
-#ifdef KIN_EXP_HALFREADS
-                    fb[(s + 1) & 1][u] = fa[(s + 1) & 1][u];
-#else
-                    fb[(s + 1) & 1][u] = row[bcol[u]];
-#endif
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < KIN_TPW; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s & 1][u], fb[s & 1][u], acc[u], 0, 0, 0);
+        for (int q = 0; q < NQ - D; ++q) {
+            frag_load(buf, q + D);
+            mfma_item(q);
         }
 #ifndef KIN_EXP_NOSTAGE
         if (more) stage_store((c + 1) & 1);
         __syncthreads();
 #endif
+#pragma unroll
+        for (int q = NQ - D; q < NQ; ++q) {
+            if (more) frag_load(nbuf, q + D - NQ);
+            mfma_item(q);
+        }
     }
 
     // ---- write this workgroup's partial tiles ---------------------------------------------
