@@ -82,6 +82,14 @@ int pg_profile_get(pg_ctx *ctx, int kernel_id, double *total_ms, int64_t *launch
  *   4. pg_ols_sweep_dev      : per-column fit of y ~ [1 | C | g], last coefficient
  * pg_ols_kinship_dev runs 1,3,4 on one GPU.
  * ------------------------------------------------------------------------------------- */
+/* Optional, before pg_kinship_partial_dev: announce the phenotypes (host, n x k row-major, no NaN,
+ * k <= 4).  The kinship pass then also accumulates, from the SAME read of G, the three per-locus
+ * sums an intercept-only fit needs.  If the n_eigenvecs rule later yields m = 0 (the outcome of the
+ * default -x 0.75 on uncentred allele-frequency kinships, where lambda_1 carries ~98 % of the trace),
+ * pg_ols_sweep_dev closes the fits from those sums instead of reading G a second time; for m > 0 the
+ * sums are ignored and the regular sweep runs.  Results are the same either way (same formula,
+ * different summation order).  pg_set_phenotypes(ctx, 0, NULL, 0) switches the behaviour off. */
+int pg_set_phenotypes(pg_ctx *ctx, int n, const double *Y, int k);
 /* S_dev: n x n fp64, row-major, full symmetric sum_l g_l g_l^T over this call's p columns. */
 int pg_kinship_partial_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
                            double *S_dev);

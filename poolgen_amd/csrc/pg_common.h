@@ -36,6 +36,18 @@ struct pg_ctx {
     size_t W_cap = 0;
     double *S_dev = nullptr;     // n x n kinship sum of the single-GPU convenience path
     int S_n = 0;
+    // speculative intercept-only sums produced by the kinship pass (see pg_set_phenotypes)
+    std::vector<double> ph_Y;    // n x k row-major copy of the phenotypes announced up front
+    int ph_n = 0, ph_k = 0;
+    double *ph_ytil_dev = nullptr; // k x 256 centred phenotypes, zero padded
+    double ph_syy[4] = {0, 0, 0, 0};
+    double *spec_dev = nullptr;  // p x (2 + k): sum g', sum g'^2, sum g' ytil_t   (g' = g - g[0])
+    size_t spec_cap = 0;
+    const double *spec_G = nullptr;
+    int64_t spec_p = 0, spec_ld = 0;
+    int spec_n = 0, spec_k = 0;
+    bool spec_valid = false;
+    bool st_Y_matches_ph = false;
     // small pinned host staging
     void *pin = nullptr;
     size_t pin_bytes = 0;
@@ -71,4 +83,4 @@ int pg_pinv_sym(const double *A, int n, double *out);
 
 // launchers (defined in the .hip files)
 int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
-                      bool add_intercept, int kid);
+                      bool add_intercept, int kid, bool allow_fuse = false);

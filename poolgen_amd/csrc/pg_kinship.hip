@@ -21,6 +21,7 @@ namespace {
 
 constexpr int KIN_THREADS = 1024;
 constexpr int KIN_WAVES = 16;
+constexpr int KIN_FUSE_MAXK = 2; // traits the fused intercept-only pass carries
 constexpr int KIN_TPW = 6;  // max tiles per wave (ceil(91/16), ceil(81/16))
 #ifndef KIN_KC_DEF
 #define KIN_KC_DEF 16
@@ -31,6 +32,14 @@ constexpr int KIN_PPT = (KIN_KC * 128 + KIN_THREADS - 1) / KIN_THREADS;  // 16-b
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
+// v + (v shifted by a DPP control) on the VALU only: the generic __shfl_xor goes through ds_bpermute,
+// whose latency would stall the issuing wave in the middle of the MFMA stream.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
 struct KinParams {
     const double *G;
     int64_t p;
@@ -38,8 +47,13 @@ struct KinParams {
     int64_t loci_per_wg;
     double *slabs; // [gridDim.x][npad * npad]
     int n, T, npad, Tb, nb;
+    // fused speculative intercept-only sums (FUSE kernels only)
+    const double *ytil; // k x 256 centred phenotypes, zero padded
+    double *spec;       // p x (2 + k)
+    int k;
 };
 
+template <bool FUSE>
 __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -134,6 +148,9 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
 
     // zero both buffers once: the padding columns must stay zero for the edge tiles
     for (int i = tid; i < 2 * bufsz; i += KIN_THREADS) lds[i] = 0.0;
+    double *ylds = lds + 2 * bufsz; // FUSE: KIN_FUSE_MAXK x 256 centred phenotypes, then the partial-sum scratch
+    if (FUSE)
+        for (int i = tid; i < P.k * 256; i += KIN_THREADS) ylds[i] = P.ytil[i];
     __syncthreads();
 
     // Staging uses raw buffer loads over a descriptor that covers exactly this workgroup's slab:
@@ -200,6 +217,51 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q & (R - 1)], fb[q & (R - 1)], acc[u], 0, 0, 0);
     };
     static_assert(NQ % R == 0 && NQ > 2 * D, "ring indexing assumes the stage length is a multiple of the ring");
+    // FUSE: from the stage that is in LDS anyway, wave w also forms the sums an intercept-only fit of
+    // locus w of the stage needs (g' = g - g[0]):  sum g', sum g'^2, sum g' ytil_t.  Its 64 lanes cover
+    // the pools 4 apiece; the 64 partials per value are transposed through a wave-private LDS scratch
+    // so that row v of the wave (16 lanes) holds value v, 4 partials per lane, and a 4-step intra-row
+    // DPP shift-add finishes the sum in lanes 15/31/47/63 -- no ds_bpermute, no cross-row step, no
+    // extra barrier (a wave's own LDS writes and reads are ordered).
+    const int NV = 2 + P.k;
+    double *scratch = ylds + KIN_FUSE_MAXK * 256 + wave * (4 * 64); // [4 values][64 lanes]
+    auto spec_pass = [&](const double *buf, int64_t lbase) {
+#pragma unroll
+        for (int jl = 0; jl < KIN_KC / KIN_WAVES; ++jl) {
+            const int loc = wave + KIN_WAVES * jl;
+            const double *row = buf + loc * ldsld;
+            const double shift = row[0]; // same address in every lane: an LDS broadcast
+            double s1 = 0.0, s2 = 0.0, sy[KIN_FUSE_MAXK];
+#pragma unroll
+            for (int t = 0; t < KIN_FUSE_MAXK; ++t) sy[t] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pool = lane + 64 * j;
+                const double gv = row[pool < ldsld ? pool : ldsld - 1];
+                const double d = (pool < P.n) ? gv - shift : 0.0;
+                s1 += d;
+                s2 = fma(d, d, s2);
+#pragma unroll
+                for (int t = 0; t < KIN_FUSE_MAXK; ++t)
+                    if (t < P.k) sy[t] = fma(d, ylds[t * 256 + pool], sy[t]);
+            }
+            scratch[lane] = s1;
+            scratch[64 + lane] = s2;
+#pragma unroll
+            for (int t = 0; t < KIN_FUSE_MAXK; ++t) scratch[(2 + t) * 64 + lane] = sy[t];
+            __builtin_amdgcn_wave_barrier();
+            const int v = lane >> 4, r = lane & 15;
+            const double *sc = scratch + v * 64 + r;
+            double tot = (sc[0] + sc[16]) + (sc[32] + sc[48]);
+            tot = dpp_add<0x111, 0xf>(tot); // row_shr:1
+            tot = dpp_add<0x112, 0xf>(tot); // row_shr:2
+            tot = dpp_add<0x114, 0xf>(tot); // row_shr:4
+            tot = dpp_add<0x118, 0xf>(tot); // row_shr:8 -> lane 15 of row v holds value v
+            const int64_t l = lbase + loc;
+            if (r == 15 && v < NV && l < l_end) P.spec[l * NV + v] = tot;
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
     if (nstages > 0) {
 #pragma unroll
         for (int q = 0; q < D; ++q) frag_load(lds, q);
@@ -218,6 +280,9 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         }
 #ifndef KIN_EXP_NOSTAGE
         if (more) stage_store((c + 1) & 1);
+#endif
+        if (FUSE) spec_pass(buf, l_begin + (int64_t)c * KIN_KC); // staging registers are free again here
+#ifndef KIN_EXP_NOSTAGE
         __syncthreads();
 #endif
 #pragma unroll
@@ -262,7 +327,7 @@ __global__ void k_kinship_reduce(const double *__restrict__ slabs, int nslabs, i
 } // namespace
 
 int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
-                      bool add_intercept, int kid) {
+                      bool add_intercept, int kid, bool allow_fuse) {
     PG_CHECK(ctx, G && S, "kinship: null pointer");
     PG_CHECK(ctx, p > 0 && n > 0, "kinship: need p > 0 and n > 0 (p=%lld n=%d)", (long long)p, n);
     PG_CHECK(ctx, ld >= n && (ld % 2) == 0, "kinship: ld (%lld) must be even and >= n (%d)",
@@ -299,15 +364,41 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     // worst-case LDS row: two blocks of Tb tiles (+16 pad)
     int ldsld = (P.nb == 1) ? P.Tb * 16 : 2 * P.Tb * 16;
     if ((ldsld & 31) != 16) ldsld += 16;
-    const size_t shmem = (size_t)2 * KIN_KC * ldsld * sizeof(double);
+    // fused speculative intercept-only sums: only in the single-block path and with phenotypes announced
+    const size_t fuse_lds = (size_t)2 * KIN_KC * ldsld * 8 + ((size_t)KIN_FUSE_MAXK * 256 + (size_t)KIN_WAVES * 4 * 64) * 8;
+    const bool fuse = allow_fuse && fuse_lds <= 160 * 1024 && P.nb == 1 && ctx->ph_n == n && ctx->ph_k >= 1 && ctx->ph_k <= KIN_FUSE_MAXK &&
+                      ctx->ph_ytil_dev != nullptr;
+    P.ytil = nullptr; P.spec = nullptr; P.k = 0;
+    ctx->spec_valid = false;
+    if (fuse) {
+        const size_t need = (size_t)p * (2 + ctx->ph_k) * sizeof(double);
+        if (need > ctx->spec_cap) {
+            PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->spec_dev) PG_HIP(ctx, hipFree(ctx->spec_dev));
+            ctx->spec_dev = nullptr; ctx->spec_cap = 0;
+            PG_HIP(ctx, hipMalloc((void **)&ctx->spec_dev, need));
+            ctx->spec_cap = need;
+        }
+        P.ytil = ctx->ph_ytil_dev; P.spec = ctx->spec_dev; P.k = ctx->ph_k;
+    }
+    const size_t shmem = (size_t)2 * KIN_KC * ldsld * sizeof(double) + (fuse ? ((size_t)KIN_FUSE_MAXK * 256 + (size_t)KIN_WAVES * 4 * 64) * sizeof(double) : 0);
     const int max_cols = (P.nb == 1) ? P.Tb * 16 : 2 * P.Tb * 16; // staged pools per locus row
     PG_CHECK(ctx, KIN_KC * (max_cols / 2) <= KIN_PPT * KIN_THREADS, "kinship: staging overflow");
-    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_kinship_syrk),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    // slabs for tiles of pairs are disjoint but padding rows/cols of unwritten tiles are never read
     pg_prof_begin(ctx, kid);
-    hipLaunchKernelGGL(k_kinship_syrk, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
+    if (fuse) {
+        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_kinship_syrk<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k_kinship_syrk<true>, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
+    } else {
+        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_kinship_syrk<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k_kinship_syrk<false>, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
+    }
     pg_prof_end(ctx);
+    if (fuse) {
+        ctx->spec_G = G; ctx->spec_p = p; ctx->spec_ld = ld; ctx->spec_n = n; ctx->spec_k = ctx->ph_k;
+        ctx->spec_valid = true;
+    }
     PG_HIP(ctx, hipGetLastError());
     pg_prof_begin(ctx, PG_K_KINSHIP_REDUCE);
     hipLaunchKernelGGL(k_kinship_reduce, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream,
@@ -320,7 +411,7 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
 extern "C" int pg_kinship_partial_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
                                       int64_t ld, double *S_dev) {
     if (!ctx) return PG_ERR_INVALID;
-    return pg_launch_kinship(ctx, G_dev, p, n, ld, S_dev, false, PG_K_KINSHIP);
+    return pg_launch_kinship(ctx, G_dev, p, n, ld, S_dev, false, PG_K_KINSHIP, true);
 }
 
 extern "C" int pg_gp_xxt_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
@@ -328,4 +419,36 @@ extern "C" int pg_gp_xxt_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
     if (!ctx) return PG_ERR_INVALID;
     // X = [1 | G^T]  =>  X X^T = 1 1^T + sum_l g_l g_l^T
     return pg_launch_kinship(ctx, G_dev, p, n, ld, XXt_dev, true, PG_K_GP_XXT);
+}
+
+extern "C" int pg_set_phenotypes(pg_ctx *ctx, int n, const double *Y, int k) {
+    if (!ctx) return PG_ERR_INVALID;
+    ctx->spec_valid = false;
+    ctx->ph_n = 0; ctx->ph_k = 0; ctx->ph_Y.clear();
+    if (n == 0 || !Y) return PG_OK; // switched off
+    PG_CHECK(ctx, n >= 2 && k >= 1, "set_phenotypes: bad shape n=%d k=%d", n, k);
+    if (k > 4 || n > 256) return PG_OK; // not an error: the regular two-pass path is used
+    for (int i = 0; i < n * k; ++i)
+        PG_CHECK(ctx, Y[i] == Y[i], "set_phenotypes: phenotype matrix contains NaN; remove pools with "
+                                    "missing phenotypes first (gwas/ols.rs:287)");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> yt((size_t)k * 256, 0.0);
+    for (int t = 0; t < k; ++t) {
+        double mu = 0.0;
+        for (int i = 0; i < n; ++i) mu += Y[(size_t)i * k + t];
+        mu /= n;
+        double syy = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double y = Y[(size_t)i * k + t] - mu;
+            yt[(size_t)t * 256 + i] = y;
+            syy += y * y;
+        }
+        ctx->ph_syy[t] = syy;
+    }
+    if (!ctx->ph_ytil_dev) PG_HIP(ctx, hipMalloc((void **)&ctx->ph_ytil_dev, sizeof(double) * 4 * 256));
+    PG_HIP(ctx, hipMemcpyAsync(ctx->ph_ytil_dev, yt.data(), sizeof(double) * k * 256, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ph_Y.assign(Y, Y + (size_t)n * k);
+    ctx->ph_n = n; ctx->ph_k = k;
+    return PG_OK;
 }

@@ -42,6 +42,22 @@ struct SweepDims {
     double tau; // relative singularity threshold on s_gg / g'g
 };
 
+// Closing arithmetic of one (locus, trait) fit from the projected sums (gwas/ols.rs:102-116, 139-158)
+__device__ __forceinline__ void ols_close(double sgg, double sgy, double syy, bool bad, double dfe, int tdf,
+                                          const double *__restrict__ tcoef, int ntcoef, double &b,
+                                          double &vb, double &pv) {
+    b = NAN; vb = NAN; pv = NAN;
+    if (bad) return;
+    b = sgy / sgg;
+    double rss = syy - sgy * b;
+    rss = rss < 0.0 ? 0.0 : rss;
+    vb = (rss / dfe) / sgg;
+    const double tt = (fabs(b) <= PG_EPS) ? 0.0 : b / sqrt(vb);
+    if (fabs(tt) <= PG_EPS) pv = 1.0;
+    else if (isnan(tt)) pv = 1.0;
+    else pv = pg_t_two_sided_p(fabs(tt), tdf, tcoef, ntcoef);
+}
+
 // One 32-pool chunk of a 64-locus tile: coalesced global loads -> wave-private LDS tile ->
 // lane-per-locus accumulation.  FULL = all 32 pools valid (compile-time trip count).
 template <int C, bool FULL, bool SHIFT = true>
@@ -143,17 +159,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_ols_sweep(
                 double sgy = 0.0;
 #pragma unroll
                 for (int a = 0; a < C; ++a) sgy = (a == D.m1 + j) ? acc[a] : sgy;
-                double b = NAN, vb = NAN, pv = NAN;
-                if (!bad) {
-                    b = sgy / sgg;
-                    double rss = syy[j] - sgy * b;
-                    rss = rss < 0.0 ? 0.0 : rss;
-                    vb = (rss / D.dfe) / sgg;
-                    const double tt = (fabs(b) <= PG_EPS) ? 0.0 : b / sqrt(vb);
-                    if (fabs(tt) <= PG_EPS) pv = 1.0;
-                    else if (isnan(tt)) pv = 1.0;
-                    else pv = pg_t_two_sided_p(fabs(tt), D.tdf, tcoef, D.ntcoef);
-                }
+                double b, vb, pv;
+                ols_close(sgg, sgy, syy[j], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
                 beta[l * D.k + j] = b;
                 var[l * D.k + j] = vb;
                 pval[l * D.k + j] = pv;
@@ -194,6 +201,26 @@ __global__ __launch_bounds__(SW_THREADS) void k_gp_beta(const double *__restrict
             for (int c = 0; c < C; ++c)
                 if (c < D.k) out[l * D.k + c] = acc[c];
         }
+    }
+}
+
+// Intercept-only fits closed from the sums the fused kinship pass left behind (pg_set_phenotypes):
+// spec[l] = { sum g', sum g'^2, sum g' ytil_t }, g' = g - g[0].  With Z = [1]: u = sum g' / sqrt(n).
+__global__ void k_sweep_finish(const double *__restrict__ spec, const double *__restrict__ syy,
+                               const double *__restrict__ tcoef, double *__restrict__ beta,
+                               double *__restrict__ var, double *__restrict__ pval, const SweepDims D) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= D.p) return;
+    const double *sp = spec + l * (2 + D.k);
+    const double s1 = sp[0], s2 = sp[1];
+    const double sgg = s2 - s1 * s1 / (double)D.n;
+    const bool bad = !(sgg > D.tau * s2);
+    for (int j = 0; j < D.k; ++j) {
+        double b, vb, pv;
+        ols_close(sgg, sp[2 + j], syy[j], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
+        beta[l * D.k + j] = b;
+        var[l * D.k + j] = vb;
+        pval[l * D.k + j] = pv;
     }
 }
 
@@ -301,6 +328,8 @@ extern "C" int pg_covariates_set(pg_ctx *ctx, int n, const double *Cmat, int m, 
     ctx->st_m = m;
     ctx->st_k = k;
     ctx->st_cols = cols;
+    ctx->st_Y_matches_ph = (ctx->ph_n == n && ctx->ph_k == k && ctx->ph_Y.size() == (size_t)n * k &&
+                            std::memcmp(ctx->ph_Y.data(), Y, sizeof(double) * n * k) == 0);
     return PG_OK;
 }
 
@@ -409,6 +438,16 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
     P.D.tdf = ctx->tcoef_df; P.D.ntcoef = ctx->tcoef_len;
     P.D.dfe = (double)n - (double)(ctx->st_m + 2);
     P.D.tau = 1e-12;
+    if (ctx->st_m == 0 && ctx->spec_valid && ctx->spec_G == G_dev && ctx->spec_p == p && ctx->spec_n == n &&
+        ctx->spec_ld == ld && ctx->spec_k == ctx->st_k && ctx->ph_n == n && ctx->st_Y_matches_ph) {
+        // m = 0: the kinship pass already formed the sums of the intercept-only fits from its read of G
+        pg_prof_begin(ctx, PG_K_SWEEP);
+        hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->spec_dev, ctx->syy_dev, ctx->tcoef_dev, beta_dev, var_dev, pval_dev, P.D);
+        pg_prof_end(ctx);
+        PG_HIP(ctx, hipGetLastError());
+        return PG_OK;
+    }
     int64_t blocks = (P.D.ntiles + SW_WAVES - 1) / SW_WAVES;
     const int64_t cap = (int64_t)cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
@@ -441,7 +480,9 @@ extern "C" int pg_ols_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
         ctx->S_n = n;
     }
     double *S_dev = ctx->S_dev;
-    int rc = pg_launch_kinship(ctx, G_dev, p, n, ld, S_dev, false, PG_K_KINSHIP);
+    int rc = pg_set_phenotypes(ctx, n, Y, k);
+    if (rc) return rc;
+    rc = pg_launch_kinship(ctx, G_dev, p, n, ld, S_dev, false, PG_K_KINSHIP, true);
     if (rc) return rc;
     rc = pg_kinship_set(ctx, S_dev, p, n, Y, k, var_explained, force_m, m_out, K_out, nullptr);
     if (rc) return rc;

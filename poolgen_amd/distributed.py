@@ -22,6 +22,8 @@ def shard_range(p_total: int, rank: int, world: int):
 def ols_with_covariate_sharded(engine, G_local: torch.Tensor, p_total: int, Y, var_explained=0.75,
                                force_m: int = -1, n: int | None = None, out=None, group=None):
     """One step of the sharded path.  Returns (m, K, beta_local, var_local, pval_local)."""
+    if hasattr(engine, "set_phenotypes"):
+        engine.set_phenotypes(Y)  # lets the kinship pass pre-compute the intercept-only fits
     S = engine.kinship_partial(G_local, n)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)

@@ -95,6 +95,16 @@ class Engine:
         p, ld = G.shape
         return int(p), int(ld), int(ld if n is None else n)
 
+    def set_phenotypes(self, Y, n: int | None = None):
+        """Announce Y before kinship_partial so the kinship pass can pre-compute the m = 0 fits."""
+        if Y is None:
+            self._check(self._lib.pg_set_phenotypes(self._ctx, 0, None, 0), "pg_set_phenotypes")
+            return
+        Yh = _host_f64(Y)
+        Yh = Yh.reshape(len(Yh) if n is None else n, -1)
+        self._check(self._lib.pg_set_phenotypes(self._ctx, Yh.shape[0], Yh.ctypes.data, Yh.shape[1]),
+                    "pg_set_phenotypes")
+
     def kinship_partial(self, G: torch.Tensor, n: int | None = None) -> torch.Tensor:
         """Unscaled sum_l g_l g_l^T (n x n) over the loci of G (p x ld, locus-major)."""
         p, ld, n = self._g_dims(G, n)
