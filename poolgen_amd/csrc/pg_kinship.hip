@@ -16,6 +16,7 @@
 // of G.  Each workgroup finally writes its partial tiles to a slab; a second tiny kernel sums
 // the slabs in a fixed order (deterministic, no atomics) and mirrors the lower triangle.
 #include "pg_common.h"
+#include <utility>
 
 namespace {
 
@@ -40,6 +41,21 @@ __device__ __forceinline__ double dpp_add(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
     return v + __hiloint2double(hi, lo);
 }
+// ---- compile-time helpers ------------------------------------------------------------------------
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+// row-major enumeration of the upper triangle of a T x T tile grid
+constexpr int kin_tri_ti(int t, int T) { int ti = 0; while (ti < T && t >= T - ti) { t -= T - ti; ++ti; } return ti < T ? ti : 0; }
+constexpr int kin_tri_tj(int t, int T) { int ti = 0; while (ti < T && t >= T - ti) { t -= T - ti; ++ti; } return ti < T ? ti + t : 0; }
+// tile of slot u of wave w (slots past the end of the list recompute tile 0 and are never stored)
+constexpr int kin_slot_tile(int w, int u, int T) { return (w + 16 * u) < T * (T + 1) / 2 ? (w + 16 * u) : 0; }
+
 struct KinParams {
     const double *G;
     int64_t p;
@@ -53,7 +69,7 @@ struct KinParams {
     int k;
 };
 
-template <bool FUSE>
+template <bool FUSE, bool SPEC13>
 __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -183,40 +199,12 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         }
     };
 
-    double4_t acc[KIN_TPW];
-#pragma unroll
-    for (int u = 0; u < KIN_TPW; ++u) acc[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
     if (nstages > 0) {
         stage_load(0);
         stage_store(0);
     }
     __syncthreads();
 
-    // Rolling software pipeline over the (k-step, tile-slot) sequence of a stage: the fragment pair
-    // of item q + D is requested before the MFMA of item q is issued (ring of D + 1 pairs in
-    // registers).  The stage barrier sits D items before the end of the stage, so every wave still
-    // holds D MFMAs' worth of operands when it arrives: the barrier's arrival skew and the first LDS
-    // round trip of the next stage hide behind them.
-    constexpr int KS = KIN_KC / 4;
-    constexpr int NQ = KS * KIN_TPW; // items per stage
-    constexpr int D = 3, R = 4;
-    double fa[R], fb[R];
-    auto frag_load = [&](const double *buf, int q) {
-        const int s = q / KIN_TPW, u = q % KIN_TPW;
-        const double *row = buf + (4 * s + kq) * ldsld + fi;
-        fa[q & (R - 1)] = row[acol[u]];
-#ifdef KIN_EXP_HALFREADS
-        fb[q & (R - 1)] = fa[q & (R - 1)];
-#else
-        fb[q & (R - 1)] = row[bcol[u]];
-#endif
-    };
-    auto mfma_item = [&](int q) {
-        const int u = q % KIN_TPW;
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q & (R - 1)], fb[q & (R - 1)], acc[u], 0, 0, 0);
-    };
-    static_assert(NQ % R == 0 && NQ > 2 * D, "ring indexing assumes the stage length is a multiple of the ring");
     // FUSE: from the stage that is in LDS anyway, wave w also forms the sums an intercept-only fit of
     // locus w of the stage needs (g' = g - g[0]):  sum g', sum g'^2, sum g' ytil_t.  Its 64 lanes cover
     // the pools 4 apiece; the 64 partials per value are transposed through a wave-private LDS scratch
@@ -262,49 +250,113 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
             __builtin_amdgcn_wave_barrier();
         }
     };
-    if (nstages > 0) {
-#pragma unroll
-        for (int q = 0; q < D; ++q) frag_load(lds, q);
-    }
-    for (int c = 0; c < nstages; ++c) {
-        const bool more = (c + 1) < nstages;
-#ifndef KIN_EXP_NOSTAGE
-        if (more) stage_load(c + 1);
-#endif
-        const double *buf = lds + (c & 1) * bufsz;
-        const double *nbuf = lds + ((c + 1) & 1) * bufsz;
-#pragma unroll
-        for (int q = 0; q < NQ - D; ++q) {
-            frag_load(buf, q + D);
-            mfma_item(q);
-        }
-#ifndef KIN_EXP_NOSTAGE
-        if (more) stage_store((c + 1) & 1);
-#endif
-        if (FUSE) spec_pass(buf, l_begin + (int64_t)c * KIN_KC); // staging registers are free again here
-#ifndef KIN_EXP_NOSTAGE
-        __syncthreads();
-#endif
-#pragma unroll
-        for (int q = NQ - D; q < NQ; ++q) {
-            if (more) frag_load(nbuf, q + D - NQ);
-            mfma_item(q);
-        }
-    }
 
-    // ---- write this workgroup's partial tiles ---------------------------------------------
-    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
-    double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
+    // ---- main loop ------------------------------------------------------------------------------
+    // Rolling software pipeline over the (k-step, tile-slot) sequence of a stage: the fragment pair
+    // of item q + D is requested before the MFMA of item q is issued (ring of D + 1 pairs in
+    // registers).  The stage barrier sits D items before the end of the stage, so every wave still
+    // holds D MFMAs' worth of operands when it arrives: the barrier's arrival skew and the first LDS
+    // round trip of the next stage hide behind them.
+    // W >= 0 (SPEC13 kernels: one block of 13 tiles, 193..208 pools, LDS pitch 208): the body is
+    // instantiated once per wave with COMPILE-TIME tile coordinates, so every fragment address is
+    // "lane base + immediate" (no per-item address arithmetic, A/B pairs merge into ds_read2_b64).
+    // W = -1: run-time tile tables, any shape.
+    auto run = [&](auto wc) {
+        constexpr int W = decltype(wc)::value;
+        constexpr int KS = KIN_KC / 4;
+        constexpr int NQ = KS * KIN_TPW; // items per stage
+        constexpr int D = 3, R = 4;
+        static_assert(NQ % R == 0 && NQ > 2 * D, "ring indexing assumes the stage length is a multiple of the ring");
+        double4_t acc[KIN_TPW];
 #pragma unroll
-    for (int u = 0; u < KIN_TPW; ++u) {
-        if (live[u]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = orow[u] + kq + 4 * r;
-                const int col = ocol[u] + fi;
-                slab[(size_t)row * P.npad + col] = acc[u][r];
+        for (int u = 0; u < KIN_TPW; ++u) acc[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        double fa[R], fb[R];
+        const double *lanebase = lds + kq * ldsld + fi; // + buffer + 4 s ldsld + tile column
+        auto frag_load = [&](const double *bufbase, auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int s = q / KIN_TPW, u = q % KIN_TPW;
+            if constexpr (W >= 0) {
+                if constexpr (W + KIN_WAVES * u >= 91) return; // no such tile: the slot is simply skipped
+                constexpr int t = kin_slot_tile(W, u, 13);
+                constexpr int ao = 4 * s * 208 + 16 * kin_tri_ti(t, 13);
+                constexpr int bo = 4 * s * 208 + 16 * kin_tri_tj(t, 13);
+                fa[q & (R - 1)] = bufbase[ao];
+                fb[q & (R - 1)] = bufbase[bo];
+            } else {
+                const double *row = bufbase + 4 * s * ldsld;
+                fa[q & (R - 1)] = row[acol[u]];
+                fb[q & (R - 1)] = row[bcol[u]];
             }
+        };
+        auto mfma_item = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int u = q % KIN_TPW;
+            if constexpr (W >= 0 && W + KIN_WAVES * u >= 91) return;
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q & (R - 1)], fb[q & (R - 1)], acc[u], 0, 0, 0);
+        };
+        if (nstages > 0)
+            static_for<D>([&](auto qc) { frag_load(lanebase, qc); });
+        for (int c = 0; c < nstages; ++c) {
+            const bool more = (c + 1) < nstages;
+            if (more) stage_load(c + 1);
+            const double *buf = lds + (c & 1) * bufsz;
+            const double *fb0 = lanebase + (c & 1) * bufsz;
+            const double *fb1 = lanebase + ((c + 1) & 1) * bufsz;
+            static_for<NQ - D>([&](auto qc) {
+                frag_load(fb0, std::integral_constant<int, decltype(qc)::value + D>{});
+                mfma_item(qc);
+            });
+            if (more) stage_store((c + 1) & 1);
+            if (FUSE) spec_pass(buf, l_begin + (int64_t)c * KIN_KC); // staging registers are free again here
+            __syncthreads();
+            static_for<D>([&](auto dc) {
+                constexpr int q = NQ - D + decltype(dc)::value;
+                if (more) frag_load(fb1, std::integral_constant<int, q + D - NQ>{});
+                mfma_item(std::integral_constant<int, q>{});
+            });
         }
+        // ---- write this workgroup's partial tiles -----------------------------------------------
+        // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
+        double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
+        static_for<KIN_TPW>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            bool on;
+            int r0, c0;
+            if constexpr (W >= 0) {
+                constexpr int t = W + KIN_WAVES * u;
+                on = t < 91;
+                r0 = 16 * kin_tri_ti(kin_slot_tile(W, u, 13), 13);
+                c0 = 16 * kin_tri_tj(kin_slot_tile(W, u, 13), 13);
+            } else {
+                on = live[u]; r0 = orow[u]; c0 = ocol[u];
+            }
+            if (on) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(size_t)(r0 + kq + 4 * r) * P.npad + c0 + fi] = acc[u][r];
+            }
+        });
+    };
+    if constexpr (SPEC13) {
+        switch (wave) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 5: run(std::integral_constant<int, 5>{}); break;
+        case 6: run(std::integral_constant<int, 6>{}); break;
+        case 7: run(std::integral_constant<int, 7>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}); break;
+        case 9: run(std::integral_constant<int, 9>{}); break;
+        case 10: run(std::integral_constant<int, 10>{}); break;
+        case 11: run(std::integral_constant<int, 11>{}); break;
+        case 12: run(std::integral_constant<int, 12>{}); break;
+        case 13: run(std::integral_constant<int, 13>{}); break;
+        case 14: run(std::integral_constant<int, 14>{}); break;
+        default: run(std::integral_constant<int, 15>{}); break;
+        }
+    } else {
+        run(std::integral_constant<int, -1>{});
     }
 }
 
@@ -384,16 +436,19 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     const size_t shmem = (size_t)2 * KIN_KC * ldsld * sizeof(double) + (fuse ? ((size_t)KIN_FUSE_MAXK * 256 + (size_t)KIN_WAVES * 4 * 64) * sizeof(double) : 0);
     const int max_cols = (P.nb == 1) ? P.Tb * 16 : 2 * P.Tb * 16; // staged pools per locus row
     PG_CHECK(ctx, KIN_KC * (max_cols / 2) <= KIN_PPT * KIN_THREADS, "kinship: staging overflow");
+    const bool spec13 = (P.nb == 1 && P.T == 13);
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
+        return hipSuccess;
+    };
     pg_prof_begin(ctx, kid);
-    if (fuse) {
-        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_kinship_syrk<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_kinship_syrk<true>, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
-    } else {
-        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_kinship_syrk<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_kinship_syrk<false>, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
-    }
+    hipError_t le;
+    if (fuse) le = spec13 ? launch(k_kinship_syrk<true, true>) : launch(k_kinship_syrk<true, false>);
+    else le = spec13 ? launch(k_kinship_syrk<false, true>) : launch(k_kinship_syrk<false, false>);
+    PG_HIP(ctx, le);
     pg_prof_end(ctx);
     if (fuse) {
         ctx->spec_G = G; ctx->spec_p = p; ctx->spec_ld = ld; ctx->spec_n = n; ctx->spec_k = ctx->ph_k;
