@@ -22,6 +22,9 @@ namespace {
 
 constexpr int KIN_THREADS = 1024;
 constexpr int KIN_WAVES = 16;
+#ifndef KIN_RING_D
+#define KIN_RING_D 3
+#endif
 constexpr int KIN_FUSE_MAXK = 2; // traits the fused intercept-only pass carries
 constexpr int KIN_TPW = 6;  // max tiles per wave (ceil(91/16), ceil(81/16))
 #ifndef KIN_KC_DEF
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         constexpr int W = decltype(wc)::value;
         constexpr int KS = KIN_KC / 4;
         constexpr int NQ = KS * KIN_TPW; // items per stage
-        constexpr int D = 3, R = 4;
+        constexpr int D = KIN_RING_D, R = KIN_RING_D + 1;
         static_assert(NQ % R == 0 && NQ > 2 * D, "ring indexing assumes the stage length is a multiple of the ring");
         double4_t acc[KIN_TPW];
 #pragma unroll
@@ -280,19 +283,19 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
                 constexpr int t = kin_slot_tile(W, u, 13);
                 constexpr int ao = 4 * s * 208 + 16 * kin_tri_ti(t, 13);
                 constexpr int bo = 4 * s * 208 + 16 * kin_tri_tj(t, 13);
-                fa[q & (R - 1)] = bufbase[ao];
-                fb[q & (R - 1)] = bufbase[bo];
+                fa[q % R] = bufbase[ao];
+                fb[q % R] = bufbase[bo];
             } else {
                 const double *row = bufbase + 4 * s * ldsld;
-                fa[q & (R - 1)] = row[acol[u]];
-                fb[q & (R - 1)] = row[bcol[u]];
+                fa[q % R] = row[acol[u]];
+                fb[q % R] = row[bcol[u]];
             }
         };
         auto mfma_item = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int u = q % KIN_TPW;
             if constexpr (W >= 0 && W + KIN_WAVES * u >= 91) return;
-            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q & (R - 1)], fb[q & (R - 1)], acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q % R], fb[q % R], acc[u], 0, 0, 0);
         };
         if (nstages > 0)
             static_for<D>([&](auto qc) { frag_load(lanebase, qc); });

@@ -8,6 +8,8 @@ stay sharded: rank r holds rows [lo_r, hi_r) -- the host concatenates in rank or
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -23,7 +25,8 @@ def ols_with_covariate_sharded(engine, G_local: torch.Tensor, p_total: int, Y, v
                                force_m: int = -1, n: int | None = None, out=None, group=None):
     """One step of the sharded path.  Returns (m, K, beta_local, var_local, pval_local)."""
     if hasattr(engine, "set_phenotypes"):
-        engine.set_phenotypes(Y)  # lets the kinship pass pre-compute the intercept-only fits
+        # POOLGEN_TWO_PASS=1 keeps the plain two-pass path (kinship, then a full sweep) for measurement
+        engine.set_phenotypes(None if os.environ.get("POOLGEN_TWO_PASS") == "1" or force_m > 0 else Y)  # lets the kinship pass pre-compute the intercept-only fits
     S = engine.kinship_partial(G_local, n)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
