@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--var-explained", type=float, default=0.75)
     ap.add_argument("--force-m", type=int, default=-1, help=">=0 forces the number of kinship PCs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1_500_000)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +129,7 @@ def main():
     kin_ms, kin_n = eng.profile_get("kinship")
     red_ms, red_n = eng.profile_get("kinship_reduce")
     sw_ms, sw_n = eng.profile_get("sweep")
+    fin_ms, fin_n = eng.profile_get("sweep_finish")
     eng.profile(False)
 
     if rank == 0:
@@ -179,9 +180,11 @@ def main():
                 "k_kinship_syrk": {"avg_ms": kin_avg, "tflops_algorithmic": kin_tflops,
                                    "frac_of_fp64_mfma_peak": kin_tflops / FP64_MFMA_PEAK_TFLOPS},
                 "k_kinship_reduce": {"avg_ms": red_ms / max(red_n, 1)},
-                "k_ols_sweep": {"avg_ms": sw_avg, "gbs_algorithmic": sweep_gbs,
-                                "frac_of_hbm_peak": sweep_gbs / HBM_PEAK_GBS},
-                "host_eig_and_glue_ms": ms_per_step - kin_avg - sw_avg - red_ms / max(red_n, 1),
+                "k_ols_sweep": ({"avg_ms": sw_avg, "gbs_algorithmic": sweep_gbs,
+                                 "frac_of_hbm_peak": sweep_gbs / HBM_PEAK_GBS} if sw_n else
+                                {"avg_ms": 0.0, "note": "not launched: m = 0 fits closed from the sums fused into the kinship pass"}),
+                "k_sweep_finish": {"avg_ms": fin_ms / max(fin_n, 1), "launches": fin_n},
+                "host_eig_and_glue_ms": ms_per_step - kin_avg - sw_avg - red_ms / max(red_n, 1) - fin_ms / max(fin_n, 1),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

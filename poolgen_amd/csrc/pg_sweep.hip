@@ -441,7 +441,7 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
     if (ctx->st_m == 0 && ctx->spec_valid && ctx->spec_G == G_dev && ctx->spec_p == p && ctx->spec_n == n &&
         ctx->spec_ld == ld && ctx->spec_k == ctx->st_k && ctx->ph_n == n && ctx->st_Y_matches_ph) {
         // m = 0: the kinship pass already formed the sums of the intercept-only fits from its read of G
-        pg_prof_begin(ctx, PG_K_SWEEP);
+        pg_prof_begin(ctx, PG_K_SWEEP_FINISH);
         hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream,
                            ctx->spec_dev, ctx->syy_dev, ctx->tcoef_dev, beta_dev, var_dev, pval_dev, P.D);
         pg_prof_end(ctx);
