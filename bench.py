@@ -80,11 +80,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)   # one rank per GPU; wraps only in the 1-GPU rehearsal below
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # nccl == RCCL on ROCm.  POOLGEN_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
+        # control flow on a single-GPU box (several ranks sharing cuda:0), never for measurements.
+        backend = os.environ.get("POOLGEN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from poolgen_amd import Engine, synth
     from poolgen_amd.distributed import ols_with_covariate_sharded, shard_range
@@ -92,7 +100,7 @@ def main():
     n, p_total, k = args.pools, args.loci, 1
     lo, hi = shard_range(p_total, rank, world)
     p_local = hi - lo
-    eng = Engine(local_rank)
+    eng = Engine(dev_index)
     G = synth.genotype_matrix(p_local, n, dev, start=lo)
     # phenotype: 10 causal loci spread over the WHOLE matrix; any rank can regenerate any locus
     causal = [(p_total * (2 * i + 1)) // 20 for i in range(10)]

@@ -47,35 +47,42 @@ struct LocusParams {
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
-// Stage pools [pool0, pool0 + np) of loci l0..l0+63 into the wave's tile.  A full stage (8 pools,
-// 192 bytes per locus) moves PB-byte pieces; the last, partial stage always moves 8-byte pieces
-// whose source offset is clamped INSIDE the row (no read past the end of the batch) and which
-// land at that same offset in the tile.
+// Stage pools [pool0, pool0 + np) of loci l0..l0+63 into the wave's tile.  A locus row of a stage is
+// 192 bytes = 12 pieces of 16 B (24 of 8 B when n is odd and rows are only 8-byte aligned): 48 lanes
+// cover 4 (2) loci per instruction, so that every address is "lane base + r * constant" -- no
+// per-piece address registers -- at the price of 16 idle lanes (loads are not the bottleneck, bytes
+// in flight are).  The last, partial stage always moves 8-byte pieces whose offset is clamped
+// INSIDE the row (no read past the end of the batch) and which land at that same offset in the tile.
 template <int PB, bool FULL>
 __device__ __forceinline__ void stage_counts(const uint32_t *__restrict__ counts, char *tile,
                                              int64_t l0, int64_t L, int n, int pool0, int np,
                                              int lane) {
     constexpr int PBE = FULL ? PB : 8;
-    constexpr int PPR = LO_ROWB / PBE;     // pieces per locus row
-    constexpr int NI = PPR;                // wave instructions per stage (64 loci * PPR / 64 lanes)
-    const int64_t rowb = (int64_t)n * 24;
-    const int valid = np * 24;             // bytes valid in this stage's rows
-#pragma unroll
-    for (int r = 0; r < NI; ++r) {
-        const int q = r * 64 + lane;
-        const int loc = q / PPR;
-        const int pc = q - loc * PPR;
-        int64_t l = l0 + loc;
-        l = l < L ? l : L - 1;
+    constexpr int PPR = LO_ROWB / PBE;     // pieces per locus row: 12 or 24
+    constexpr int LPI = 48 / PPR;          // loci per wave instruction: 4 or 2
+    constexpr int NI = 64 / LPI;           // instructions per stage: 16 or 32
+    if (lane < 48) {
+        const int64_t rowb = (int64_t)n * 24;
+        const int sub = lane / PPR;
+        const int pc = lane - sub * PPR;
         int off = pc * PBE;
-        if (!FULL) off = off < valid ? off : valid - PBE;
-        const char *src = reinterpret_cast<const char *>(counts) + l * rowb + (int64_t)pool0 * 24 + off;
-        if (PBE == 16) {
-            const uint4_t v = *reinterpret_cast<const uint4_t *>(src);
-            *reinterpret_cast<uint4_t *>(tile + loc * LO_PITCH + off) = v;
-        } else {
-            const uint2_t v = *reinterpret_cast<const uint2_t *>(src);
-            *reinterpret_cast<uint2_t *>(tile + loc * LO_PITCH + off) = v;
+        if (!FULL) {
+            const int valid = np * 24;
+            off = off < valid ? off : valid - PBE;
+        }
+        const char *gbase = reinterpret_cast<const char *>(counts) + (int64_t)pool0 * 24 + off;
+        char *tbase = tile + sub * LO_PITCH + off;
+#pragma unroll
+        for (int r = 0; r < NI; ++r) {
+            int64_t l = l0 + LPI * r + sub;
+            l = l < L ? l : L - 1;
+            if (PBE == 16) {
+                const uint4_t v = *reinterpret_cast<const uint4_t *>(gbase + l * rowb);
+                *reinterpret_cast<uint4_t *>(tbase + r * (LPI * LO_PITCH)) = v;
+            } else {
+                const uint2_t v = *reinterpret_cast<const uint2_t *>(gbase + l * rowb);
+                *reinterpret_cast<uint2_t *>(tbase + r * (LPI * LO_PITCH)) = v;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -86,6 +93,23 @@ __device__ __forceinline__ void read_pool(const char *row, int i, uint32_t (&c)[
     const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
     const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
     c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = d.x; c[5] = d.y;
+}
+
+// IEEE-correct c / rs for a whole pool from ONE reciprocal.  This is the arithmetic hipcc itself
+// emits for an fp64 division of normal-range operands (v_rcp_f64, two Newton steps on the
+// reciprocal, q0 = c * r, one fused residual, one fused correction -- the v_div_scale / v_div_fixup
+// wrappers only act on over-/underflowing operands, which counts and coverages are not), with the
+// reciprocal shared by the (up to six) alleles of the pool instead of being recomputed per allele.
+// The quotients are therefore bit-identical to `c / rs`; tests/test_gpu_locus_ops.py pins that
+// through the bit-exact mean frequencies and filter decisions.
+__device__ __forceinline__ double recip_for_div(double b) {
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double r1 = fma(fma(-b, r0, 1.0), r0, r0);
+    return fma(fma(-b, r1, 1.0), r1, r1);
+}
+__device__ __forceinline__ double div_by(double a, double b, double r) {
+    const double q0 = a * r;
+    return fma(fma(-b, q0, a), r, q0);
 }
 
 template <typename T>
@@ -101,12 +125,17 @@ __device__ __forceinline__ constexpr int tri(int a, int b) { // a <= b
     return a * NA - a * (a - 1) / 2 + (b - a);
 }
 
+// record layout (struct-of-arrays: field f of locus l at rec[f * L + l])
+constexpr int R_CS = 0, R_XX = R_CS + NA, R_XY = R_XX + 21, R_PX = R_XY + NA * MAXK, R_PXX = R_PX + NA * MAXK,
+              R_PY = R_PXX + NA * MAXK, R_PYY = R_PY + MAXK, R_PN = R_PYY + MAXK, R_TOTAL = R_PN + MAXK,
+              REC_DOUBLES = R_TOTAL + 1;
+
 template <int OP, int PB>
-__global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
+__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_ops(
     const uint32_t *__restrict__ counts, const double *__restrict__ w, const double *__restrict__ Y,
     const double *__restrict__ tcoef, int32_t *__restrict__ n_out, int32_t *__restrict__ ids_out,
     double *__restrict__ mf_out, double *__restrict__ stat_out, double *__restrict__ pv_out,
-    const LocusParams P) {
+    int32_t *__restrict__ rec_flags, double *__restrict__ rec, const LocusParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -131,6 +160,7 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
             const int np = min(LO_CHP, n - pool0);
             if (np == LO_CHP) stage_counts<PB, true>(counts, tile, l0, P.L, n, pool0, np, lane);
             else stage_counts<PB, false>(counts, tile, l0, P.L, n, pool0, np, lane);
+#pragma unroll 1
             for (int i = 0; i < np; ++i) {
                 uint32_t c[NA];
                 read_pool(row, i, c);
@@ -141,14 +171,13 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
                 mincov = (pool0 + i == 0 || rs < mincov) ? rs : mincov;
                 n_missing += (rs == 0.0) ? 1 : 0;
                 const double wi = w[pool0 + i];
+                const double rinv = recip_for_div(rs);
 #pragma unroll
                 for (int j = 0; j < NA; ++j) {
                     if (P.remove_ns && j == 4) continue;
                     // f = c / rs (NaN if rs == 0, skipped); q += f * w_i   (sync.rs:258-271)
-                    if (c[j] != 0u && rs != 0.0) {
-                        const double f = (double)c[j] / rs;
-                        q[j] = q[j] + f * wi;
-                    }
+                    const double f = div_by((double)c[j], rs, rinv);
+                    q[j] = (c[j] != 0u && rs != 0.0) ? q[j] + f * wi : q[j];
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -190,6 +219,7 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
             const int np = min(LO_CHP, n - pool0);
             if (np == LO_CHP) stage_counts<PB, true>(counts, tile, l0, P.L, n, pool0, np, lane);
             else stage_counts<PB, false>(counts, tile, l0, P.L, n, pool0, np, lane);
+#pragma unroll 1
             for (int i = 0; i < np; ++i) {
                 uint32_t c[NA];
                 read_pool(row, i, c);
@@ -197,9 +227,10 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
 #pragma unroll
                 for (int j = 0; j < NA; ++j) rs = keep[j] ? rs + (double)c[j] : rs;
                 double f[NA];
+                const double rinv = recip_for_div(rs);
 #pragma unroll
                 for (int j = 0; j < NA; ++j)
-                    f[j] = (rs == 0.0) ? NAN : ((c[j] != 0u && keep[j]) ? (double)c[j] / rs : 0.0);
+                    f[j] = (rs == 0.0) ? NAN : ((c[j] != 0u && keep[j]) ? div_by((double)c[j], rs, rinv) : 0.0);
                 const bool rowok = rs != 0.0;
 #pragma unroll
                 for (int j = 0; j < NA; ++j) cs[j] = rowok ? cs[j] + f[j] : cs[j];
@@ -252,7 +283,90 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
             __builtin_amdgcn_wave_barrier();
         }
         if (l >= P.L) continue;
+        // The sums go to a per-locus record (struct-of-arrays, coalesced stores); k_locus_close<OP>
+        // finishes the statistic.  Keeping the transcendental / LU code out of this kernel keeps its
+        // register count -- and so the number of waves that hide the HBM latency -- small.
+        {
+            int mask = alive ? 1 : 0;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) mask |= keep[j] ? (2 << j) : 0;
+            rec_flags[l] = mask;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) rec[(size_t)(R_CS + j) * P.L + l] = cs[j];
+            if (OP == OP_OLS || OP == OP_CHISQ) {
+#pragma unroll
+                for (int j = 0; j < 21; ++j)
+                    if (OP == OP_OLS || j == tri(0, 0) || j == tri(1, 1) || j == tri(2, 2) || j == tri(3, 3) ||
+                        j == tri(4, 4) || j == tri(5, 5))
+                        rec[(size_t)(R_XX + j) * P.L + l] = xx[j];
+            }
+            if (OP == OP_OLS || OP == OP_PEARSON) {
+#pragma unroll
+                for (int j = 0; j < NA * MAXK; ++j) rec[(size_t)(R_XY + j) * P.L + l] = xy[j];
+            }
+            if (OP == OP_PEARSON) {
+#pragma unroll
+                for (int j = 0; j < NA * MAXK; ++j) {
+                    rec[(size_t)(R_PX + j) * P.L + l] = px[j];
+                    rec[(size_t)(R_PXX + j) * P.L + l] = pxx[j];
+                }
+#pragma unroll
+                for (int j = 0; j < MAXK; ++j) {
+                    rec[(size_t)(R_PY + j) * P.L + l] = py[j];
+                    rec[(size_t)(R_PYY + j) * P.L + l] = pyy[j];
+                    rec[(size_t)(R_PN + j) * P.L + l] = pn[j];
+                }
+            }
+            if (OP == OP_CHISQ) rec[(size_t)R_TOTAL * P.L + l] = total;
+        }
+    }
+}
 
+// Closing kernels: one thread per locus, from the record the streaming kernel left.
+template <int OP>
+__global__ __launch_bounds__(64) void k_locus_close(const int32_t *__restrict__ rec_flags,
+                                                    const double *__restrict__ rec,
+                                                    const double *__restrict__ tcoef, int32_t *__restrict__ n_out,
+                                                    int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
+                                                    double *__restrict__ stat_out, double *__restrict__ pv_out,
+                                                    const LocusParams P) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= P.L) return;
+    const int n = P.n, k = P.k;
+    const int mask = rec_flags[l];
+    const bool alive = (mask & 1) != 0;
+    bool keep[NA];
+    int nk = 0;
+    double cs[NA], xx[21], xy[NA * MAXK], px[NA * MAXK], pxx[NA * MAXK], py[MAXK], pyy[MAXK], pn[MAXK];
+    double total = 0.0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        keep[j] = (mask & (2 << j)) != 0;
+        nk += keep[j] ? 1 : 0;
+        cs[j] = rec[(size_t)(R_CS + j) * P.L + l];
+    }
+#pragma unroll
+    for (int j = 0; j < 21; ++j) xx[j] = 0.0;
+    if (OP == OP_OLS) {
+#pragma unroll
+        for (int j = 0; j < 21; ++j) xx[j] = rec[(size_t)(R_XX + j) * P.L + l];
+    } else if (OP == OP_CHISQ) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) xx[tri(j, j)] = rec[(size_t)(R_XX + tri(j, j)) * P.L + l];
+        total = rec[(size_t)R_TOTAL * P.L + l];
+    }
+#pragma unroll
+    for (int j = 0; j < NA * MAXK; ++j) {
+        xy[j] = (OP == OP_OLS || OP == OP_PEARSON) ? rec[(size_t)(R_XY + j) * P.L + l] : 0.0;
+        px[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PX + j) * P.L + l] : 0.0;
+        pxx[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PXX + j) * P.L + l] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        py[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PY + j) * P.L + l] : 0.0;
+        pyy[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PYY + j) * P.L + l] : 0.0;
+        pn[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PN + j) * P.L + l] : 0.0;
+    }
         // ================= closing arithmetic per locus ==========================================
         if (OP == OP_CHISQ) {
             // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
@@ -271,7 +385,7 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
             n_out[l] = alive ? nk : 0;
             stat_out[l] = alive ? chi2 : NAN;
             pv_out[l] = alive ? pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)) : NAN;
-            continue;
+            return;
         }
 
         // order of the surviving alleles
@@ -350,7 +464,7 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
                     pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
                 }
             }
-            continue;
+            return;
         }
 
         // ---------------- OP_OLS: literal normal equations in the reference's column order -------
@@ -558,7 +672,6 @@ __global__ __launch_bounds__(LO_THREADS) void k_locus_ops(
                 pv_out[(l * PG_MAX_OUT + r - 1) * P.k_total + P.t0 + tt] = pv;
             }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -584,12 +697,16 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     for (int i = 0; i < n; ++i) w[i] = pool_sizes[i] / total;
     const int df = (OP == OP_OLS) ? n - 1 : n - 2; // ols.rs:139 / correlation_test.rs:65
     std::vector<double> tc = pg_tdist_coef(df < 1 ? 1 : df);
-    const size_t need = sizeof(double) * ((size_t)n + (size_t)n * MAXK + tc.size() + 8);
+    const size_t side = ((size_t)n + (size_t)n * MAXK + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
+    const size_t recd = (size_t)L * REC_DOUBLES;
+    const size_t need = sizeof(double) * (side + recd) + sizeof(int32_t) * (size_t)L;
     int rc = pg_ws_reserve(ctx, need);
     if (rc) return rc;
     double *wd = static_cast<double *>(ctx->ws);
     double *Ydev = wd + n;
     double *tcd = Ydev + (size_t)n * MAXK;
+    double *recp = wd + side;
+    int32_t *recf = reinterpret_cast<int32_t *>(recp + recd);
     PG_HIP(ctx, hipMemcpyAsync(wd, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (!tc.empty())
         PG_HIP(ctx, hipMemcpyAsync(tcd, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -647,10 +764,12 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
         pg_prof_begin(ctx, kid);
         if (p16)
             hipLaunchKernelGGL((k_locus_ops<OP, 16>), dim3(grid), dim3(LO_THREADS), shmem, ctx->stream, counts_dev,
-                               wd, Ydev, tcd, n_out, ids, mf, stat, pv, P);
+                               wd, Ydev, tcd, n_out, ids, mf, stat, pv, recf, recp, P);
         else
             hipLaunchKernelGGL((k_locus_ops<OP, 8>), dim3(grid), dim3(LO_THREADS), shmem, ctx->stream, counts_dev,
-                               wd, Ydev, tcd, n_out, ids, mf, stat, pv, P);
+                               wd, Ydev, tcd, n_out, ids, mf, stat, pv, recf, recp, P);
+        hipLaunchKernelGGL(k_locus_close<OP>, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, ctx->stream, recf, recp, tcd,
+                           n_out, ids, mf, stat, pv, P);
         pg_prof_end(ctx);
         PG_HIP(ctx, hipGetLastError());
         PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Yd is reused by the next trait pair
