@@ -1,0 +1,49 @@
+"""bench.py contract checks on the GPU box: the JSON line has the fields the driver reads, the
+N = 1 path works under torch.distributed.run, and the multi-rank control flow (shard, all-reduce,
+max-over-ranks timing, rank-0 print) runs -- rehearsed with two ranks sharing cuda:0 over gloo,
+because a 1-GPU box cannot host two RCCL ranks."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+NEED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def last_json(out: str):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--loci", "1000000",
+                        "--cpu-sample", "20000"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert NEED <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "loci/s" and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["value"] > 50 * cb["value"]
+
+
+def test_two_rank_control_flow_rehearsal():
+    env = dict(os.environ, POOLGEN_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(ROOT / "bench.py"), "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--loci", "1000001", "--no-cpu-baseline"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["loci_total"] == 1000001 and d["config"]["loci_per_gpu"] == 500000
+    assert d["scaling"] == "strong" and d["value"] > 0
