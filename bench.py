@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--loci", type=int, default=10_000_000, help="TOTAL loci over all GPUs")
     ap.add_argument("--var-explained", type=float, default=0.75)
     ap.add_argument("--force-m", type=int, default=-1, help=">=0 forces the number of kinship PCs")
+    ap.add_argument("--ld", type=int, default=0, help="leading dimension of G in doubles (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     args = ap.parse_args()
@@ -101,7 +102,7 @@ def main():
     lo, hi = shard_range(p_total, rank, world)
     p_local = hi - lo
     eng = Engine(dev_index)
-    G = synth.genotype_matrix(p_local, n, dev, start=lo)
+    G = synth.genotype_matrix(p_local, n, dev, start=lo, ld=(args.ld or None))
     # phenotype: 10 causal loci spread over the WHOLE matrix; any rank can regenerate any locus
     causal = [(p_total * (2 * i + 1)) // 20 for i in range(10)]
     Gc = torch.cat([synth.genotype_matrix(1, n, dev, start=c) for c in causal], dim=0)

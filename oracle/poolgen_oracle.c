@@ -1143,3 +1143,100 @@ void orc_expand_and_contract(const double *b_in, const double *b_proxy, int64_t 
     }
     free(normed);
 }
+
+/* ======================================================================================
+ * gp/penalise.rs: error_index (:359-426) and the ridge-like lambda path (:133-140, :461-669)
+ * ====================================================================================== */
+/* error_index for trait j on the validation rows; Xt locus-major (P x n, ld), b P x k */
+void orc_error_index(const double *Xt, int64_t P, int n, int64_t ld, const double *b, int k,
+                     const double *Y, const int64_t *idx_val, int n_val, double *err_out) {
+    (void)n;
+    double *yt = (double *)malloc(sizeof(double) * n_val * 2);
+    double *yp = yt + n_val;
+    for (int j = 0; j < k; j++) {
+        for (int i = 0; i < n_val; i++) {
+            yt[i] = Y[idx_val[i] * k + j];
+            double x = 0.0; /* multiply_views_xx: sequential over the columns (helpers.rs:176-180) */
+            for (int64_t c = 0; c < P; c++) x += Xt[c * ld + idx_val[i]] * b[c * k + j];
+            yp[i] = x;
+        }
+        double mn = yt[0], mx = yt[0];
+        for (int i = 0; i < n_val; i++) { if (yt[i] < mn) mn = yt[i]; if (yt[i] > mx) mx = yt[i]; }
+        double cor, pv;
+        orc_pearsons_correlation(yt, 1, yp, 1, n_val, &cor, &pv);
+        double mae = 0.0, mse = 0.0;
+        for (int i = 0; i < n_val; i++) { double d = yt[i] - yp[i]; mae += fabs(d); }
+        mae = mae / (mx - mn);
+        for (int i = 0; i < n_val; i++) { double d = yt[i] - yp[i]; mse += d * d; }
+        mse = mse / ((mx - mn) * (mx - mn));
+        double rmse = sqrt(mse) / (mx - mn);
+        err_out[j] = ((1.0 - fabs(cor)) + mae + mse + rmse) / 4.0; /* :409-418 */
+    }
+    free(yt);
+}
+
+/* penalised_lambda_path_with_k_fold_cross_validation with alpha >= 0, iterative = false
+ * (:461-669).  The reference draws the folds with an unseeded rand::thread_rng (:452-453); here the
+ * fold of row_idx[i] in repetition rep is given: fold_of[rep * n_rows + i] in 0..nfolds-1.
+ * perf (may be NULL): r x nfolds x L x k.  Returns L (number of lambdas), lambdas_out k, beta P x k. */
+int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
+                              const int64_t *row_idx, int n_rows, const int32_t *fold_of, int r,
+                              int nfolds, double alpha, double lambda_step, double *beta,
+                              double *lambdas_out, double *perf, int n_threads) {
+    const int max_usize = (int)round(1.0 / lambda_step);
+    const int L = max_usize + 1;
+    double *path = (double *)malloc(sizeof(double) * L);
+    for (int i = 0; i < L; i++) path[i] = (double)i / (double)max_usize;
+    double *perf_l = perf ? perf : (double *)malloc(sizeof(double) * r * nfolds * L * k);
+    double *b_hat = (double *)malloc(sizeof(double) * P * k * 2);
+    double *b_new = b_hat + P * k;
+    int64_t *itr = (int64_t *)malloc(sizeof(int64_t) * n_rows * 2);
+    int64_t *iva = itr + n_rows;
+    for (int rep = 0; rep < r; rep++)
+        for (int fold = 0; fold < nfolds; fold++) {
+            int nt = 0, nv = 0;
+            for (int i = 0; i < n_rows; i++) {
+                if (fold_of[rep * n_rows + i] == fold) iva[nv++] = row_idx[i];
+                else itr[nt++] = row_idx[i];
+            }
+            orc_gp_ols(Xt, P, n, ld, Y, k, itr, nt, b_hat, n_threads); /* :526 */
+            for (int li = 0; li < L; li++) {
+                orc_expand_and_contract(b_hat, b_hat, P, k, alpha, path[li], b_new);
+                orc_error_index(Xt, P, n, ld, b_new, k, Y, iva, nv, &perf_l[((rep * nfolds + fold) * L + li) * k]);
+            }
+        }
+    orc_gp_ols(Xt, P, n, ld, Y, k, row_idx, n_rows, b_hat, n_threads); /* :573 */
+    memcpy(beta, b_hat, sizeof(double) * P * k);
+    int *counts = (int *)malloc(sizeof(int) * L);
+    for (int j = 0; j < k; j++) {
+        for (int a = 0; a < L; a++) counts[a] = 0;
+        for (int rep = 0; rep < r; rep++) { /* per repetition: arg-min of the mean error across folds */
+            double minv = 0.0;
+            int arg = -1;
+            for (int li = 0; li < L; li++) {
+                double s = 0.0;
+                for (int fold = 0; fold < nfolds; fold++) s += perf_l[((rep * nfolds + fold) * L + li) * k + j];
+                double m = s / (double)nfolds;
+                if (li == 0) { minv = m; }
+                else if (m < minv) minv = m;
+            }
+            for (int li = 0; li < L && arg < 0; li++) {
+                double s = 0.0;
+                for (int fold = 0; fold < nfolds; fold++) s += perf_l[((rep * nfolds + fold) * L + li) * k + j];
+                if (s / (double)nfolds == minv) arg = li;
+            }
+            if (arg >= 0) counts[arg] += 1;
+        }
+        int best = 0, mx = 0; /* mode, first maximum (:609-627) */
+        for (int a = 0; a < L; a++)
+            if (counts[a] > mx) mx = counts[a];
+        for (int a = 0; a < L; a++)
+            if (counts[a] == mx) { best = a; break; }
+        lambdas_out[j] = path[best];
+        orc_expand_and_contract(b_hat, b_hat, P, k, alpha, path[best], b_new);
+        for (int64_t i = 0; i < P; i++) beta[i * k + j] = b_new[i * k + j];
+    }
+    free(counts); free(itr); free(b_hat); free(path);
+    if (!perf) free(perf_l);
+    return L;
+}

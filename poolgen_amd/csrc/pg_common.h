@@ -15,6 +15,7 @@ struct pg_event_pair { hipEvent_t a, b; int kid; };
 
 struct pg_ctx {
     int device = -1;
+    int cus = 256; // compute units of the device (cached at pg_create)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;

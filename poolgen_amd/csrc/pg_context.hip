@@ -51,6 +51,7 @@ extern "C" int pg_create(pg_ctx **out, int device, void *stream) {
     }
     pg_ctx *ctx = new pg_ctx();
     ctx->device = device;
+    ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // NULL = the device's default (null) stream, which is what torch hands out as cuda_stream 0;
     // work is therefore always ordered with the caller's stream.
     ctx->stream = (hipStream_t)stream;

@@ -1,2 +1,356 @@
-// pg_gp.hip -- intentionally empty: gp::ols lives next to the streaming pass it shares (pg_sweep.hip).
+// pg_gp.hip -- ridge-like penalised genomic prediction (gp/penalise.rs:133-159, :248-669).
+//
+// Reference flow (alpha = 0, iterative = false): for r repetitions x nfolds folds: b = gp::ols on the
+// training pools; for every lambda of the path: b_lambda = expand_and_contract(b, b, alpha, lambda)
+// (:248-357) and error_index on the validation pools (:359-426); per repetition the lambda with the
+// smallest mean error over folds; the mode over repetitions; finally expand_and_contract of the
+// all-rows fit.  The reference draws folds from an unseeded thread_rng (:452-453); here the fold of
+// every training row in every repetition is an explicit argument, so results are reproducible.
+//
+// GPU decomposition per (repetition, fold):
+//   1. pg_gp_ols_dev              b (1+p) x k        one streaming pass over G (k_gp_beta)
+//   2. k_gp_norm_max              max of the penalty norm over the p slopes
+//   3. k_gp_path_sums             for all L lambdas at once: the four redistribution masses of
+//                                 expand_and_contract (one pass over b)
+//   4. k_gp_blambda               B[l][i] = expand_and_contract(b)[l] for lambda_i   (p x L)
+//   5. k_gp_predict (+ reduce)    yhat[pool][lambda] = b0 + sum_l G[l][pool] B[l][lambda]: the second
+//                                 streaming pass over G, all lambdas at once
+//   6. host: error_index on the validation pools (n_val x L numbers)
+// All L lambdas share the two passes over G; the reference does 1 + L passes per fold.
 #include "pg_common.h"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int GP_LMAX = 16; // lambdas per path (the reference uses 11: 0, 0.1, ..., 1)
+
+struct PathParams {
+    double alpha;
+    double nmax;                  // max penalty norm (proxy = b itself, :262-283)
+    double lambda[GP_LMAX];
+    double sub_scale[GP_LMAX];    // subtracted_penalised / subtracted_depenalised (0 if nothing to expand)
+    double add_scale[GP_LMAX];    // added_penalised / added_depenalised
+    int L;
+};
+
+__device__ __forceinline__ double gp_norm(double b, double alpha) { // :259-261
+    return ((1.00 - alpha) * (b * b) / 1.00) + (alpha * fabs(b));
+}
+
+// max over the slopes (rows 1..p of column j) of the penalty norm; partial maxima per block
+__global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k, int j, double alpha,
+                              double *__restrict__ part) {
+    double m = 0.0;
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < p; l += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, gp_norm(beta[(l + 1) * k + j], alpha));
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, sm[w]);
+        part[blockIdx.x] = m;
+    }
+}
+
+// For every lambda_i: subtracted/added masses of the penalised set and the norm masses of the
+// de-penalised set, split by the sign of b (:296-326).  part: [block][4][GP_LMAX].
+__global__ void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, PathParams P,
+                               double *__restrict__ part) {
+    double sp[GP_LMAX], ap[GP_LMAX], sd[GP_LMAX], ad[GP_LMAX];
+#pragma unroll
+    for (int i = 0; i < GP_LMAX; ++i) { sp[i] = 0.0; ap[i] = 0.0; sd[i] = 0.0; ad[i] = 0.0; }
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < p; l += (int64_t)gridDim.x * blockDim.x) {
+        const double b = beta[(l + 1) * k + j];
+        const double nrm = gp_norm(b, P.alpha);
+        const double sc = nrm / P.nmax; // normed_proxy / normed_proxy_max (:282), a true division: max/max == 1
+        const bool pos = b >= 0.0;
+        const double pen_pos = pos ? (((b - nrm) < 0.0) ? b : nrm) : 0.0;       // :298-305
+        const double pen_neg = pos ? 0.0 : (((b + nrm) > 0.0) ? fabs(b) : nrm); // :306-313
+#pragma unroll
+        for (int i = 0; i < GP_LMAX; ++i) {
+            if (i < P.L) {
+                const bool pen = sc < P.lambda[i];
+                sp[i] += pen ? pen_pos : 0.0;
+                ap[i] += pen ? pen_neg : 0.0;
+                sd[i] += (!pen && pos) ? nrm : 0.0;
+                ad[i] += (!pen && !pos) ? nrm : 0.0;
+            }
+        }
+    }
+    __shared__ double sm[4][4 * GP_LMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < GP_LMAX; ++i) {
+        double a = sp[i], b2 = ap[i], c = sd[i], d = ad[i];
+        for (int off = 32; off >= 1; off >>= 1) {
+            a += __shfl_xor(a, off); b2 += __shfl_xor(b2, off); c += __shfl_xor(c, off); d += __shfl_xor(d, off);
+        }
+        if (lane == 0) { sm[wave][i] = a; sm[wave][GP_LMAX + i] = b2; sm[wave][2 * GP_LMAX + i] = c; sm[wave][3 * GP_LMAX + i] = d; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * GP_LMAX) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sm[w][threadIdx.x];
+        part[(size_t)blockIdx.x * 4 * GP_LMAX + threadIdx.x] = s;
+    }
+}
+
+// expand_and_contract of one coefficient for lambda_i (:296-352), given the global masses
+__device__ __forceinline__ double gp_contract(double b, const PathParams &P, int i) {
+    const double nrm = gp_norm(b, P.alpha);
+    const double sc = nrm / P.nmax;
+    if (sc < P.lambda[i]) { // penalised: contract by its own norm, not across zero
+        if (b >= 0.0) return ((b - nrm) < 0.0) ? 0.0 : b - nrm;
+        return ((b + nrm) > 0.0) ? 0.0 : b + nrm;
+    }
+    // de-penalised: receives its share of the contracted mass of its sign
+    if (b >= 0.0) return b + P.sub_scale[i] * nrm;
+    return b - P.add_scale[i] * nrm;
+}
+
+// B[l][i] for all lambdas (row stride GP_LMAX)
+__global__ void k_gp_blambda(const double *__restrict__ beta, int64_t p, int k, int j, PathParams P,
+                             double *__restrict__ B) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= p) return;
+    const double b = beta[(l + 1) * k + j];
+#pragma unroll
+    for (int i = 0; i < GP_LMAX; ++i) B[l * GP_LMAX + i] = (i < P.L) ? gp_contract(b, P, i) : 0.0;
+}
+
+// single-lambda variant writing the penalised column back (final model, :653-662)
+__global__ void k_gp_apply(double *__restrict__ beta, int64_t p, int k, int j, PathParams P, int i) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= p) return;
+    beta[(l + 1) * k + j] = gp_contract(beta[(l + 1) * k + j], P, i);
+}
+
+// yhat partials: thread = pool, block = slab of loci; B rows are wave-uniform (scalar loads)
+__global__ __launch_bounds__(256) void k_gp_predict(const double *__restrict__ G, const double *__restrict__ B,
+                                                    int64_t p, int n, int64_t ld, int64_t loci_per_block,
+                                                    double *__restrict__ part) {
+    const int pool = blockIdx.y * 256 + threadIdx.x;
+    const int64_t l0 = (int64_t)blockIdx.x * loci_per_block;
+    const int64_t l1 = min(p, l0 + loci_per_block);
+    double acc[GP_LMAX];
+#pragma unroll
+    for (int i = 0; i < GP_LMAX; ++i) acc[i] = 0.0;
+    const bool on = pool < n;
+    const double *gp = G + (on ? pool : 0);
+    int64_t l = l0;
+    for (; l + 4 <= l1; l += 4) {
+        double g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = gp[(l + u) * ld];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *bl = B + (l + u) * GP_LMAX;
+#pragma unroll
+            for (int i = 0; i < GP_LMAX; ++i) acc[i] = fma(g[u], bl[i], acc[i]);
+        }
+    }
+    for (; l < l1; ++l) {
+        const double g = gp[l * ld];
+        const double *bl = B + l * GP_LMAX;
+#pragma unroll
+        for (int i = 0; i < GP_LMAX; ++i) acc[i] = fma(g, bl[i], acc[i]);
+    }
+    if (on) {
+        double *o = part + ((size_t)blockIdx.x * n + pool) * GP_LMAX;
+#pragma unroll
+        for (int i = 0; i < GP_LMAX; ++i) o[i] = acc[i];
+    }
+}
+
+__global__ void k_gp_predict_reduce(const double *__restrict__ part, int nblocks, int n, double *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // pool * GP_LMAX + i
+    if (idx >= n * GP_LMAX) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * n * GP_LMAX + idx];
+    out[idx] = s;
+}
+
+// pearsons_correlation (gwas/correlation_test.rs:7-71) on two complete vectors, as error_index calls it
+double host_pearson_r(const std::vector<double> &x, const std::vector<double> &y) {
+    const int n = (int)x.size();
+    double mx = 0, my = 0;
+    for (int i = 0; i < n; ++i) { mx += x[i]; my += y[i]; }
+    mx /= n; my /= n;
+    double sxy = 0, sxx = 0, syy = 0;
+    for (int i = 0; i < n; ++i) { const double dx = x[i] - mx, dy = y[i] - my; sxy += dx * dy; sxx += dx * dx; syy += dy * dy; }
+    const double r = sxy / (std::sqrt(sxx) * std::sqrt(syy));
+    if (std::isnan(r)) return NAN;
+    const double sden = (1.0 - r * r) / ((double)n - 2.0);
+    if (sden <= 0.0) return r;
+    return std::round(r * 1e7) / 1e7; // sensible_round(r, 7)
+}
+
+struct RidgeWork {
+    double *part = nullptr;   // block partials (max / path sums / predictions)
+    double *B = nullptr;      // p x GP_LMAX
+    double *yhat = nullptr;   // n x GP_LMAX
+};
+
+// steps 2-4 for trait j of `beta_dev`; returns the path parameters with the masses filled in
+int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int j, double alpha,
+                      const std::vector<double> &path, RidgeWork &W, PathParams &P) {
+    const int nb = 1024;
+    std::vector<double> h((size_t)nb * 4 * GP_LMAX);
+    hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, alpha, W.part);
+    PG_HIP(ctx, hipGetLastError());
+    PG_HIP(ctx, hipMemcpyAsync(h.data(), W.part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double mx = 0.0;
+    for (int b = 0; b < nb; ++b) mx = std::max(mx, h[b]);
+    std::memset(&P, 0, sizeof P);
+    P.alpha = alpha;
+    P.nmax = mx;
+    P.L = (int)path.size();
+    for (int i = 0; i < P.L; ++i) P.lambda[i] = path[i];
+    hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, W.part);
+    PG_HIP(ctx, hipGetLastError());
+    PG_HIP(ctx, hipMemcpyAsync(h.data(), W.part, sizeof(double) * nb * 4 * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < P.L; ++i) {
+        double sp = 0, ap = 0, sd = 0, ad = 0;
+        for (int b = 0; b < nb; ++b) {
+            const double *q = &h[(size_t)b * 4 * GP_LMAX];
+            sp += q[i]; ap += q[GP_LMAX + i]; sd += q[2 * GP_LMAX + i]; ad += q[3 * GP_LMAX + i];
+        }
+        // "absence of available slots" (:329-335)
+        if ((sp > 0.0) & (sd == 0.0)) { ap -= sp; sp = 0.0; }
+        else if ((ap > 0.0) & (ad == 0.0)) { sp -= ap; ap = 0.0; }
+        // b += subtracted_penalised * (normed / subtracted_depenalised)  (:345-351); 0/0 never reaches a
+        // coefficient because an empty de-penalised side has no coefficients to expand
+        P.sub_scale[i] = (sd != 0.0) ? sp / sd : 0.0;
+        P.add_scale[i] = (ad != 0.0) ? ap / ad : 0.0;
+    }
+    return PG_OK;
+}
+
+} // namespace
+
+extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
+                               int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
+                               int n_folds, double alpha, double lambda_step, double *beta_dev,
+                               double *lambdas_out, double *perf_out) {
+    if (!ctx) return PG_ERR_INVALID;
+    PG_CHECK(ctx, G_dev && Y && row_idx && fold_of && beta_dev && lambdas_out, "gp_ridge: null pointer");
+    PG_CHECK(ctx, p > 0 && n >= 3 && k >= 1 && k <= 8 && n_rows >= 3 && n_rows <= n && n_reps >= 1 && n_folds >= 2,
+             "gp_ridge: bad shape");
+    PG_CHECK(ctx, alpha >= 0.0 && alpha <= 1.0 && lambda_step > 0.0 && lambda_step <= 1.0, "gp_ridge: bad alpha / lambda step");
+    const int maxu = (int)std::llround(1.0 / lambda_step);
+    const int L = maxu + 1;
+    PG_CHECK(ctx, L <= GP_LMAX, "gp_ridge: at most %d lambdas on the path", GP_LMAX);
+    std::vector<double> path(L);
+    for (int i = 0; i < L; ++i) path[i] = (double)i / (double)maxu; // :470-476
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+
+    // the full-data X X^T once; every training subset uses a principal sub-block
+    std::vector<double> xxt((size_t)n * n);
+    {
+        if (ctx->S_n < n) {
+            PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->S_dev) PG_HIP(ctx, hipFree(ctx->S_dev));
+            ctx->S_dev = nullptr; ctx->S_n = 0;
+            PG_HIP(ctx, hipMalloc((void **)&ctx->S_dev, sizeof(double) * n * n));
+            ctx->S_n = n;
+        }
+        int rc = pg_gp_xxt_dev(ctx, G_dev, p, n, ld, ctx->S_dev);
+        if (rc) return rc;
+        PG_HIP(ctx, hipMemcpyAsync(xxt.data(), ctx->S_dev, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // scratch
+    const int nblk = std::max(1, std::min<int>(ctx->cus * 4, (int)((p + 255) / 256)));
+    const int64_t lpb = (p + nblk - 1) / nblk;
+    const int nblk2 = (int)((p + lpb - 1) / lpb);
+    RidgeWork W;
+    const size_t part_doubles = std::max<size_t>((size_t)1024 * 4 * GP_LMAX, (size_t)nblk2 * n * GP_LMAX);
+    char *raw = nullptr;
+    PG_HIP(ctx, hipMalloc((void **)&raw, sizeof(double) * (part_doubles + (size_t)p * GP_LMAX + (size_t)n * GP_LMAX)));
+    W.part = reinterpret_cast<double *>(raw);
+    W.B = W.part + part_doubles;
+    W.yhat = W.B + (size_t)p * GP_LMAX;
+    auto fail = [&](int rc) { (void)hipFree(raw); return rc; };
+
+    std::vector<double> perf((size_t)n_reps * n_folds * L * k, NAN), b0(k), yh((size_t)n * GP_LMAX);
+    std::vector<int64_t> itr, iva;
+    for (int rep = 0; rep < n_reps; ++rep)
+        for (int fold = 0; fold < n_folds; ++fold) {
+            itr.clear(); iva.clear();
+            for (int i = 0; i < n_rows; ++i) {
+                const int f = fold_of[(size_t)rep * n_rows + i];
+                if (f < 0 || f >= n_folds) { ctx->err = "gp_ridge: fold id out of range"; return fail(PG_ERR_INVALID); }
+                (f == fold ? iva : itr).push_back(row_idx[i]);
+            }
+            if (iva.empty() || itr.empty()) continue; // an empty fold leaves NaN, as an empty slice would
+            int rc = pg_gp_ols_dev(ctx, G_dev, p, n, ld, Y, k, itr.data(), (int)itr.size(), xxt.data(), beta_dev); // :526
+            if (rc) return fail(rc);
+            if (hipMemcpyAsync(b0.data(), beta_dev, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: D2H failed"));
+            for (int j = 0; j < k; ++j) {
+                PathParams P;
+                rc = ridge_path_params(ctx, beta_dev, p, k, j, alpha, path, W, P);
+                if (rc) return fail(rc);
+                hipLaunchKernelGGL(k_gp_blambda, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, W.B);
+                hipLaunchKernelGGL(k_gp_predict, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, W.B, p, n, ld, lpb, W.part);
+                hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
+                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess)
+                    return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
+                // error_index (:359-426) on the validation pools
+                const int nv = (int)iva.size();
+                std::vector<double> yt(nv), yp(nv);
+                double mn = 0, mx = 0;
+                for (int i = 0; i < nv; ++i) {
+                    yt[i] = Y[(size_t)iva[i] * k + j];
+                    if (i == 0 || yt[i] < mn) mn = yt[i];
+                    if (i == 0 || yt[i] > mx) mx = yt[i];
+                }
+                for (int li = 0; li < L; ++li) {
+                    for (int i = 0; i < nv; ++i) yp[i] = b0[j] + yh[(size_t)iva[i] * GP_LMAX + li];
+                    const double cor = host_pearson_r(yt, yp);
+                    double mae = 0, mse = 0;
+                    for (int i = 0; i < nv; ++i) { const double d = yt[i] - yp[i]; mae += std::fabs(d); mse += d * d; }
+                    mae /= (mx - mn);
+                    mse /= ((mx - mn) * (mx - mn));
+                    const double rmse = std::sqrt(mse) / (mx - mn);
+                    perf[(((size_t)rep * n_folds + fold) * L + li) * k + j] = ((1.0 - std::fabs(cor)) + mae + mse + rmse) / 4.0;
+                }
+            }
+        }
+    // all-rows fit, per trait the mode over repetitions of the per-repetition arg-min (:573-627)
+    int rc = pg_gp_ols_dev(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, xxt.data(), beta_dev);
+    if (rc) return fail(rc);
+    for (int j = 0; j < k; ++j) {
+        std::vector<int> counts(L, 0);
+        for (int rep = 0; rep < n_reps; ++rep) {
+            std::vector<double> mean(L);
+            for (int li = 0; li < L; ++li) {
+                double s = 0.0;
+                for (int fold = 0; fold < n_folds; ++fold) s += perf[(((size_t)rep * n_folds + fold) * L + li) * k + j];
+                mean[li] = s / (double)n_folds;
+            }
+            double mnv = mean[0];
+            for (int li = 0; li < L; ++li) if (mean[li] < mnv) mnv = mean[li];
+            for (int li = 0; li < L; ++li) if (mean[li] == mnv) { counts[li] += 1; break; }
+        }
+        int mxc = 0, best = 0;
+        for (int a = 0; a < L; ++a) mxc = std::max(mxc, counts[a]);
+        for (int a = 0; a < L; ++a) if (counts[a] == mxc) { best = a; break; }
+        lambdas_out[j] = path[best];
+        PathParams P;
+        rc = ridge_path_params(ctx, beta_dev, p, k, j, alpha, path, W, P);
+        if (rc) return fail(rc);
+        hipLaunchKernelGGL(k_gp_apply, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, best);
+        if (hipGetLastError() != hipSuccess) return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: apply failed"));
+    }
+    if (perf_out) std::memcpy(perf_out, perf.data(), sizeof(double) * perf.size());
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(raw);
+    return PG_OK;
+}

@@ -389,9 +389,7 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
              (long long)ld, n);
     PG_CHECK(ctx, (reinterpret_cast<uintptr_t>(G) & 15) == 0, "kinship: G must be 16-byte aligned");
     PG_HIP(ctx, hipSetDevice(ctx->device));
-    hipDeviceProp_t prop;
-    PG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int cus = ctx->cus;
 
     KinParams P;
     P.G = G; P.p = p; P.ld = ld; P.n = n;

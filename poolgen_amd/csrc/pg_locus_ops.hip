@@ -710,9 +710,7 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     PG_HIP(ctx, hipMemcpyAsync(wd, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (!tc.empty())
         PG_HIP(ctx, hipMemcpyAsync(tcd, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
-    hipDeviceProp_t prop;
-    PG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int cus = ctx->cus;
     const int64_t ntiles = (L + 63) / 64;
     int64_t blocks = (ntiles + LO_WAVES - 1) / LO_WAVES;
     const int64_t cap = (int64_t)cus * 8;

@@ -30,8 +30,17 @@ namespace {
 
 constexpr int SW_THREADS = 256;
 constexpr int SW_WAVES = SW_THREADS / 64;
-constexpr int SW_CH = 32;            // pools per LDS chunk
-constexpr int SW_PITCH = SW_CH + 2;  // doubles per LDS row (272 B)
+#ifndef SW_CH_DEF
+#define SW_CH_DEF 32
+#endif
+#ifndef SW_MINWAVES
+#define SW_MINWAVES 1
+#endif
+constexpr int SW_CH = SW_CH_DEF;     // pools per LDS chunk (32 or 16)
+constexpr int SW_PITCH = SW_CH + 2;  // doubles per LDS row: an odd number of 16-byte slots
+constexpr int SW_LPR = SW_CH / 2;    // lanes (16-byte pieces) per locus row of a chunk
+constexpr int SW_RPI = 64 / SW_LPR;  // locus rows per wave load instruction
+constexpr int SW_NLD = 64 / SW_RPI;  // load instructions per chunk
 constexpr int SW_TILE = 64 * SW_PITCH;
 
 struct SweepDims {
@@ -66,8 +75,8 @@ __device__ __forceinline__ void sweep_chunk(const double *__restrict__ G,
                                             int64_t l0, int64_t p, int64_t ld, int pool0, int npool,
                                             int lane, bool first, double &shift, double &s2,
                                             double (&acc)[C]) {
-    const int lr = lane >> 4;
-    const int piece = lane & 15;
+    const int lr = lane / SW_LPR;
+    const int piece = lane % SW_LPR;
     // ---- global -> registers: 16 x (4 loci x 256 B), branch-free (clamped address + select)
     int cofs = 2 * piece;
     bool col_ok = true, two = true;
@@ -77,21 +86,21 @@ __device__ __forceinline__ void sweep_chunk(const double *__restrict__ G,
         const int last = (npool - 1) & ~1;
         cofs = cofs < last ? cofs : last;
     }
-    double2 v[16];
+    double2 v[SW_NLD];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int64_t l = l0 + 4 * r + lr;
+    for (int r = 0; r < SW_NLD; ++r) {
+        int64_t l = l0 + SW_RPI * r + lr;
         l = l < p ? l : p - 1;
         v[r] = *reinterpret_cast<const double2 *>(G + l * ld + pool0 + cofs);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < SW_NLD; ++r) {
         double2 x = v[r];
         if (!FULL) {
             x.x = col_ok ? x.x : 0.0;
             x.y = two ? x.y : 0.0;
         }
-        *reinterpret_cast<double2 *>(&tile[(4 * r + lr) * SW_PITCH + 2 * piece]) = x;
+        *reinterpret_cast<double2 *>(&tile[(SW_RPI * r + lr) * SW_PITCH + 2 * piece]) = x;
     }
     __builtin_amdgcn_wave_barrier();
     // ---- lane = locus: walk the row; W is wave-uniform (scalar-cache operands) -----------------
@@ -122,7 +131,7 @@ __device__ __forceinline__ void sweep_chunk(const double *__restrict__ G,
 }
 
 template <int C>
-__global__ __launch_bounds__(SW_THREADS) void k_ols_sweep(
+__global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
     const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
     const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
     double *__restrict__ pval, const SweepDims D) {
@@ -427,9 +436,7 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
              (long long)ld, n);
     PG_CHECK(ctx, (reinterpret_cast<uintptr_t>(G_dev) & 15) == 0, "sweep: G must be 16-byte aligned");
     PG_HIP(ctx, hipSetDevice(ctx->device));
-    hipDeviceProp_t prop;
-    PG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int cus = ctx->cus;
     SweepArgs P;
     P.G = G_dev; P.W = ctx->W_dev; P.syy = ctx->syy_dev; P.tcoef = ctx->tcoef_dev;
     P.beta = beta_dev; P.var = var_dev; P.pval = pval_dev;
@@ -597,9 +604,7 @@ extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
     ctx->st_m = -1; // the regression state in W_dev is gone
     PG_HIP(ctx, hipMemcpyAsync(ctx->W_dev, Z.data(), zbytes, hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(beta_dev, b0.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
-    hipDeviceProp_t prop;
-    PG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int cus = ctx->cus;
     SweepDims D;
     std::memset(&D, 0, sizeof D);
     D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = k;

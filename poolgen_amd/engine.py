@@ -227,3 +227,22 @@ class Engine:
                                             Yh.ctypes.data, k, ri.ctypes.data, len(ri), xptr,
                                             beta.data_ptr()), "pg_gp_ols_dev")
         return beta
+
+    def gp_ridge(self, G: torch.Tensor, Y, row_idx, fold_of, n_folds: int, alpha: float = 0.0,
+                 lambda_step: float = 0.1, n: int | None = None):
+        """penalise_ridge_like (gp/penalise.rs:133-159) with explicit folds: fold_of is (n_reps, len(row_idx)).
+        Returns (beta (1+p) x k on the device, lambdas[k], perf[n_reps, n_folds, L, k])."""
+        p, ld, n = self._g_dims(G, n)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        ri = np.ascontiguousarray(np.asarray(row_idx, dtype=np.int64))
+        fo = np.ascontiguousarray(np.asarray(fold_of, dtype=np.int32)).reshape(-1, len(ri))
+        L = int(round(1.0 / lambda_step)) + 1
+        beta = torch.empty((p + 1, k), dtype=torch.float64, device=G.device)
+        lam = np.empty(k)
+        perf = np.empty((fo.shape[0], n_folds, L, k))
+        self._check(self._lib.pg_gp_ridge_dev(self._ctx, self._dev(G, torch.float64), p, n, ld, Yh.ctypes.data, k,
+                                              ri.ctypes.data, len(ri), fo.ctypes.data, fo.shape[0], int(n_folds),
+                                              float(alpha), float(lambda_step), beta.data_ptr(), lam.ctypes.data,
+                                              perf.ctypes.data), "pg_gp_ridge_dev")
+        return beta, lam, perf

