@@ -20,13 +20,16 @@
 
 namespace {
 
-constexpr int KIN_THREADS = 1024;
-constexpr int KIN_WAVES = 16;
+#ifndef KIN_WAVES_DEF
+#define KIN_WAVES_DEF 16
+#endif
+constexpr int KIN_WAVES = KIN_WAVES_DEF; // 16 (6 tile slots per wave) or 8 (12 slots)
+constexpr int KIN_THREADS = 64 * KIN_WAVES;
 #ifndef KIN_RING_D
 #define KIN_RING_D 3
 #endif
 constexpr int KIN_FUSE_MAXK = 2; // traits the fused intercept-only pass carries
-constexpr int KIN_TPW = 6;  // max tiles per wave (ceil(91/16), ceil(81/16))
+constexpr int KIN_TPW = 96 / KIN_WAVES;  // max tiles per wave (>= ceil(91 / waves), ceil(81 / waves))
 #ifndef KIN_KC_DEF
 #define KIN_KC_DEF 16
 #endif
@@ -57,7 +60,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 constexpr int kin_tri_ti(int t, int T) { int ti = 0; while (ti < T && t >= T - ti) { t -= T - ti; ++ti; } return ti < T ? ti : 0; }
 constexpr int kin_tri_tj(int t, int T) { int ti = 0; while (ti < T && t >= T - ti) { t -= T - ti; ++ti; } return ti < T ? ti + t : 0; }
 // tile of slot u of wave w (slots past the end of the list recompute tile 0 and are never stored)
-constexpr int kin_slot_tile(int w, int u, int T) { return (w + 16 * u) < T * (T + 1) / 2 ? (w + 16 * u) : 0; }
+constexpr int kin_slot_tile(int w, int u, int T) { return (w + KIN_WAVES_DEF * u) < T * (T + 1) / 2 ? (w + KIN_WAVES_DEF * u) : 0; }
 
 struct KinParams {
     const double *G;
@@ -348,6 +351,9 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         case 4: run(std::integral_constant<int, 4>{}); break;
         case 5: run(std::integral_constant<int, 5>{}); break;
         case 6: run(std::integral_constant<int, 6>{}); break;
+#if KIN_WAVES_DEF == 8
+        default: run(std::integral_constant<int, 7>{}); break;
+#else
         case 7: run(std::integral_constant<int, 7>{}); break;
         case 8: run(std::integral_constant<int, 8>{}); break;
         case 9: run(std::integral_constant<int, 9>{}); break;
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         case 13: run(std::integral_constant<int, 13>{}); break;
         case 14: run(std::integral_constant<int, 14>{}); break;
         default: run(std::integral_constant<int, 15>{}); break;
+#endif
         }
     } else {
         run(std::integral_constant<int, -1>{});

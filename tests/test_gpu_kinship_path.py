@@ -206,3 +206,23 @@ def test_gp_ridge_path_matches_oracle(engine, oracle, n, p, k, alpha):
     # the reference's unit vectors (gp/penalise.rs:709-720) through the same device code path: alpha = 1,
     # lambda = 0.5 contracts the small coefficients and moves their mass to the large ones
     assert len(np.unique(lam)) >= 1 and np.all((lam >= 0) & (lam <= 1))
+
+
+@pytest.mark.parametrize("p,n,k", [(6000, 200, 2), (5000, 200, 3), (3000, 33, 1), (2000, 100, 2), (4000, 208, 1), (1500, 193, 1)])
+def test_fused_and_two_pass_paths_agree_with_oracle(engine, oracle, p, n, k):
+    """m = 0 through the fused kinship pass (k <= 2) or the two-pass path (k = 3), generic and 13-tile
+    kernels, odd n: same answers as the oracle, and as each other."""
+    G, Y2 = make(p, n, 53)
+    Y = np.hstack([Y2, (Y2[:, :1] - Y2[:, 1:2]) ** 2])[:, :k]
+    m, K, beta, var, pv = engine.ols_with_covariate(G, Y, 0.75, n=n)
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y, 0.75, n=n)
+    assert m == ref["m"] == 0
+    assert np.allclose(K, ref["K"], rtol=1e-11)
+    cmp_fit((beta, var, pv), ref, f"fused/auto p={p} n={n} k={k}")
+    # explicit two-pass path on the same inputs
+    engine.set_phenotypes(None)
+    S = engine.kinship_partial(G, n)
+    m2, _, _ = engine.kinship_set(S, p, Y, 0.75)
+    b2, v2, p2 = engine.ols_sweep(G, k, n)
+    assert m2 == 0
+    assert torch.allclose(b2, beta, rtol=1e-9, atol=1e-12) and float((p2 - pv).abs().max()) < 1e-11
