@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef LO_POOL_UNROLL
+#define LO_POOL_UNROLL 1
+#endif
 constexpr int LO_THREADS = 256;
 constexpr int LO_WAVES = 4;
 constexpr int LO_CHP = 8;                 // pools per stage
@@ -72,17 +75,27 @@ __device__ __forceinline__ void stage_counts(const uint32_t *__restrict__ counts
         }
         const char *gbase = reinterpret_cast<const char *>(counts) + (int64_t)pool0 * 24 + off;
         char *tbase = tile + sub * LO_PITCH + off;
+        // all loads of the stage are issued before the first LDS write (NI x 16 bytes in flight per lane)
+        if (PBE == 16) {
+            uint4_t v[NI];
 #pragma unroll
-        for (int r = 0; r < NI; ++r) {
-            int64_t l = l0 + LPI * r + sub;
-            l = l < L ? l : L - 1;
-            if (PBE == 16) {
-                const uint4_t v = *reinterpret_cast<const uint4_t *>(gbase + l * rowb);
-                *reinterpret_cast<uint4_t *>(tbase + r * (LPI * LO_PITCH)) = v;
-            } else {
-                const uint2_t v = *reinterpret_cast<const uint2_t *>(gbase + l * rowb);
-                *reinterpret_cast<uint2_t *>(tbase + r * (LPI * LO_PITCH)) = v;
+            for (int r = 0; r < NI; ++r) {
+                int64_t l = l0 + LPI * r + sub;
+                l = l < L ? l : L - 1;
+                v[r] = *reinterpret_cast<const uint4_t *>(gbase + l * rowb);
             }
+#pragma unroll
+            for (int r = 0; r < NI; ++r) *reinterpret_cast<uint4_t *>(tbase + r * (LPI * LO_PITCH)) = v[r];
+        } else {
+            uint2_t v[NI];
+#pragma unroll
+            for (int r = 0; r < NI; ++r) {
+                int64_t l = l0 + LPI * r + sub;
+                l = l < L ? l : L - 1;
+                v[r] = *reinterpret_cast<const uint2_t *>(gbase + l * rowb);
+            }
+#pragma unroll
+            for (int r = 0; r < NI; ++r) *reinterpret_cast<uint2_t *>(tbase + r * (LPI * LO_PITCH)) = v[r];
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -149,88 +162,70 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_ops(
     for (int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave; t < ntiles; t += wstride) {
         const int64_t l0 = t * 64;
         const int64_t l = l0 + lane;
-        // ================= pass 1: coverage and pool-size weighted allele frequencies =========
+        // ================= streaming passes =====================================================
+        // Pass 1 computes the filter quantities (coverage, q_j) AND, speculatively, the operator's sums
+        // with every candidate allele kept.  If every allele the filter then drops has zero counts in
+        // every pool (the common case: absent alleles), the row sums over the surviving alleles equal
+        // the ones used, i.e. the speculative sums ARE the reference's -- one read of the counts.
+        // Otherwise (a dropped allele with reads, e.g. a sequencing-error allele below the MAF) the
+        // wave runs pass 2 over the surviving alleles, as the reference's second to_frequencies does.
         double q[NA];
-#pragma unroll
-        for (int j = 0; j < NA; ++j) q[j] = 0.0;
         double mincov = 0.0;
         int n_missing = 0;
-        for (int st = 0; st < nst; ++st) {
-            const int pool0 = st * LO_CHP;
-            const int np = min(LO_CHP, n - pool0);
-            if (np == LO_CHP) stage_counts<PB, true>(counts, tile, l0, P.L, n, pool0, np, lane);
-            else stage_counts<PB, false>(counts, tile, l0, P.L, n, pool0, np, lane);
-#pragma unroll 1
-            for (int i = 0; i < np; ++i) {
-                uint32_t c[NA];
-                read_pool(row, i, c);
-                double rs = 0.0; // row sum over the columns left after the N removal (sync.rs:217-222)
-#pragma unroll
-                for (int j = 0; j < NA; ++j)
-                    if (!(P.remove_ns && j == 4)) rs = rs + (double)c[j];
-                mincov = (pool0 + i == 0 || rs < mincov) ? rs : mincov;
-                n_missing += (rs == 0.0) ? 1 : 0;
-                const double wi = w[pool0 + i];
-                const double rinv = recip_for_div(rs);
-#pragma unroll
-                for (int j = 0; j < NA; ++j) {
-                    if (P.remove_ns && j == 4) continue;
-                    // f = c / rs (NaN if rs == 0, skipped); q += f * w_i   (sync.rs:258-271)
-                    const double f = div_by((double)c[j], rs, rinv);
-                    q[j] = (c[j] != 0u && rs != 0.0) ? q[j] + f * wi : q[j];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        bool keep[NA];
-        int nk = 0;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            keep[j] = !(P.remove_ns && j == 4) && !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
-            nk += keep[j] ? 1 : 0;
-        }
-        bool alive = !(mincov < P.min_cov);                                        // sync.rs:227
-        alive = alive && nk >= 2;                                                  // sync.rs:284
-        alive = alive && n_missing != n;                                           // sync.rs:293
-        alive = alive && !(((double)n_missing / (double)n) > P.max_miss);          // sync.rs:297
-        alive = alive && l < P.L;
-
-        // ================= pass 2: frequencies over the surviving alleles + operator sums ======
+        bool anynz[NA];
         double cs[NA];            // NaN-ignoring column sums (sort key, mean frequency)
         double xx[21];            // OLS: sum f_a f_b (a <= b); CHISQ: xx[tri(j,j)] = sum f_j^2 / rs_i
         double xy[NA * MAXK];     // OLS: sum f_j y_t ; PEARSON: sum x y over complete pairs
         double px[NA * MAXK], pxx[NA * MAXK], py[MAXK], pyy[MAXK], pn[MAXK];
         double total = 0.0;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) cs[j] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 21; ++j) xx[j] = 0.0;
-#pragma unroll
-        for (int j = 0; j < NA * MAXK; ++j) { xy[j] = 0.0; px[j] = 0.0; pxx[j] = 0.0; }
-#pragma unroll
-        for (int j = 0; j < MAXK; ++j) { py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
         double shx[NA]; // Pearson: per-allele shift (first valid frequency) for stable one-pass sums
-#pragma unroll
-        for (int j = 0; j < NA; ++j) shx[j] = 0.0;
         bool shset = false;
+        bool keep[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) { q[j] = 0.0; anynz[j] = false; keep[j] = !(P.remove_ns && j == 4); }
 
-        for (int st = 0; st < nst; ++st) {
-            const int pool0 = st * LO_CHP;
-            const int np = min(LO_CHP, n - pool0);
-            if (np == LO_CHP) stage_counts<PB, true>(counts, tile, l0, P.L, n, pool0, np, lane);
-            else stage_counts<PB, false>(counts, tile, l0, P.L, n, pool0, np, lane);
-#pragma unroll 1
-            for (int i = 0; i < np; ++i) {
-                uint32_t c[NA];
-                read_pool(row, i, c);
-                double rs = 0.0; // row sum over the surviving alleles (to_frequencies, sync.rs:170-175)
+        bool alive = false;
+        int nk = 0;
+        for (int pass = 0; pass < 2; ++pass) { // one code copy for both passes keeps the register count down
+            const bool first = (pass == 0);
 #pragma unroll
-                for (int j = 0; j < NA; ++j) rs = keep[j] ? rs + (double)c[j] : rs;
-                double f[NA];
-                const double rinv = recip_for_div(rs);
+            for (int j = 0; j < NA; ++j) { cs[j] = 0.0; shx[j] = 0.0; }
 #pragma unroll
-                for (int j = 0; j < NA; ++j)
-                    f[j] = (rs == 0.0) ? NAN : ((c[j] != 0u && keep[j]) ? div_by((double)c[j], rs, rinv) : 0.0);
+            for (int j = 0; j < 21; ++j) xx[j] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NA * MAXK; ++j) { xy[j] = 0.0; px[j] = 0.0; pxx[j] = 0.0; }
+#pragma unroll
+            for (int j = 0; j < MAXK; ++j) { py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
+            total = 0.0;
+            shset = false;
+            for (int st = 0; st < nst; ++st) {
+                const int pool0 = st * LO_CHP;
+                const int np = min(LO_CHP, n - pool0);
+                if (np == LO_CHP) stage_counts<PB, true>(counts, tile, l0, P.L, n, pool0, np, lane);
+                else stage_counts<PB, false>(counts, tile, l0, P.L, n, pool0, np, lane);
+#pragma unroll LO_POOL_UNROLL
+                for (int i = 0; i < np; ++i) {
+                    uint32_t c[NA];
+                    read_pool(row, i, c);
+                    double rs = 0.0; // row sum over the alleles in play (sync.rs:217-222 / :170-175)
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) rs = keep[j] ? rs + (double)c[j] : rs;
+                    const double rinv = recip_for_div(rs);
+                    double f[NA];
+#pragma unroll
+                    for (int j = 0; j < NA; ++j)
+                        f[j] = (rs == 0.0) ? NAN : ((c[j] != 0u && keep[j]) ? div_by((double)c[j], rs, rinv) : 0.0);
+                    if (first) {
+                        mincov = (pool0 + i == 0 || rs < mincov) ? rs : mincov;
+                        n_missing += (rs == 0.0) ? 1 : 0;
+                        const double wi = w[pool0 + i];
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) {
+                            // q += f * w_i, NaN frequencies contribute 0 (sync.rs:258-271)
+                            q[j] = (c[j] != 0u && rs != 0.0 && keep[j]) ? q[j] + f[j] * wi : q[j];
+                            anynz[j] = anynz[j] || (c[j] != 0u);
+                        }
+                    }
                 const bool rowok = rs != 0.0;
 #pragma unroll
                 for (int j = 0; j < NA; ++j) cs[j] = rowok ? cs[j] + f[j] : cs[j];
@@ -279,9 +274,27 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_ops(
 #pragma unroll
                     for (int j = 0; j < NA; ++j) xx[tri(j, j)] = xx[tri(j, j)] + (f[j] * f[j]) / rsum;
                 }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
+            if (!first) break;
+            bool dropped_with_reads = false;
+            nk = 0;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const bool cand = keep[j];
+                keep[j] = cand && !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
+                nk += keep[j] ? 1 : 0;
+                dropped_with_reads = dropped_with_reads || (cand && !keep[j] && anynz[j]);
+            }
+            alive = !(mincov < P.min_cov);                                             // sync.rs:227
+            alive = alive && nk >= 2;                                                  // sync.rs:284
+            alive = alive && n_missing != n;                                           // sync.rs:293
+            alive = alive && !(((double)n_missing / (double)n) > P.max_miss);          // sync.rs:297
+            alive = alive && l < P.L;
+            if (!__any(alive && dropped_with_reads)) break; // wave-uniform: the speculative sums stand
         }
+
         if (l >= P.L) continue;
         // The sums go to a per-locus record (struct-of-arrays, coalesced stores); k_locus_close<OP>
         // finishes the statistic.  Keeping the transcendental / LU code out of this kernel keeps its
