@@ -18,13 +18,11 @@
 #include "pg_common.h"
 #include "pg_stats_device.h"
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace {
 
-#ifndef LO_POOL_UNROLL
-#define LO_POOL_UNROLL 1
-#endif
 constexpr int LO_THREADS = 256;
 constexpr int LO_WAVES = 4;
 constexpr int LO_CHP = 8;                 // pools per stage
@@ -50,62 +48,75 @@ struct LocusParams {
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
-// Stage pools [pool0, pool0 + np) of loci l0..l0+63 into the wave's tile.  A locus row of a stage is
-// 192 bytes = 12 pieces of 16 B (24 of 8 B when n is odd and rows are only 8-byte aligned): 48 lanes
-// cover 4 (2) loci per instruction, so that every address is "lane base + r * constant" -- no
-// per-piece address registers -- at the price of 16 idle lanes (loads are not the bottleneck, bytes
-// in flight are).  The last, partial stage always moves 8-byte pieces whose offset is clamped
-// INSIDE the row (no read past the end of the batch) and which land at that same offset in the tile.
-template <int PB, bool FULL>
-__device__ __forceinline__ void stage_counts(const uint32_t *__restrict__ counts, char *tile,
-                                             int64_t l0, int64_t L, int n, int pool0, int np,
-                                             int lane) {
-    constexpr int PBE = FULL ? PB : 8;
-    constexpr int PPR = LO_ROWB / PBE;     // pieces per locus row: 12 or 24
-    constexpr int LPI = 48 / PPR;          // loci per wave instruction: 4 or 2
-    constexpr int NI = 64 / LPI;           // instructions per stage: 16 or 32
+// ---- staging: HBM -> registers -> wave-private LDS tile ------------------------------------------
+// A locus row of a stage is 192 bytes = 12 pieces of 16 B (24 of 8 B when rows are only 8-byte
+// aligned, and always for the last, partial stage): 48 lanes cover 4 (2) loci per instruction, so that
+// every address is "lane base + r * constant".  The loads of a stage land in 64 registers per lane and
+// are written to the tile one stage later: they are in flight while the previous stage is computed.
+// The partial stage moves 8-byte pieces whose offset is clamped INSIDE the row (no read past the end
+// of the batch) and which land at that same offset in the tile.
+struct StageRegs { uint32_t v[64]; };
+
+template <int PBE> struct StageGeom {
+    static constexpr int PPR = LO_ROWB / PBE;  // pieces per locus row: 12 or 24
+    static constexpr int LPI = 48 / PPR;       // loci per wave instruction: 4 or 2
+    static constexpr int NI = 64 / LPI;        // instructions per stage: 16 or 32
+};
+
+// rowsel(r_locus) -> global locus index of tile row r_locus (0..63)
+template <int PBE, bool CLAMP, typename RowSel>
+__device__ __forceinline__ void stage_load(StageRegs &S, const uint32_t *__restrict__ counts, int n, int pool0,
+                                           int np, int lane, RowSel rowsel) {
+    using G = StageGeom<PBE>;
     if (lane < 48) {
         const int64_t rowb = (int64_t)n * 24;
-        const int sub = lane / PPR;
-        const int pc = lane - sub * PPR;
+        const int sub = lane / G::PPR;
+        const int pc = lane - sub * G::PPR;
         int off = pc * PBE;
-        if (!FULL) {
+        if (CLAMP) {
             const int valid = np * 24;
             off = off < valid ? off : valid - PBE;
         }
         const char *gbase = reinterpret_cast<const char *>(counts) + (int64_t)pool0 * 24 + off;
-        char *tbase = tile + sub * LO_PITCH + off;
-        // all loads of the stage are issued before the first LDS write (NI x 16 bytes in flight per lane)
-        if (PBE == 16) {
-            uint4_t v[NI];
 #pragma unroll
-            for (int r = 0; r < NI; ++r) {
-                int64_t l = l0 + LPI * r + sub;
-                l = l < L ? l : L - 1;
-                v[r] = *reinterpret_cast<const uint4_t *>(gbase + l * rowb);
+        for (int r = 0; r < G::NI; ++r) {
+            const int64_t l = rowsel(G::LPI * r + sub);
+            if (PBE == 16) {
+                const uint4_t x = *reinterpret_cast<const uint4_t *>(gbase + l * rowb);
+                S.v[4 * r] = x.x; S.v[4 * r + 1] = x.y; S.v[4 * r + 2] = x.z; S.v[4 * r + 3] = x.w;
+            } else {
+                const uint2_t x = *reinterpret_cast<const uint2_t *>(gbase + l * rowb);
+                S.v[2 * r] = x.x; S.v[2 * r + 1] = x.y;
             }
-#pragma unroll
-            for (int r = 0; r < NI; ++r) *reinterpret_cast<uint4_t *>(tbase + r * (LPI * LO_PITCH)) = v[r];
-        } else {
-            uint2_t v[NI];
-#pragma unroll
-            for (int r = 0; r < NI; ++r) {
-                int64_t l = l0 + LPI * r + sub;
-                l = l < L ? l : L - 1;
-                v[r] = *reinterpret_cast<const uint2_t *>(gbase + l * rowb);
-            }
-#pragma unroll
-            for (int r = 0; r < NI; ++r) *reinterpret_cast<uint2_t *>(tbase + r * (LPI * LO_PITCH)) = v[r];
         }
     }
-    __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void read_pool(const char *row, int i, uint32_t (&c)[NA]) {
-    const uint2_t a = *reinterpret_cast<const uint2_t *>(row + i * 24);
-    const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
-    const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
-    c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = d.x; c[5] = d.y;
+template <int PBE, bool CLAMP>
+__device__ __forceinline__ void stage_store(const StageRegs &S, char *tile, int np, int lane) {
+    using G = StageGeom<PBE>;
+    if (lane < 48) {
+        const int sub = lane / G::PPR;
+        const int pc = lane - sub * G::PPR;
+        int off = pc * PBE;
+        if (CLAMP) {
+            const int valid = np * 24;
+            off = off < valid ? off : valid - PBE;
+        }
+        char *tbase = tile + sub * LO_PITCH + off;
+#pragma unroll
+        for (int r = 0; r < G::NI; ++r) {
+            if (PBE == 16) {
+                uint4_t x;
+                x.x = S.v[4 * r]; x.y = S.v[4 * r + 1]; x.z = S.v[4 * r + 2]; x.w = S.v[4 * r + 3];
+                *reinterpret_cast<uint4_t *>(tbase + r * (G::LPI * LO_PITCH)) = x;
+            } else {
+                uint2_t x;
+                x.x = S.v[2 * r]; x.y = S.v[2 * r + 1];
+                *reinterpret_cast<uint2_t *>(tbase + r * (G::LPI * LO_PITCH)) = x;
+            }
+        }
+    }
 }
 
 // IEEE-correct c / rs for a whole pool from ONE reciprocal.  This is the arithmetic hipcc itself
@@ -114,7 +125,8 @@ __device__ __forceinline__ void read_pool(const char *row, int i, uint32_t (&c)[
 // wrappers only act on over-/underflowing operands, which counts and coverages are not), with the
 // reciprocal shared by the (up to six) alleles of the pool instead of being recomputed per allele.
 // The quotients are therefore bit-identical to `c / rs`; tests/test_gpu_locus_ops.py pins that
-// through the bit-exact mean frequencies and filter decisions.
+// through the bit-exact mean frequencies and filter decisions.  rs == 0 gives NaN (0 * inf), which
+// is what to_frequencies produces for an uncovered pool (sync.rs:176-183).
 __device__ __forceinline__ double recip_for_div(double b) {
     const double r0 = __builtin_amdgcn_rcp(b);
     const double r1 = fma(fma(-b, r0, 1.0), r0, r0);
@@ -142,196 +154,337 @@ __device__ __forceinline__ constexpr int tri(int a, int b) { // a <= b
 constexpr int R_CS = 0, R_XX = R_CS + NA, R_XY = R_XX + 21, R_PX = R_XY + NA * MAXK, R_PXX = R_PX + NA * MAXK,
               R_PY = R_PXX + NA * MAXK, R_PYY = R_PY + MAXK, R_PN = R_PYY + MAXK, R_TOTAL = R_PN + MAXK,
               REC_DOUBLES = R_TOTAL + 1;
+constexpr int FLAG_ALIVE = 1, FLAG_SECOND = 1 << 7; // bits 1..6: surviving alleles
 
-template <int OP, int PB>
-__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_ops(
+// The operator's running sums of one locus over the alleles "in play" (NJ of them; allele id of slot
+// jj is aj(jj)).  Everything is accumulated sequentially in pool order.
+template <int OP, int NJ, int K>
+struct Sums {
+    double cs[NJ];                 // NaN-ignoring column sums (sort key, mean frequency); plain adds
+    double xx[NJ * (NJ + 1) / 2];  // OLS: sum f_a f_b (a <= b); CHISQ: first NJ entries = sum f_j^2 / rowsum
+    double xy[NJ * K];          // OLS: sum f_j y_t; PEARSON: sum x y over complete pairs
+    double px[NJ * K], pxx[NJ * K], py[K], pyy[K], pn[K], shx[NJ];
+    double total;
+    bool shset;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { cs[j] = 0.0; shx[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < NJ * (NJ + 1) / 2; ++j) xx[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ * K; ++j) { xy[j] = 0.0; px[j] = 0.0; pxx[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < K; ++j) { py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
+        total = 0.0;
+        shset = false;
+    }
+    static __device__ __forceinline__ constexpr int trin(int a, int b) { return a * NJ - a * (a - 1) / 2 + (b - a); }
+    // f: frequencies of this pool (NaN when the pool is uncovered), f0: the same with NaN -> 0
+    __device__ __forceinline__ void add_pool(const double (&f)[NJ], const double (&f0)[NJ], bool rowok,
+                                             const double *__restrict__ Yrow) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cs[j] = cs[j] + f0[j];
+        if (OP == OP_OLS) {
+#pragma unroll
+            for (int a = 0; a < NJ; ++a)
+#pragma unroll
+                for (int b = a; b < NJ; ++b) xx[trin(a, b)] = fma(f[a], f[b], xx[trin(a, b)]);
+#pragma unroll
+            for (int tt = 0; tt < K; ++tt) {
+                const double y = Yrow[tt];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) xy[j * K + tt] = fma(f[j], y, xy[j * K + tt]);
+            }
+        } else if (OP == OP_PEARSON) {
+            if (rowok && !shset) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) shx[j] = f[j];
+                shset = true;
+            }
+#pragma unroll
+            for (int tt = 0; tt < K; ++tt) {
+                {
+                    const double y = Yrow[tt];           // shifted by its first valid value on the host
+                    const bool ok = rowok && !isnan(y);  // pairwise complete (correlation_test.rs:22-26)
+                    py[tt] = ok ? py[tt] + y : py[tt];
+                    pyy[tt] = ok ? fma(y, y, pyy[tt]) : pyy[tt];
+                    pn[tt] = ok ? pn[tt] + 1.0 : pn[tt];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const double x = f[j] - shx[j];
+                        const int e = j * K + tt;
+                        px[e] = ok ? px[e] + x : px[e];
+                        pxx[e] = ok ? fma(x, x, pxx[e]) : pxx[e];
+                        xy[e] = ok ? fma(x, y, xy[e]) : xy[e];
+                    }
+                }
+            }
+        } else { // OP_CHISQ: chi2 = total * (sum_j A_j / cs_j - 1), A_j = sum_i f_ij^2 / rowsum_i
+            double rsum = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rsum = rsum + f[j]; // row sum of the frequencies (~1)
+            total = total + rsum;
+            const double ri = recip_for_div(rsum);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xx[j] = xx[j] + div_by(f[j] * f[j], rsum, ri);
+        }
+    }
+};
+
+// write the sums of one locus to its record; AJ(jj) = allele id of slot jj
+template <int OP, int NJ, int K, typename AJ>
+__device__ __forceinline__ void store_record(const Sums<OP, NJ, K> &S, double *__restrict__ rec, int64_t L, int64_t l,
+                                             AJ aj) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rec[(size_t)(R_CS + aj(j)) * L + l] = S.cs[j];
+    if (OP == OP_OLS) {
+#pragma unroll
+        for (int a = 0; a < NJ; ++a)
+#pragma unroll
+            for (int b = a; b < NJ; ++b) rec[(size_t)(R_XX + tri(aj(a), aj(b))) * L + l] = S.xx[S.trin(a, b)];
+    }
+    if (OP == OP_CHISQ) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) rec[(size_t)(R_XX + tri(aj(j), aj(j))) * L + l] = S.xx[j];
+        rec[(size_t)R_TOTAL * L + l] = S.total;
+    }
+    if (OP == OP_OLS || OP == OP_PEARSON) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int tt = 0; tt < K; ++tt) rec[(size_t)(R_XY + aj(j) * MAXK + tt) * L + l] = S.xy[j * K + tt];
+    }
+    if (OP == OP_PEARSON) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int tt = 0; tt < K; ++tt) {
+                rec[(size_t)(R_PX + aj(j) * MAXK + tt) * L + l] = S.px[j * K + tt];
+                rec[(size_t)(R_PXX + aj(j) * MAXK + tt) * L + l] = S.pxx[j * K + tt];
+            }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            rec[(size_t)(R_PY + j) * L + l] = S.py[j];
+            rec[(size_t)(R_PYY + j) * L + l] = S.pyy[j];
+            rec[(size_t)(R_PN + j) * L + l] = S.pn[j];
+        }
+    }
+}
+
+// ---- first pass: every locus, one read of its counts ----------------------------------------------
+// Computes the filter quantities (coverage, q_j) AND, speculatively, the operator's sums with every
+// candidate allele in play.  If every allele the filter then drops has zero counts in every pool (the
+// common case: absent alleles), the row sums over the surviving alleles equal the ones used, i.e. the
+// speculative sums ARE the reference's.  Otherwise (a dropped allele with reads, e.g. a
+// sequencing-error allele below the MAF) the locus is appended to `second` and k_locus_second redoes
+// its sums over the surviving alleles, as the reference's second to_frequencies does.
+// RNS = "remove Ns" (the CLI default, main.rs:203): column 4 is not in play at all.
+template <int OP, int PB, bool RNS, int K>
+__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
     const uint32_t *__restrict__ counts, const double *__restrict__ w, const double *__restrict__ Y,
-    const double *__restrict__ tcoef, int32_t *__restrict__ n_out, int32_t *__restrict__ ids_out,
-    double *__restrict__ mf_out, double *__restrict__ stat_out, double *__restrict__ pv_out,
-    int32_t *__restrict__ rec_flags, double *__restrict__ rec, const LocusParams P) {
+    int32_t *__restrict__ rec_flags, double *__restrict__ rec, int64_t *__restrict__ second,
+    unsigned long long *__restrict__ second_count, const LocusParams P) {
+    constexpr int NJ = RNS ? 5 : 6;
+    auto aj = [](int jj) { return (RNS && jj >= 4) ? jj + 1 : jj; };
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     char *tile = lds_raw + wave * LO_TILEB;
     const char *row = tile + lane * LO_PITCH;
-    const int n = P.n, k = P.k;
+    const int n = P.n;
+    const int nfull = n / LO_CHP;
     const int nst = (n + LO_CHP - 1) / LO_CHP;
     const int64_t ntiles = (P.L + 63) / 64;
     const int64_t wstride = (int64_t)gridDim.x * LO_WAVES;
+    const int64_t L = P.L;
 
-    for (int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave; t < ntiles; t += wstride) {
+    StageRegs S;
+    Sums<OP, NJ, K> A;
+    double q[NJ];
+    uint32_t orc[NJ];
+    double mincov = 0.0;
+    int n_missing = 0;
+
+    auto issue = [&](int64_t t, int st) {
         const int64_t l0 = t * 64;
-        const int64_t l = l0 + lane;
-        // ================= streaming passes =====================================================
-        // Pass 1 computes the filter quantities (coverage, q_j) AND, speculatively, the operator's sums
-        // with every candidate allele kept.  If every allele the filter then drops has zero counts in
-        // every pool (the common case: absent alleles), the row sums over the surviving alleles equal
-        // the ones used, i.e. the speculative sums ARE the reference's -- one read of the counts.
-        // Otherwise (a dropped allele with reads, e.g. a sequencing-error allele below the MAF) the
-        // wave runs pass 2 over the surviving alleles, as the reference's second to_frequencies does.
-        double q[NA];
-        double mincov = 0.0;
-        int n_missing = 0;
-        bool anynz[NA];
-        double cs[NA];            // NaN-ignoring column sums (sort key, mean frequency)
-        double xx[21];            // OLS: sum f_a f_b (a <= b); CHISQ: xx[tri(j,j)] = sum f_j^2 / rs_i
-        double xy[NA * MAXK];     // OLS: sum f_j y_t ; PEARSON: sum x y over complete pairs
-        double px[NA * MAXK], pxx[NA * MAXK], py[MAXK], pyy[MAXK], pn[MAXK];
-        double total = 0.0;
-        double shx[NA]; // Pearson: per-allele shift (first valid frequency) for stable one-pass sums
-        bool shset = false;
-        bool keep[NA];
+        auto rowsel = [&](int r) { const int64_t l = l0 + r; return l < L ? l : L - 1; };
+        const int pool0 = st * LO_CHP;
+        if (st < nfull) stage_load<PB, false>(S, counts, n, pool0, LO_CHP, lane, rowsel);
+        else stage_load<8, true>(S, counts, n, pool0, n - pool0, lane, rowsel);
+    };
+    // one pool of this lane's locus
+    auto pool = [&](const uint32_t (&c)[NJ], int pi) {
+        double cd[NJ], f[NJ], f0[NJ];
+        double rs = 0.0; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175)
 #pragma unroll
-        for (int j = 0; j < NA; ++j) { q[j] = 0.0; anynz[j] = false; keep[j] = !(P.remove_ns && j == 4); }
+        for (int j = 0; j < NJ; ++j) { cd[j] = (double)c[j]; rs = rs + cd[j]; }
+        const double rinv = recip_for_div(rs);
+        const bool rowok = rs != 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f[j] = div_by(cd[j], rs, rinv);
+            f0[j] = rowok ? f[j] : 0.0;
+            orc[j] |= c[j];
+        }
+        mincov = (pi == 0 || rs < mincov) ? rs : mincov;   // sync.rs:223-227
+        n_missing += rowok ? 0 : 1;
+        const double wi = w[pi];
+        // q += f * w_i with separate multiply and add; NaN frequencies contribute 0 (sync.rs:258-271)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) q[j] = q[j] + f0[j] * wi;
+        A.add_pool(f, f0, rowok, Y + (size_t)pi * K);
+    };
 
-        bool alive = false;
-        int nk = 0;
-        for (int pass = 0; pass < 2; ++pass) { // one code copy for both passes keeps the register count down
-            const bool first = (pass == 0);
+    int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave;
+    int st = 0;
+    if (t < ntiles) issue(t, 0);
+    while (t < ntiles) {
+        const bool cur_full = st < nfull;
+        const int pool0 = st * LO_CHP;
+        if (cur_full) stage_store<PB, false>(S, tile, LO_CHP, lane);
+        else stage_store<8, true>(S, tile, n - pool0, lane);
+        __builtin_amdgcn_wave_barrier();
+        int64_t nt = t;
+        int ns = st + 1;
+        if (ns == nst) { ns = 0; nt = t + wstride; }
+        if (nt < ntiles) issue(nt, ns); // in flight while this stage is computed
+        if (st == 0) {
+            A.clear();
 #pragma unroll
-            for (int j = 0; j < NA; ++j) { cs[j] = 0.0; shx[j] = 0.0; }
+            for (int j = 0; j < NJ; ++j) { q[j] = 0.0; orc[j] = 0u; }
+            mincov = 0.0;
+            n_missing = 0;
+        }
+        if (cur_full) {
+#pragma unroll 1
+            for (int i = 0; i < LO_CHP; i += 2) { // two pools = 48 bytes = three 16-byte reads
+                const uint4_t a = *reinterpret_cast<const uint4_t *>(row + i * 24);
+                const uint4_t b = *reinterpret_cast<const uint4_t *>(row + i * 24 + 16);
+                const uint4_t d = *reinterpret_cast<const uint4_t *>(row + i * 24 + 32);
+                const uint32_t c0[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+                const uint32_t c1[6] = {b.z, b.w, d.x, d.y, d.z, d.w};
+                uint32_t e0[NJ], e1[NJ];
 #pragma unroll
-            for (int j = 0; j < 21; ++j) xx[j] = 0.0;
-#pragma unroll
-            for (int j = 0; j < NA * MAXK; ++j) { xy[j] = 0.0; px[j] = 0.0; pxx[j] = 0.0; }
-#pragma unroll
-            for (int j = 0; j < MAXK; ++j) { py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
-            total = 0.0;
-            shset = false;
-            for (int st = 0; st < nst; ++st) {
-                const int pool0 = st * LO_CHP;
-                const int np = min(LO_CHP, n - pool0);
-                if (np == LO_CHP) stage_counts<PB, true>(counts, tile, l0, P.L, n, pool0, np, lane);
-                else stage_counts<PB, false>(counts, tile, l0, P.L, n, pool0, np, lane);
-#pragma unroll LO_POOL_UNROLL
-                for (int i = 0; i < np; ++i) {
-                    uint32_t c[NA];
-                    read_pool(row, i, c);
-                    double rs = 0.0; // row sum over the alleles in play (sync.rs:217-222 / :170-175)
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) rs = keep[j] ? rs + (double)c[j] : rs;
-                    const double rinv = recip_for_div(rs);
-                    double f[NA];
-#pragma unroll
-                    for (int j = 0; j < NA; ++j)
-                        f[j] = (rs == 0.0) ? NAN : ((c[j] != 0u && keep[j]) ? div_by((double)c[j], rs, rinv) : 0.0);
-                    if (first) {
-                        mincov = (pool0 + i == 0 || rs < mincov) ? rs : mincov;
-                        n_missing += (rs == 0.0) ? 1 : 0;
-                        const double wi = w[pool0 + i];
-#pragma unroll
-                        for (int j = 0; j < NA; ++j) {
-                            // q += f * w_i, NaN frequencies contribute 0 (sync.rs:258-271)
-                            q[j] = (c[j] != 0u && rs != 0.0 && keep[j]) ? q[j] + f[j] * wi : q[j];
-                            anynz[j] = anynz[j] || (c[j] != 0u);
-                        }
-                    }
-                const bool rowok = rs != 0.0;
-#pragma unroll
-                for (int j = 0; j < NA; ++j) cs[j] = rowok ? cs[j] + f[j] : cs[j];
-                if (OP == OP_OLS) {
-#pragma unroll
-                    for (int a = 0; a < NA; ++a)
-#pragma unroll
-                        for (int b = a; b < NA; ++b) xx[tri(a, b)] = xx[tri(a, b)] + f[a] * f[b];
-#pragma unroll
-                    for (int tt = 0; tt < MAXK; ++tt) {
-                        if (tt < k) {
-                            const double y = Y[(size_t)(pool0 + i) * k + tt];
-#pragma unroll
-                            for (int j = 0; j < NA; ++j) xy[j * MAXK + tt] = xy[j * MAXK + tt] + f[j] * y;
-                        }
-                    }
-                } else if (OP == OP_PEARSON) {
-                    if (rowok && !shset) {
-#pragma unroll
-                        for (int j = 0; j < NA; ++j) shx[j] = f[j];
-                        shset = true;
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < MAXK; ++tt) {
-                        if (tt < k) {
-                            const double y = Y[(size_t)(pool0 + i) * k + tt]; // shifted by its first valid value on the host
-                            const bool ok = rowok && !isnan(y);              // pairwise complete (correlation_test.rs:22-26)
-                            py[tt] = ok ? py[tt] + y : py[tt];
-                            pyy[tt] = ok ? fma(y, y, pyy[tt]) : pyy[tt];
-                            pn[tt] = ok ? pn[tt] + 1.0 : pn[tt];
-#pragma unroll
-                            for (int j = 0; j < NA; ++j) {
-                                const double x = f[j] - shx[j];
-                                const int e = j * MAXK + tt;
-                                px[e] = ok ? px[e] + x : px[e];
-                                pxx[e] = ok ? fma(x, x, pxx[e]) : pxx[e];
-                                xy[e] = ok ? fma(x, y, xy[e]) : xy[e];
-                            }
-                        }
-                    }
-                } else { // OP_CHISQ: chi2 = total * (sum_j A_j / cs_j - 1), A_j = sum_i f_ij^2 / rs_i
-                    double rsum = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) rsum = keep[j] ? rsum + f[j] : rsum; // row sum of frequencies (~1)
-                    total = total + rsum;
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) xx[tri(j, j)] = xx[tri(j, j)] + (f[j] * f[j]) / rsum;
-                }
-                }
-                __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < NJ; ++j) { e0[j] = c0[aj(j)]; e1[j] = c1[aj(j)]; }
+                pool(e0, pool0 + i);
+                pool(e1, pool0 + i + 1);
             }
-            if (!first) break;
+        } else {
+            const int np = n - pool0;
+#pragma unroll 1
+            for (int i = 0; i < np; ++i) {
+                const uint2_t a = *reinterpret_cast<const uint2_t *>(row + i * 24);
+                const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
+                const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
+                const uint32_t c0[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
+                uint32_t e0[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) e0[j] = c0[aj(j)];
+                pool(e0, pool0 + i);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (st == nst - 1) {
+            // filter decisions (sync.rs:223-300) and the record of this locus
+            const int64_t l = t * 64 + lane;
+            int mask = 0, nk = 0;
             bool dropped_with_reads = false;
-            nk = 0;
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                const bool cand = keep[j];
-                keep[j] = cand && !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
-                nk += keep[j] ? 1 : 0;
-                dropped_with_reads = dropped_with_reads || (cand && !keep[j] && anynz[j]);
+            for (int j = 0; j < NJ; ++j) {
+                const bool kp = !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
+                nk += kp ? 1 : 0;
+                mask |= kp ? (2 << aj(j)) : 0;
+                dropped_with_reads = dropped_with_reads || (!kp && orc[j] != 0u);
             }
-            alive = !(mincov < P.min_cov);                                             // sync.rs:227
+            bool alive = !(mincov < P.min_cov);                                        // sync.rs:227
             alive = alive && nk >= 2;                                                  // sync.rs:284
             alive = alive && n_missing != n;                                           // sync.rs:293
             alive = alive && !(((double)n_missing / (double)n) > P.max_miss);          // sync.rs:297
-            alive = alive && l < P.L;
-            if (!__any(alive && dropped_with_reads)) break; // wave-uniform: the speculative sums stand
+            alive = alive && l < L;
+            const bool again = alive && dropped_with_reads;
+            if (l < L) {
+                rec_flags[l] = mask | (alive ? FLAG_ALIVE : 0) | (again ? FLAG_SECOND : 0);
+                store_record<OP, NJ, K>(A, rec, L, l, aj);
+            }
+            const unsigned long long bal = __ballot(again);
+            if (bal) { // wave-uniform
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(second_count, (unsigned long long)__popcll(bal));
+                base = __shfl(base, 0);
+                if (again) second[base + __popcll(bal & ((1ull << lane) - 1ull))] = l;
+            }
         }
+        t = nt;
+        st = ns;
+    }
+}
 
-        if (l >= P.L) continue;
-        // The sums go to a per-locus record (struct-of-arrays, coalesced stores); k_locus_close<OP>
-        // finishes the statistic.  Keeping the transcendental / LU code out of this kernel keeps its
-        // register count -- and so the number of waves that hide the HBM latency -- small.
-        {
-            int mask = alive ? 1 : 0;
+// ---- second pass: only the loci the first pass listed ----------------------------------------------
+// One lane per listed locus (rows gathered through the list), sums over the SURVIVING alleles only.
+template <int OP, int PB, int K>
+__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
+    const uint32_t *__restrict__ counts, const double *__restrict__ Y, const int32_t *__restrict__ rec_flags,
+    double *__restrict__ rec, const int64_t *__restrict__ second,
+    const unsigned long long *__restrict__ second_count, const LocusParams P) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    char *tile = lds_raw + wave * LO_TILEB;
+    int64_t *lidx = reinterpret_cast<int64_t *>(lds_raw + LO_WAVES * LO_TILEB) + wave * 64;
+    const char *row = tile + lane * LO_PITCH;
+    const int n = P.n;
+    const int nfull = n / LO_CHP;
+    const int nst = (n + LO_CHP - 1) / LO_CHP;
+    const int64_t cnt = (int64_t)*second_count;
+    const int64_t ntiles = (cnt + 63) / 64;
+    const int64_t wstride = (int64_t)gridDim.x * LO_WAVES;
+    auto aj = [](int jj) { return jj; };
+    StageRegs S;
+    Sums<OP, NA, K> A;
+    for (int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave; t < ntiles; t += wstride) {
+        const int64_t e = t * 64 + lane;
+        const int64_t l = second[e < cnt ? e : cnt - 1];
+        lidx[lane] = l;
+        __builtin_amdgcn_wave_barrier();
+        const int mask = rec_flags[l];
+        bool keep[NA];
 #pragma unroll
-            for (int j = 0; j < NA; ++j) mask |= keep[j] ? (2 << j) : 0;
-            rec_flags[l] = mask;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) rec[(size_t)(R_CS + j) * P.L + l] = cs[j];
-            if (OP == OP_OLS || OP == OP_CHISQ) {
-#pragma unroll
-                for (int j = 0; j < 21; ++j)
-                    if (OP == OP_OLS || j == tri(0, 0) || j == tri(1, 1) || j == tri(2, 2) || j == tri(3, 3) ||
-                        j == tri(4, 4) || j == tri(5, 5))
-                        rec[(size_t)(R_XX + j) * P.L + l] = xx[j];
+        for (int j = 0; j < NA; ++j) keep[j] = (mask & (2 << j)) != 0;
+        auto rowsel = [&](int r) { return lidx[r]; };
+        A.clear();
+        for (int st = 0; st < nst; ++st) {
+            const int pool0 = st * LO_CHP;
+            const int np = st < nfull ? LO_CHP : n - pool0;
+            if (st < nfull) {
+                stage_load<PB, false>(S, counts, n, pool0, np, lane, rowsel);
+                stage_store<PB, false>(S, tile, np, lane);
+            } else {
+                stage_load<8, true>(S, counts, n, pool0, np, lane, rowsel);
+                stage_store<8, true>(S, tile, np, lane);
             }
-            if (OP == OP_OLS || OP == OP_PEARSON) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int i = 0; i < np; ++i) {
+                const uint2_t a = *reinterpret_cast<const uint2_t *>(row + i * 24);
+                const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
+                const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
+                const uint32_t c[NA] = {a.x, a.y, b.x, b.y, d.x, d.y};
+                double cd[NA], f[NA], f0[NA];
+                double rs = 0.0; // row sum over the surviving alleles (second to_frequencies, sync.rs:170-175)
 #pragma unroll
-                for (int j = 0; j < NA * MAXK; ++j) rec[(size_t)(R_XY + j) * P.L + l] = xy[j];
-            }
-            if (OP == OP_PEARSON) {
+                for (int j = 0; j < NA; ++j) { cd[j] = keep[j] ? (double)c[j] : 0.0; rs = keep[j] ? rs + cd[j] : rs; }
+                const double rinv = recip_for_div(rs);
+                const bool rowok = rs != 0.0;
 #pragma unroll
-                for (int j = 0; j < NA * MAXK; ++j) {
-                    rec[(size_t)(R_PX + j) * P.L + l] = px[j];
-                    rec[(size_t)(R_PXX + j) * P.L + l] = pxx[j];
+                for (int j = 0; j < NA; ++j) {
+                    f[j] = keep[j] ? div_by(cd[j], rs, rinv) : 0.0;
+                    f0[j] = rowok ? f[j] : 0.0;
                 }
-#pragma unroll
-                for (int j = 0; j < MAXK; ++j) {
-                    rec[(size_t)(R_PY + j) * P.L + l] = py[j];
-                    rec[(size_t)(R_PYY + j) * P.L + l] = pyy[j];
-                    rec[(size_t)(R_PN + j) * P.L + l] = pn[j];
-                }
+                A.add_pool(f, f0, rowok, Y + (size_t)(pool0 + i) * K);
             }
-            if (OP == OP_CHISQ) rec[(size_t)R_TOTAL * P.L + l] = total;
+            __builtin_amdgcn_wave_barrier();
         }
+        if (e < cnt) store_record<OP, NA, K>(A, rec, P.L, l, aj);
     }
 }
 
@@ -712,14 +865,17 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     std::vector<double> tc = pg_tdist_coef(df < 1 ? 1 : df);
     const size_t side = ((size_t)n + (size_t)n * MAXK + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
     const size_t recd = (size_t)L * REC_DOUBLES;
-    const size_t need = sizeof(double) * (side + recd) + sizeof(int32_t) * (size_t)L;
+    // workspace: [w | Y | tcoef] [records] [second-pass list: L x i64] [its length: u64] [flags: L x i32]
+    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 8 + sizeof(int32_t) * (size_t)L;
     int rc = pg_ws_reserve(ctx, need);
     if (rc) return rc;
     double *wd = static_cast<double *>(ctx->ws);
     double *Ydev = wd + n;
     double *tcd = Ydev + (size_t)n * MAXK;
     double *recp = wd + side;
-    int32_t *recf = reinterpret_cast<int32_t *>(recp + recd);
+    int64_t *second = reinterpret_cast<int64_t *>(recp + recd);
+    unsigned long long *second_count = reinterpret_cast<unsigned long long *>(second + L);
+    int32_t *recf = reinterpret_cast<int32_t *>(second_count + 1);
     PG_HIP(ctx, hipMemcpyAsync(wd, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (!tc.empty())
         PG_HIP(ctx, hipMemcpyAsync(tcd, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -729,11 +885,24 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     const int64_t cap = (int64_t)cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
     const size_t shmem = (size_t)LO_WAVES * LO_TILEB;
+    const size_t shmem2 = shmem + (size_t)LO_WAVES * 64 * sizeof(int64_t);
     const bool p16 = ((int64_t)n * 24) % 16 == 0;
-    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_locus_ops<OP, 16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_locus_ops<OP, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const bool rns = flt->remove_ns != 0;
+    auto pick_first = [&](int kg) -> const void * {
+        auto sel = [&](auto kc) -> const void * {
+            constexpr int KC = decltype(kc)::value;
+            return p16 ? (rns ? (const void *)k_locus_first<OP, 16, true, KC> : (const void *)k_locus_first<OP, 16, false, KC>)
+                       : (rns ? (const void *)k_locus_first<OP, 8, true, KC> : (const void *)k_locus_first<OP, 8, false, KC>);
+        };
+        if (OP == OP_CHISQ || kg == 1) return sel(std::integral_constant<int, 1>{});
+        return sel(std::integral_constant<int, (OP == OP_CHISQ ? 1 : 2)>{});
+    };
+    auto pick_second = [&](int kg) -> const void * {
+        if (OP == OP_CHISQ || kg == 1)
+            return p16 ? (const void *)k_locus_second<OP, 16, 1> : (const void *)k_locus_second<OP, 8, 1>;
+        return p16 ? (const void *)k_locus_second<OP, 16, (OP == OP_CHISQ ? 1 : 2)>
+                   : (const void *)k_locus_second<OP, 8, (OP == OP_CHISQ ? 1 : 2)>;
+    };
 
     std::vector<double> Yd((size_t)n * MAXK);
     for (int t0 = 0; t0 < k; t0 += MAXK) { // the filter passes are recomputed per trait pair
@@ -772,13 +941,22 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
             }
         }
         PG_HIP(ctx, hipMemcpyAsync(Ydev, Yd.data(), sizeof(double) * n * MAXK, hipMemcpyHostToDevice, ctx->stream));
+        const void *kfirst = pick_first(kg), *ksecond = pick_second(kg);
+        PG_HIP(ctx, hipFuncSetAttribute(kfirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PG_HIP(ctx, hipFuncSetAttribute(ksecond, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+        PG_HIP(ctx, hipMemsetAsync(second_count, 0, 8, ctx->stream));
         pg_prof_begin(ctx, kid);
-        if (p16)
-            hipLaunchKernelGGL((k_locus_ops<OP, 16>), dim3(grid), dim3(LO_THREADS), shmem, ctx->stream, counts_dev,
-                               wd, Ydev, tcd, n_out, ids, mf, stat, pv, recf, recp, P);
-        else
-            hipLaunchKernelGGL((k_locus_ops<OP, 8>), dim3(grid), dim3(LO_THREADS), shmem, ctx->stream, counts_dev,
-                               wd, Ydev, tcd, n_out, ids, mf, stat, pv, recf, recp, P);
+        {
+            const uint32_t *a0 = counts_dev;
+            const double *a1 = wd, *a2 = Ydev;
+            void *args1[] = {&a0, &a1, &a2, &recf, &recp, &second, &second_count, &P};
+            PG_HIP(ctx, hipLaunchKernel(kfirst, dim3(grid), dim3(LO_THREADS), args1, shmem, ctx->stream));
+            const int32_t *b0 = recf;
+            const int64_t *b1 = second;
+            const unsigned long long *b2 = second_count;
+            void *args2[] = {&a0, &a2, &b0, &recp, &b1, &b2, &P};
+            PG_HIP(ctx, hipLaunchKernel(ksecond, dim3(grid), dim3(LO_THREADS), args2, shmem2, ctx->stream));
+        }
         hipLaunchKernelGGL(k_locus_close<OP>, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, ctx->stream, recf, recp, tcd,
                            n_out, ids, mf, stat, pv, P);
         pg_prof_end(ctx);
