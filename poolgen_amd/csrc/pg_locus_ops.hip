@@ -23,6 +23,14 @@
 
 namespace {
 
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 constexpr int LO_THREADS = 256;
 constexpr int LO_WAVES = 4;
 constexpr int LO_CHP = 8;                 // pools per stage
@@ -39,6 +47,7 @@ struct LocusParams {
     int n, k;        // k = traits handled by this launch (<= MAXK)
     int k_total, t0; // output layout: trait t0 + tt of k_total
     int remove_ns;
+    int pshift;      // log2(period), see k_locus_first / unit_slot
     double min_cov, maf, max_miss;
     int tdf, ntcoef;     // t-test degrees of freedom (OLS: n-1, Pearson: n-2)
     double syy[MAXK];    // OLS: sum of centred y^2
@@ -154,6 +163,18 @@ __device__ __forceinline__ constexpr int tri(int a, int b) { // a <= b
 constexpr int R_CS = 0, R_XX = R_CS + NA, R_XY = R_XX + 21, R_PX = R_XY + NA * MAXK, R_PXX = R_PX + NA * MAXK,
               R_PY = R_PXX + NA * MAXK, R_PYY = R_PY + MAXK, R_PN = R_PYY + MAXK, R_TOTAL = R_PN + MAXK,
               REC_DOUBLES = R_TOTAL + 1;
+// Records and flags are stored UNIT-MAJOR: the 64 loci a wave of k_locus_first works on (one alignment
+// class of a group of 64 * period rows, see there) are adjacent, field f of slot s at
+// rec[(s / 64) * REC_DOUBLES * 64 + f * 64 + s % 64], so that a wave's stores are whole 512-byte runs.
+__device__ __forceinline__ int64_t unit_slot(int64_t l, int pshift) {
+    const int64_t g = l >> (6 + pshift);
+    const int within = (int)(l - (g << (6 + pshift)));
+    const int c = within & ((1 << pshift) - 1);
+    return (((g << pshift) + c) << 6) + (within >> pshift);
+}
+__device__ __forceinline__ size_t rec_base(int64_t slot) {
+    return (size_t)(slot >> 6) * (size_t)(REC_DOUBLES * 64) + (size_t)(slot & 63);
+}
 constexpr int FLAG_ALIVE = 1, FLAG_SECOND = 1 << 7; // bits 1..6: surviving alleles
 
 // The operator's running sums of one locus over the alleles "in play" (NJ of them; allele id of slot
@@ -179,11 +200,12 @@ struct Sums {
         shset = false;
     }
     static __device__ __forceinline__ constexpr int trin(int a, int b) { return a * NJ - a * (a - 1) / 2 + (b - a); }
-    // f: frequencies of this pool (NaN when the pool is uncovered), f0: the same with NaN -> 0
-    __device__ __forceinline__ void add_pool(const double (&f)[NJ], const double (&f0)[NJ], bool rowok,
-                                             const double *__restrict__ Yrow) {
+    // f: frequencies of this pool, all 0 when the pool is uncovered (rowok false).  The reference has NaN
+    // there: its NaN-ignoring sums (cs, the Pearson sums) skip the pool, which adding 0 / `ok` does
+    // too; its plain sums (OLS, chi-square) become NaN, which store_record does from `poisoned`.
+    __device__ __forceinline__ void add_pool(const double (&f)[NJ], bool rowok, const double *__restrict__ Yrow) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) cs[j] = cs[j] + f0[j];
+        for (int j = 0; j < NJ; ++j) cs[j] = cs[j] + f[j];
         if (OP == OP_OLS) {
 #pragma unroll
             for (int a = 0; a < NJ; ++a)
@@ -224,49 +246,52 @@ struct Sums {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) rsum = rsum + f[j]; // row sum of the frequencies (~1)
             total = total + rsum;
-            const double ri = recip_for_div(rsum);
+            const double rsd = rowok ? rsum : 1.0;
+            const double ri = recip_for_div(rsd);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) xx[j] = xx[j] + div_by(f[j] * f[j], rsum, ri);
+            for (int j = 0; j < NJ; ++j) xx[j] = xx[j] + div_by(f[j] * f[j], rsd, ri);
         }
     }
 };
 
 // write the sums of one locus to its record; AJ(jj) = allele id of slot jj
 template <int OP, int NJ, int K, typename AJ>
-__device__ __forceinline__ void store_record(const Sums<OP, NJ, K> &S, double *__restrict__ rec, int64_t L, int64_t l,
-                                             AJ aj) {
+__device__ __forceinline__ void store_record(const Sums<OP, NJ, K> &S, bool poisoned, double *__restrict__ rec,
+                                             size_t rb, AJ aj) {
+    const double pz = poisoned ? NAN : 0.0; // x + NaN = NaN: an uncovered pool makes the plain sums NaN
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) rec[(size_t)(R_CS + aj(j)) * L + l] = S.cs[j];
+    for (int j = 0; j < NJ; ++j) rec[rb + (size_t)(R_CS + aj(j)) * 64] = S.cs[j];
     if (OP == OP_OLS) {
 #pragma unroll
         for (int a = 0; a < NJ; ++a)
 #pragma unroll
-            for (int b = a; b < NJ; ++b) rec[(size_t)(R_XX + tri(aj(a), aj(b))) * L + l] = S.xx[S.trin(a, b)];
+            for (int b = a; b < NJ; ++b) rec[rb + (size_t)(R_XX + tri(aj(a), aj(b))) * 64] = S.xx[S.trin(a, b)] + pz;
     }
     if (OP == OP_CHISQ) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) rec[(size_t)(R_XX + tri(aj(j), aj(j))) * L + l] = S.xx[j];
-        rec[(size_t)R_TOTAL * L + l] = S.total;
+        for (int j = 0; j < NJ; ++j) rec[rb + (size_t)(R_XX + tri(aj(j), aj(j))) * 64] = S.xx[j] + pz;
+        rec[rb + (size_t)(R_TOTAL) * 64] = S.total + pz;
     }
     if (OP == OP_OLS || OP == OP_PEARSON) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int tt = 0; tt < K; ++tt) rec[(size_t)(R_XY + aj(j) * MAXK + tt) * L + l] = S.xy[j * K + tt];
+            for (int tt = 0; tt < K; ++tt)
+                rec[rb + (size_t)(R_XY + aj(j) * MAXK + tt) * 64] = S.xy[j * K + tt] + ((OP == OP_OLS) ? pz : 0.0);
     }
     if (OP == OP_PEARSON) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int tt = 0; tt < K; ++tt) {
-                rec[(size_t)(R_PX + aj(j) * MAXK + tt) * L + l] = S.px[j * K + tt];
-                rec[(size_t)(R_PXX + aj(j) * MAXK + tt) * L + l] = S.pxx[j * K + tt];
+                rec[rb + (size_t)(R_PX + aj(j) * MAXK + tt) * 64] = S.px[j * K + tt];
+                rec[rb + (size_t)(R_PXX + aj(j) * MAXK + tt) * 64] = S.pxx[j * K + tt];
             }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            rec[(size_t)(R_PY + j) * L + l] = S.py[j];
-            rec[(size_t)(R_PYY + j) * L + l] = S.pyy[j];
-            rec[(size_t)(R_PN + j) * L + l] = S.pn[j];
+            rec[rb + (size_t)(R_PY + j) * 64] = S.py[j];
+            rec[rb + (size_t)(R_PYY + j) * 64] = S.pyy[j];
+            rec[rb + (size_t)(R_PN + j) * 64] = S.pn[j];
         }
     }
 }
@@ -279,114 +304,194 @@ __device__ __forceinline__ void store_record(const Sums<OP, NJ, K> &S, double *_
 // sequencing-error allele below the MAF) the locus is appended to `second` and k_locus_second redoes
 // its sums over the surviving alleles, as the reference's second to_frequencies does.
 // RNS = "remove Ns" (the CLI default, main.rs:203): column 4 is not in play at all.
-template <int OP, int PB, bool RNS, int K>
+//
+// Memory access: HBM is read in whole, aligned 128-byte lines, each exactly once per row.  A row is
+// 24n bytes, so rows start at different offsets inside a line; the rows whose start offset is the same
+// are `period` apart (period = 128 / gcd(24n, 128), 1..16).  A wave therefore works on a UNIT of 64
+// rows of one alignment class (rows r0, r0 + period, ...): every lane streams its row line by line,
+// all lanes see the same pools complete at the same stage, so the pool loop and the w / Y operands
+// stay wave-uniform.  Stage s = line s of each of the 64 rows: 8 x (8 rows x 128 B) buffer loads per
+// lane-group into a 2-line ring per row in LDS (pitch 272 B = 17 x 16: conflict-free row-wise reads);
+// a pool that straddles two lines is read across the ring.  The descriptor covers the unit's lines
+// only (a line that holds a valid byte lies in the same page as that byte, so whole-line reads are
+// safe at both ends of the batch), out-of-range lines come back as zeros, and the (unit, stage) pairs
+// of a wave form ONE flat sequence whose next loads are in flight while the current stage computes.
+constexpr int LN_PITCH = 272;
+constexpr int LN_TILEB = 64 * LN_PITCH;
+#ifndef LN_DEPTH_DEF
+#define LN_DEPTH_DEF 3
+#endif
+constexpr int LN_DEPTH = LN_DEPTH_DEF;
+
+template <int OP, bool RNS, int K>
 __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
     const uint32_t *__restrict__ counts, const double *__restrict__ w, const double *__restrict__ Y,
-    int32_t *__restrict__ rec_flags, double *__restrict__ rec, int64_t *__restrict__ second,
-    unsigned long long *__restrict__ second_count, const LocusParams P) {
+    int32_t *__restrict__ rec_flags, double *__restrict__ rec, unsigned long long *__restrict__ unit_again,
+    const LocusParams P, const int period) {
     constexpr int NJ = RNS ? 5 : 6;
     auto aj = [](int jj) { return (RNS && jj >= 4) ? jj + 1 : jj; };
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    char *tile = lds_raw + wave * LO_TILEB;
-    const char *row = tile + lane * LO_PITCH;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *tile = lds_raw + wave * LN_TILEB;
+    const char *rowp = tile + lane * LN_PITCH; // this lane's 2-line ring
     const int n = P.n;
-    const int nfull = n / LO_CHP;
-    const int nst = (n + LO_CHP - 1) / LO_CHP;
-    const int64_t ntiles = (P.L + 63) / 64;
-    const int64_t wstride = (int64_t)gridDim.x * LO_WAVES;
     const int64_t L = P.L;
+    const uint32_t rowb = (uint32_t)n * 24u;
+    const int pshift = __builtin_ctz(period);              // period is a power of two
+    const uint32_t pstride = (uint32_t)period * rowb;      // bytes between consecutive rows of a unit
+    // units: group g = 64 * period consecutive rows, class c = row offset inside the period.  A block
+    // owns chunks of max(4, period) consecutive units (whole groups: the record stores of a group's
+    // classes interleave, so they should meet in one L2) and its 4 waves take them round-robin.
+    const int64_t ngroups = (L + 64 * (int64_t)period - 1) >> (6 + pshift);
+    const int64_t nunits = ngroups * period;
+    const int cu = period > LO_WAVES ? period : LO_WAVES;   // units per chunk
+    const int64_t nchunks = (nunits + cu - 1) / cu;
 
-    StageRegs S;
+    // staging assignment: lane -> (row g8 of 8, 16-byte piece of the line)
+    const int g8 = lane >> 3, piece = lane & 7;
+    const uint32_t vbase = (uint32_t)g8 * pstride + (uint32_t)piece * 16u;
+    char *tstore = tile + g8 * LN_PITCH + piece * 16;
+
+    uint4_t S[LN_DEPTH][8]; // LN_DEPTH stages of loads in flight per lane
     Sums<OP, NJ, K> A;
     double q[NJ];
     uint32_t orc[NJ];
     double mincov = 0.0;
     int n_missing = 0;
 
-    auto issue = [&](int64_t t, int st) {
-        const int64_t l0 = t * 64;
-        auto rowsel = [&](int r) { const int64_t l = l0 + r; return l < L ? l : L - 1; };
-        const int pool0 = st * LO_CHP;
-        if (st < nfull) stage_load<PB, false>(S, counts, n, pool0, LO_CHP, lane, rowsel);
-        else stage_load<8, true>(S, counts, n, pool0, n - pool0, lane, rowsel);
+    // a unit's descriptor: first row, start offset inside its line, lines per row, buffer resource.
+    // Everything in it is wave-uniform by construction (readfirstlane says so to the compiler, or
+    // every load would be wrapped in a waterfall loop).
+    struct Unit { int64_t r0; uint32_t delta; int nlines; uint32_t base_lo, base_hi; int nrec; };
+    auto make_unit = [&](int64_t u) {
+        Unit d;
+        const int64_t g = u >> pshift;
+        d.r0 = (g << (6 + pshift)) + (u - (g << pshift));
+        const uint64_t addr0 = reinterpret_cast<uint64_t>(counts) + (uint64_t)d.r0 * rowb;
+        d.delta = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)addr0 & 127u));
+        d.nlines = (int)((d.delta + rowb + 127u) >> 7);
+        int64_t rows = d.r0 < L ? (L - d.r0 + period - 1) >> pshift : 0;
+        rows = rows < 64 ? rows : 64;
+        const uint32_t span = rows > 0 ? ((d.delta + (uint32_t)(rows - 1) * pstride + rowb + 127u) & ~127u) : 0u;
+        const uint64_t basev = addr0 & ~(uint64_t)127;
+        d.base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)basev);
+        d.base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(basev >> 32));
+        d.nrec = __builtin_amdgcn_readfirstlane((int)span);
+        return d;
+    };
+    auto issue = [&](auto kc, const Unit &d, int s) {
+        constexpr int k = decltype(kc)::value;
+        const uint64_t base = ((uint64_t)d.base_hi << 32) | d.base_lo;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(base), 0, d.nrec, 0x00020000);
+        const uint32_t v0 = vbase + (uint32_t)s * 128u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) // the whole offset goes through the VGPR: the scalar offset is not range-checked on gfx9
+            S[k][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (uint32_t)j * 8u * pstride, 0, 0);
+    };
+    auto land = [&](auto kc, int s) {
+        constexpr int k = decltype(kc)::value;
+        char *p = tstore + (s & 1) * 128;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4_t *>(p + j * (8 * LN_PITCH)) = S[k][j];
     };
     // one pool of this lane's locus
     auto pool = [&](const uint32_t (&c)[NJ], int pi) {
-        double cd[NJ], f[NJ], f0[NJ];
+        double cd[NJ], f[NJ];
         double rs = 0.0; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { cd[j] = (double)c[j]; rs = rs + cd[j]; }
-        const double rinv = recip_for_div(rs);
+        for (int j = 0; j < NJ; ++j) { cd[j] = (double)c[j]; rs = rs + cd[j]; orc[j] |= c[j]; }
         const bool rowok = rs != 0.0;
+        // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0,
+        // divided by 1) and the pool is counted in n_missing, which poisons / skips what NaN would
+        const double rsd = rowok ? rs : 1.0;
+        const double rinv = recip_for_div(rsd);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            f[j] = div_by(cd[j], rs, rinv);
-            f0[j] = rowok ? f[j] : 0.0;
-            orc[j] |= c[j];
-        }
+        for (int j = 0; j < NJ; ++j) f[j] = div_by(cd[j], rsd, rinv);
         mincov = (pi == 0 || rs < mincov) ? rs : mincov;   // sync.rs:223-227
         n_missing += rowok ? 0 : 1;
         const double wi = w[pi];
         // q += f * w_i with separate multiply and add; NaN frequencies contribute 0 (sync.rs:258-271)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) q[j] = q[j] + f0[j] * wi;
-        A.add_pool(f, f0, rowok, Y + (size_t)pi * K);
+        for (int j = 0; j < NJ; ++j) q[j] = q[j] + f[j] * wi;
+        A.add_pool(f, rowok, Y + (size_t)pi * K);
+    };
+    auto read_pool = [&](uint32_t ring_off, uint32_t (&e)[NJ]) {
+        // 24 bytes at ring offset ring_off (a multiple of 8), possibly wrapping around the 256-byte ring
+        const uint2_t a = *reinterpret_cast<const uint2_t *>(rowp + (ring_off & 255u));
+        const uint2_t b = *reinterpret_cast<const uint2_t *>(rowp + ((ring_off + 8u) & 255u));
+        const uint2_t d = *reinterpret_cast<const uint2_t *>(rowp + ((ring_off + 16u) & 255u));
+        const uint32_t c0[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) e[j] = c0[aj(j)];
     };
 
-    int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave;
-    int st = 0;
-    if (t < ntiles) issue(t, 0);
-    while (t < ntiles) {
-        const bool cur_full = st < nfull;
-        const int pool0 = st * LO_CHP;
-        if (cur_full) stage_store<PB, false>(S, tile, LO_CHP, lane);
-        else stage_store<8, true>(S, tile, n - pool0, lane);
+    // flat (unit, stage) sequence of this wave: chunk -> unit inside the chunk -> stage.  Two cursors
+    // walk it: `pre` issues loads LN_DEPTH items ahead of `cur`, which lands and computes them.
+    struct Cursor { int64_t chunk; int q; int s; bool valid; Unit D; };
+    auto unit_of = [&](int64_t ch, int q_) { return ch * cu + q_; };
+    auto advance = [&](Cursor &c) {
+        if (++c.s < c.D.nlines) return;
+        c.s = 0;
+        c.q += LO_WAVES;
+        if (c.q >= cu || unit_of(c.chunk, c.q) >= nunits) { c.q = wave; c.chunk += gridDim.x; }
+        const int64_t u = unit_of(c.chunk, c.q);
+        c.valid = c.chunk < nchunks && u < nunits;
+        if (c.valid) c.D = make_unit(u);
+    };
+    Cursor cur;
+    cur.chunk = blockIdx.x; cur.q = wave; cur.s = 0;
+    // (wave < cu always; a missing unit here means none later either)
+    if (cur.chunk >= nchunks || unit_of(cur.chunk, cur.q) >= nunits) return;
+    cur.valid = true;
+    cur.D = make_unit(unit_of(cur.chunk, cur.q));
+    Cursor pre = cur;
+    Unit lastD = cur.D; // what a dummy load re-reads once `pre` has run off the end
+    int lasts = 0;
+    int done = 0;       // pools of the current unit already processed
+
+    auto prefetch = [&](auto kc) {
+        if (pre.valid) { lastD = pre.D; lasts = pre.s; advance(pre); }
+        issue(kc, lastD, lasts);
+    };
+    auto step = [&](auto kc) {
+        const int s = cur.s;
+        const uint32_t delta = cur.D.delta;
+        const int nlines = cur.D.nlines;
+        const int64_t r0 = cur.D.r0;
         __builtin_amdgcn_wave_barrier();
-        int64_t nt = t;
-        int ns = st + 1;
-        if (ns == nst) { ns = 0; nt = t + wstride; }
-        if (nt < ntiles) issue(nt, ns); // in flight while this stage is computed
-        if (st == 0) {
+#ifndef LN_EXP_NOLOAD
+        land(kc, s);
+        __builtin_amdgcn_wave_barrier();
+        prefetch(kc); // in flight while this and the next LN_DEPTH - 1 stages are computed
+#else
+        if (pre.valid) { lastD = pre.D; lasts = pre.s; advance(pre); }
+#endif
+        if (s == 0) {
             A.clear();
 #pragma unroll
             for (int j = 0; j < NJ; ++j) { q[j] = 0.0; orc[j] = 0u; }
             mincov = 0.0;
             n_missing = 0;
+            done = 0;
         }
-        if (cur_full) {
-#pragma unroll 1
-            for (int i = 0; i < LO_CHP; i += 2) { // two pools = 48 bytes = three 16-byte reads
-                const uint4_t a = *reinterpret_cast<const uint4_t *>(row + i * 24);
-                const uint4_t b = *reinterpret_cast<const uint4_t *>(row + i * 24 + 16);
-                const uint4_t d = *reinterpret_cast<const uint4_t *>(row + i * 24 + 32);
-                const uint32_t c0[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
-                const uint32_t c1[6] = {b.z, b.w, d.x, d.y, d.z, d.w};
-                uint32_t e0[NJ], e1[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) { e0[j] = c0[aj(j)]; e1[j] = c1[aj(j)]; }
-                pool(e0, pool0 + i);
-                pool(e1, pool0 + i + 1);
-            }
-        } else {
-            const int np = n - pool0;
-#pragma unroll 1
-            for (int i = 0; i < np; ++i) {
-                const uint2_t a = *reinterpret_cast<const uint2_t *>(row + i * 24);
-                const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
-                const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
-                const uint32_t c0[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
-                uint32_t e0[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) e0[j] = c0[aj(j)];
-                pool(e0, pool0 + i);
-            }
+        int hi = (int)((128u * (uint32_t)(s + 1) - delta) / 24u); // pools complete once line s has landed
+        hi = hi < n ? hi : n;
+#ifndef LN_EXP_NOCOMPUTE
+#pragma unroll 2
+        for (int i = done; i < hi; ++i) {
+            uint32_t e[NJ];
+            read_pool(delta + 24u * (uint32_t)i, e);
+            pool(e, i);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (st == nst - 1) {
+#else
+        if (hi == 12345) { uint32_t e[NJ]; read_pool(delta, e); pool(e, 0); }
+#endif
+        done = hi;
+        if (s == nlines - 1) {
             // filter decisions (sync.rs:223-300) and the record of this locus
-            const int64_t l = t * 64 + lane;
+            const int64_t l = r0 + (int64_t)lane * period;
             int mask = 0, nk = 0;
             bool dropped_with_reads = false;
 #pragma unroll
@@ -402,20 +507,74 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
             alive = alive && !(((double)n_missing / (double)n) > P.max_miss);          // sync.rs:297
             alive = alive && l < L;
             const bool again = alive && dropped_with_reads;
+#ifdef LN_EXP_NOSTORE
+            if (l < L && mask == 12345) {
+#else
             if (l < L) {
-                rec_flags[l] = mask | (alive ? FLAG_ALIVE : 0) | (again ? FLAG_SECOND : 0);
-                store_record<OP, NJ, K>(A, rec, L, l, aj);
+#endif
+                const int64_t slot = unit_of(cur.chunk, cur.q) * 64 + lane;
+                rec_flags[slot] = mask | (alive ? FLAG_ALIVE : 0) | (again ? FLAG_SECOND : 0);
+#ifdef LN_EXP_SMALLREC
+                store_record<OP, NJ, K>(A, n_missing > 0, rec, rec_base(slot) & 0xFFFFu, aj);
+#else
+                store_record<OP, NJ, K>(A, n_missing > 0, rec, rec_base(slot), aj);
+#endif
             }
+            // which lanes of this unit need the second pass: one 64-bit mask per unit, expanded into the
+            // dense list by k_locus_compact (no returning atomic here: its wait would drain the loads in flight)
             const unsigned long long bal = __ballot(again);
-            if (bal) { // wave-uniform
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(second_count, (unsigned long long)__popcll(bal));
-                base = __shfl(base, 0);
-                if (again) second[base + __popcll(bal & ((1ull << lane) - 1ull))] = l;
-            }
+            if (lane == 0) unit_again[unit_of(cur.chunk, cur.q)] = bal;
         }
-        t = nt;
-        st = ns;
+        advance(cur);
+    };
+
+    static_for<0, LN_DEPTH>([&](auto kc) { prefetch(kc); });
+    for (;;) {
+        bool stop = false;
+        static_for<0, LN_DEPTH>([&](auto kc) {
+            if (!stop) {
+                step(kc);
+                stop = !cur.valid;
+            }
+        });
+        if (stop) break;
+    }
+}
+
+// ---- expand the per-unit "again" masks into the dense list of loci for the second pass ---------------
+__global__ __launch_bounds__(256) void k_locus_compact(const unsigned long long *__restrict__ unit_again,
+                                                       int64_t nunits, int period, int64_t *__restrict__ second,
+                                                       unsigned long long *__restrict__ second_count) {
+    __shared__ int part[256];
+    __shared__ unsigned long long base_s;
+    const int tid = threadIdx.x;
+    const int64_t u = (int64_t)blockIdx.x * 256 + tid;
+    const unsigned long long m = u < nunits ? unit_again[u] : 0ull;
+    const int c = __popcll(m);
+    part[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) { // inclusive scan
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int total = part[255];
+    if (total == 0) return; // block-uniform
+    if (tid == 0) base_s = atomicAdd(second_count, (unsigned long long)total);
+    __syncthreads();
+    if (c) {
+        const int pshift = __builtin_ctz(period);
+        const int64_t g = u >> pshift;
+        const int64_t r0 = (g << (6 + pshift)) + (u - (g << pshift));
+        int64_t *dst = second + base_s + (part[tid] - c);
+        unsigned long long mm = m;
+        int i = 0;
+        while (mm) {
+            const int b = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            dst[i++] = r0 + (int64_t)b * period;
+        }
     }
 }
 
@@ -446,12 +605,14 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
         const int64_t l = second[e < cnt ? e : cnt - 1];
         lidx[lane] = l;
         __builtin_amdgcn_wave_barrier();
-        const int mask = rec_flags[l];
+        const int64_t slot = unit_slot(l, P.pshift);
+        const int mask = rec_flags[slot];
         bool keep[NA];
 #pragma unroll
         for (int j = 0; j < NA; ++j) keep[j] = (mask & (2 << j)) != 0;
         auto rowsel = [&](int r) { return lidx[r]; };
         A.clear();
+        int n_missing = 0;
         for (int st = 0; st < nst; ++st) {
             const int pool0 = st * LO_CHP;
             const int np = st < nfull ? LO_CHP : n - pool0;
@@ -469,22 +630,21 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
                 const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
                 const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
                 const uint32_t c[NA] = {a.x, a.y, b.x, b.y, d.x, d.y};
-                double cd[NA], f[NA], f0[NA];
+                double cd[NA], f[NA];
                 double rs = 0.0; // row sum over the surviving alleles (second to_frequencies, sync.rs:170-175)
 #pragma unroll
-                for (int j = 0; j < NA; ++j) { cd[j] = keep[j] ? (double)c[j] : 0.0; rs = keep[j] ? rs + cd[j] : rs; }
-                const double rinv = recip_for_div(rs);
+                for (int j = 0; j < NA; ++j) { cd[j] = keep[j] ? (double)c[j] : 0.0; rs = rs + cd[j]; }
                 const bool rowok = rs != 0.0;
+                const double rsd = rowok ? rs : 1.0;
+                const double rinv = recip_for_div(rsd);
+                n_missing += rowok ? 0 : 1;
 #pragma unroll
-                for (int j = 0; j < NA; ++j) {
-                    f[j] = keep[j] ? div_by(cd[j], rs, rinv) : 0.0;
-                    f0[j] = rowok ? f[j] : 0.0;
-                }
-                A.add_pool(f, f0, rowok, Y + (size_t)(pool0 + i) * K);
+                for (int j = 0; j < NA; ++j) f[j] = div_by(cd[j], rsd, rinv);
+                A.add_pool(f, rowok, Y + (size_t)(pool0 + i) * K);
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (e < cnt) store_record<OP, NA, K>(A, rec, P.L, l, aj);
+        if (e < cnt) store_record<OP, NA, K>(A, n_missing > 0, rec, rec_base(slot), aj);
     }
 }
 
@@ -499,7 +659,9 @@ __global__ __launch_bounds__(64) void k_locus_close(const int32_t *__restrict__ 
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= P.L) return;
     const int n = P.n, k = P.k;
-    const int mask = rec_flags[l];
+    const int64_t slot = unit_slot(l, P.pshift);
+    const size_t rb = rec_base(slot);
+    const int mask = rec_flags[slot];
     const bool alive = (mask & 1) != 0;
     bool keep[NA];
     int nk = 0;
@@ -509,29 +671,29 @@ __global__ __launch_bounds__(64) void k_locus_close(const int32_t *__restrict__ 
     for (int j = 0; j < NA; ++j) {
         keep[j] = (mask & (2 << j)) != 0;
         nk += keep[j] ? 1 : 0;
-        cs[j] = rec[(size_t)(R_CS + j) * P.L + l];
+        cs[j] = rec[rb + (size_t)(R_CS + j) * 64];
     }
 #pragma unroll
     for (int j = 0; j < 21; ++j) xx[j] = 0.0;
     if (OP == OP_OLS) {
 #pragma unroll
-        for (int j = 0; j < 21; ++j) xx[j] = rec[(size_t)(R_XX + j) * P.L + l];
+        for (int j = 0; j < 21; ++j) xx[j] = rec[rb + (size_t)(R_XX + j) * 64];
     } else if (OP == OP_CHISQ) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) xx[tri(j, j)] = rec[(size_t)(R_XX + tri(j, j)) * P.L + l];
-        total = rec[(size_t)R_TOTAL * P.L + l];
+        for (int j = 0; j < NA; ++j) xx[tri(j, j)] = rec[rb + (size_t)(R_XX + tri(j, j)) * 64];
+        total = rec[rb + (size_t)(R_TOTAL) * 64];
     }
 #pragma unroll
     for (int j = 0; j < NA * MAXK; ++j) {
-        xy[j] = (OP == OP_OLS || OP == OP_PEARSON) ? rec[(size_t)(R_XY + j) * P.L + l] : 0.0;
-        px[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PX + j) * P.L + l] : 0.0;
-        pxx[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PXX + j) * P.L + l] : 0.0;
+        xy[j] = (OP == OP_OLS || OP == OP_PEARSON) ? rec[rb + (size_t)(R_XY + j) * 64] : 0.0;
+        px[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PX + j) * 64] : 0.0;
+        pxx[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PXX + j) * 64] : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < MAXK; ++j) {
-        py[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PY + j) * P.L + l] : 0.0;
-        pyy[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PYY + j) * P.L + l] : 0.0;
-        pn[j] = (OP == OP_PEARSON) ? rec[(size_t)(R_PN + j) * P.L + l] : 0.0;
+        py[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PY + j) * 64] : 0.0;
+        pyy[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PYY + j) * 64] : 0.0;
+        pn[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PN + j) * 64] : 0.0;
     }
         // ================= closing arithmetic per locus ==========================================
         if (OP == OP_CHISQ) {
@@ -864,9 +1026,15 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     const int df = (OP == OP_OLS) ? n - 1 : n - 2; // ols.rs:139 / correlation_test.rs:65
     std::vector<double> tc = pg_tdist_coef(df < 1 ? 1 : df);
     const size_t side = ((size_t)n + (size_t)n * MAXK + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
-    const size_t recd = (size_t)L * REC_DOUBLES;
-    // workspace: [w | Y | tcoef] [records] [second-pass list: L x i64] [its length: u64] [flags: L x i32]
-    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 8 + sizeof(int32_t) * (size_t)L;
+    // rows whose start has the same offset inside a 128-byte line are `period` apart (see k_locus_first)
+    int period = 1;
+    while ((((int64_t)n * 24 * period) & 127) != 0) period *= 2;
+    PG_CHECK(ctx, (int64_t)64 * period * n * 24 < ((int64_t)1 << 31), "locus op: too many pools (%d) for one batch row group", n);
+    const int64_t nunits = ((L + 64 * (int64_t)period - 1) / (64 * (int64_t)period)) * period;
+    const size_t recd = (size_t)nunits * 64 * REC_DOUBLES; // unit-major: 64 slots per unit
+    // workspace: [w | Y | tcoef] [records] [second-pass list: L x i64] [its length: u64] [per-unit masks: u64] [flags: i32 per slot]
+    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 8 + 8 * (size_t)nunits +
+                        sizeof(int32_t) * (size_t)nunits * 64;
     int rc = pg_ws_reserve(ctx, need);
     if (rc) return rc;
     double *wd = static_cast<double *>(ctx->ws);
@@ -875,24 +1043,27 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     double *recp = wd + side;
     int64_t *second = reinterpret_cast<int64_t *>(recp + recd);
     unsigned long long *second_count = reinterpret_cast<unsigned long long *>(second + L);
-    int32_t *recf = reinterpret_cast<int32_t *>(second_count + 1);
+    unsigned long long *unit_again = second_count + 1;
+    int32_t *recf = reinterpret_cast<int32_t *>(unit_again + nunits);
     PG_HIP(ctx, hipMemcpyAsync(wd, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (!tc.empty())
         PG_HIP(ctx, hipMemcpyAsync(tcd, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
     const int cus = ctx->cus;
     const int64_t ntiles = (L + 63) / 64;
     int64_t blocks = (ntiles + LO_WAVES - 1) / LO_WAVES;
-    const int64_t cap = (int64_t)cus * 8;
+#ifndef LO_GRID_PER_CU
+#define LO_GRID_PER_CU 2
+#endif
+    const int64_t cap = (int64_t)cus * LO_GRID_PER_CU; // = the resident blocks (2 waves/SIMD): one long item sequence per wave
     const int grid = (int)(blocks < cap ? blocks : cap);
-    const size_t shmem = (size_t)LO_WAVES * LO_TILEB;
-    const size_t shmem2 = shmem + (size_t)LO_WAVES * 64 * sizeof(int64_t);
+    const size_t shmem = (size_t)LO_WAVES * LN_TILEB;
+    const size_t shmem2 = (size_t)LO_WAVES * LO_TILEB + (size_t)LO_WAVES * 64 * sizeof(int64_t);
     const bool p16 = ((int64_t)n * 24) % 16 == 0;
     const bool rns = flt->remove_ns != 0;
     auto pick_first = [&](int kg) -> const void * {
         auto sel = [&](auto kc) -> const void * {
             constexpr int KC = decltype(kc)::value;
-            return p16 ? (rns ? (const void *)k_locus_first<OP, 16, true, KC> : (const void *)k_locus_first<OP, 16, false, KC>)
-                       : (rns ? (const void *)k_locus_first<OP, 8, true, KC> : (const void *)k_locus_first<OP, 8, false, KC>);
+            return rns ? (const void *)k_locus_first<OP, true, KC> : (const void *)k_locus_first<OP, false, KC>;
         };
         if (OP == OP_CHISQ || kg == 1) return sel(std::integral_constant<int, 1>{});
         return sel(std::integral_constant<int, (OP == OP_CHISQ ? 1 : 2)>{});
@@ -911,6 +1082,7 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
         std::memset(&P, 0, sizeof P);
         P.L = L; P.n = n; P.k = kg; P.k_total = k; P.t0 = t0;
         P.remove_ns = flt->remove_ns ? 1 : 0;
+        P.pshift = __builtin_ctz((unsigned)period);
         P.min_cov = (double)flt->min_coverage_depth;
         P.maf = flt->min_allele_frequency;
         P.max_miss = flt->max_missingness_rate;
@@ -949,8 +1121,10 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
         {
             const uint32_t *a0 = counts_dev;
             const double *a1 = wd, *a2 = Ydev;
-            void *args1[] = {&a0, &a1, &a2, &recf, &recp, &second, &second_count, &P};
+            void *args1[] = {&a0, &a1, &a2, &recf, &recp, &unit_again, &P, &period};
             PG_HIP(ctx, hipLaunchKernel(kfirst, dim3(grid), dim3(LO_THREADS), args1, shmem, ctx->stream));
+            hipLaunchKernelGGL(k_locus_compact, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, ctx->stream,
+                               unit_again, nunits, period, second, second_count);
             const int32_t *b0 = recf;
             const int64_t *b1 = second;
             const unsigned long long *b2 = second_count;

@@ -7,7 +7,7 @@ for f in files:
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "k_kinship" in k or "k_ols" in k or "k_locus" in k or "k_gp" in k:
-            short = "k_" + k.split("k_", 1)[1].split("(")[0].split("<")[0][:36]
+            short = "k_" + k.split("k_", 1)[1].split("(")[0][:36]
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
     for c, v in cs.items():
