@@ -160,9 +160,7 @@ __device__ __forceinline__ constexpr int tri(int a, int b) { // a <= b
 }
 
 // record layout (struct-of-arrays: field f of locus l at rec[f * L + l])
-constexpr int R_CS = 0, R_XX = R_CS + NA, R_XY = R_XX + 21, R_PX = R_XY + NA * MAXK, R_PXX = R_PX + NA * MAXK,
-              R_PY = R_PXX + NA * MAXK, R_PYY = R_PY + MAXK, R_PN = R_PYY + MAXK, R_TOTAL = R_PN + MAXK,
-              REC_DOUBLES = R_TOTAL + 1;
+constexpr int REC_DOUBLES = 42; // the largest compact record: pearson, 5 outputs x 2 traits (see emit_record)
 // Records and flags are stored UNIT-MAJOR: the 64 loci a wave of k_locus_first works on (one alignment
 // class of a group of 64 * period rows, see there) are adjacent, field f of slot s at
 // rec[(s / 64) * REC_DOUBLES * 64 + f * 64 + s % 64], so that a wave's stores are whole 512-byte runs.
@@ -228,16 +226,18 @@ struct Sums {
                 {
                     const double y = Yrow[tt];           // shifted by its first valid value on the host
                     const bool ok = rowok && !isnan(y);  // pairwise complete (correlation_test.rs:22-26)
-                    py[tt] = ok ? py[tt] + y : py[tt];
-                    pyy[tt] = ok ? fma(y, y, pyy[tt]) : pyy[tt];
-                    pn[tt] = ok ? pn[tt] + 1.0 : pn[tt];
+                    // an incomplete pair contributes exact zeros (x = y = 0) instead of being skipped
+                    const double ye = ok ? y : 0.0;
+                    py[tt] = py[tt] + ye;
+                    pyy[tt] = fma(ye, ye, pyy[tt]);
+                    pn[tt] = pn[tt] + (ok ? 1.0 : 0.0);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const double x = f[j] - shx[j];
+                        const double x = ok ? f[j] - shx[j] : 0.0;
                         const int e = j * K + tt;
-                        px[e] = ok ? px[e] + x : px[e];
-                        pxx[e] = ok ? fma(x, x, pxx[e]) : pxx[e];
-                        xy[e] = ok ? fma(x, y, xy[e]) : xy[e];
+                        px[e] = px[e] + x;
+                        pxx[e] = fma(x, x, pxx[e]);
+                        xy[e] = fma(x, ye, xy[e]);
                     }
                 }
             }
@@ -254,46 +254,145 @@ struct Sums {
     }
 };
 
-// write the sums of one locus to its record; AJ(jj) = allele id of slot jj
+// ---- compact records --------------------------------------------------------------------------------
+// What the closing kernel needs of a locus is decided here, where the sums are in registers: which
+// alleles survive, in which order the operator uses them, and ONLY the sums of those.  Header (int32):
+//   bit 0 alive | bits 1..6 surviving alleles | bit 7 second pass needed | bits 8..10 nk |
+//   bits 11..28 ord[0..5], 3 bits each: allele id at rank r
+// (ols_iter: stable sort by decreasing column sum, sync.rs:477-506, rank 0 = the major allele that
+// ols.rs:227-230 drops; pearson / chisq: surviving alleles in column order).  Doubles, D = nk - 1:
+//   ols_iter : per design column d = 0..D-1 (rank d+1):  cs, xy[0..K), xx(d, 0..d)
+//   pearson  : py, pyy, pn per trait, then per output d = 0..D-1 (all survivors but the last,
+//              correlation_test.rs:95-98): cs, then px, pxx, xy per trait
+//   chisq    : chi2 = total * (sum_j A_j / cs_j - 1)   (tables/chisq_test.rs:15-31 regrouped)
+// A biallelic ols_iter locus with one trait is 3 doubles + the header instead of 25: the record
+// stream is what the HBM pays for twice (written here, read by the closing kernel).
+constexpr int H_NK_SHIFT = 8, H_ORD_SHIFT = 11;
+template <int K> __device__ __forceinline__ constexpr int ols_field(int d) { return d * (1 + K) + d * (d + 1) / 2; }
+template <int K> __device__ __forceinline__ constexpr int prs_field(int d) { return 3 * K + d * (1 + 3 * K); }
+
+// a[idx] for a run-time idx WITHOUT indexing memory: hipcc folds a plain chain of selects over array
+// elements back into a dynamically indexed load, which pins the whole accumulator struct in scratch
+// memory; the empty asm makes each element an opaque register value first.
+__device__ __forceinline__ double opaque(double v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ double pickn(const double (&a)[N], int idx) {
+    double r = opaque(a[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) r = (idx == j) ? opaque(a[j]) : r;
+    return r;
+}
+template <int NJ, int K>
+__device__ __forceinline__ double pick_trait(const double (&a)[NJ * K], int idx, int t) {
+    double r = opaque(a[t]);
+#pragma unroll
+    for (int j = 1; j < NJ; ++j) r = (idx == j) ? opaque(a[j * K + t]) : r;
+    return r;
+}
+
 template <int OP, int NJ, int K, typename AJ>
-__device__ __forceinline__ void store_record(const Sums<OP, NJ, K> &S, bool poisoned, double *__restrict__ rec,
-                                             size_t rb, AJ aj) {
+__device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poisoned, const bool (&kp)[NJ], bool alive,
+                                            bool again, bool valid, int32_t *__restrict__ rec_flags,
+                                            double *__restrict__ rec, int64_t slot, AJ aj) {
+    const size_t rb = rec_base(slot);
     const double pz = poisoned ? NAN : 0.0; // x + NaN = NaN: an uncovered pool makes the plain sums NaN
+    int nk = 0, keepmask = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) rec[rb + (size_t)(R_CS + aj(j)) * 64] = S.cs[j];
-    if (OP == OP_OLS) {
+    for (int j = 0; j < NJ; ++j) { nk += kp[j] ? 1 : 0; keepmask |= kp[j] ? (2 << aj(j)) : 0; }
+    // rank of every surviving slot, and its inverse
+    int ordslot[NJ];
+    int ordbits = 0;
+    {
+        int rank[NJ];
 #pragma unroll
-        for (int a = 0; a < NJ; ++a)
+        for (int j = 0; j < NJ; ++j) {
+            int r = 0;
 #pragma unroll
-            for (int b = a; b < NJ; ++b) rec[rb + (size_t)(R_XX + tri(aj(a), aj(b))) * 64] = S.xx[S.trin(a, b)] + pz;
-    }
-    if (OP == OP_CHISQ) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) rec[rb + (size_t)(R_XX + tri(aj(j), aj(j))) * 64] = S.xx[j] + pz;
-        rec[rb + (size_t)(R_TOTAL) * 64] = S.total + pz;
-    }
-    if (OP == OP_OLS || OP == OP_PEARSON) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int tt = 0; tt < K; ++tt)
-                rec[rb + (size_t)(R_XY + aj(j) * MAXK + tt) * 64] = S.xy[j * K + tt] + ((OP == OP_OLS) ? pz : 0.0);
-    }
-    if (OP == OP_PEARSON) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int tt = 0; tt < K; ++tt) {
-                rec[rb + (size_t)(R_PX + aj(j) * MAXK + tt) * 64] = S.px[j * K + tt];
-                rec[rb + (size_t)(R_PXX + aj(j) * MAXK + tt) * 64] = S.pxx[j * K + tt];
+            for (int i = 0; i < NJ; ++i) {
+                if (i == j) continue;
+                bool before;
+                if (OP == OP_OLS) before = S.cs[i] > S.cs[j] || (S.cs[i] == S.cs[j] && i < j);
+                else before = i < j;
+                r += (kp[i] && before) ? 1 : 0;
             }
+            rank[j] = kp[j] ? r : NJ;
+        }
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            rec[rb + (size_t)(R_PY + j) * 64] = S.py[j];
-            rec[rb + (size_t)(R_PYY + j) * 64] = S.pyy[j];
-            rec[rb + (size_t)(R_PN + j) * 64] = S.pn[j];
+        for (int r = 0; r < NJ; ++r) {
+            int sl = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) sl = (rank[j] == r) ? j : sl;
+            ordslot[r] = sl;
+            int id = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) id = (sl == j) ? aj(j) : id;
+            ordbits |= (r < nk ? id : 0) << (3 * r);
         }
     }
+    if (valid)
+        rec_flags[slot] = (alive ? FLAG_ALIVE : 0) | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT) |
+                          (ordbits << H_ORD_SHIFT);
+    const int D = (valid && alive && !again) ? nk - 1 : 0; // a locus the second pass redoes gets its sums there
+    if (OP == OP_CHISQ) {
+        if (D > 0) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc = kp[j] ? acc + S.xx[j] / S.cs[j] : acc;
+            rec[rb] = S.total * (acc - 1.0) + pz;
+        }
+        return;
+    }
+    if (OP == OP_PEARSON) {
+        if (D > 0) {
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                rec[rb + (size_t)(3 * t) * 64] = S.py[t];
+                rec[rb + (size_t)(3 * t + 1) * 64] = S.pyy[t];
+                rec[rb + (size_t)(3 * t + 2) * 64] = S.pn[t];
+            }
+        }
+    }
+    static_for<0, NJ - 1>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if (!__any(d < D)) return; // wave-uniform: nobody has that many columns
+        const int a = (OP == OP_OLS) ? ordslot[d + 1] : ordslot[d];
+        const bool on = d < D;
+        if (OP == OP_OLS) {
+            const int f0 = ols_field<K>(d);
+            const double c = pickn<NJ>(S.cs, a);
+            if (on) rec[rb + (size_t)f0 * 64] = c;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const double v = pick_trait<NJ, K>(S.xy, a, t);
+                if (on) rec[rb + (size_t)(f0 + 1 + t) * 64] = v + pz;
+            }
+#pragma unroll
+            for (int cidx = 0; cidx <= d; ++cidx) {
+                const int b2 = ordslot[cidx + 1];
+                const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+                const int ti = lo * NJ - lo * (lo - 1) / 2 + (hi - lo);
+                const double v = pickn<NJ * (NJ + 1) / 2>(S.xx, ti);
+                if (on) rec[rb + (size_t)(f0 + 1 + K + cidx) * 64] = v + pz;
+            }
+        } else { // OP_PEARSON
+            const int f0 = prs_field<K>(d);
+            const double c = pickn<NJ>(S.cs, a);
+            if (on) rec[rb + (size_t)f0 * 64] = c;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const double vx = pick_trait<NJ, K>(S.px, a, t), vxx = pick_trait<NJ, K>(S.pxx, a, t),
+                             vxy = pick_trait<NJ, K>(S.xy, a, t);
+                if (on) {
+                    rec[rb + (size_t)(f0 + 1 + 3 * t) * 64] = vx;
+                    rec[rb + (size_t)(f0 + 2 + 3 * t) * 64] = vxx;
+                    rec[rb + (size_t)(f0 + 3 + 3 * t) * 64] = vxy;
+                }
+            }
+        }
+    });
 }
 
 // ---- first pass: every locus, one read of its counts ----------------------------------------------
@@ -492,14 +591,14 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
         if (s == nlines - 1) {
             // filter decisions (sync.rs:223-300) and the record of this locus
             const int64_t l = r0 + (int64_t)lane * period;
-            int mask = 0, nk = 0;
+            int nk = 0;
+            bool kp[NJ];
             bool dropped_with_reads = false;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const bool kp = !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
-                nk += kp ? 1 : 0;
-                mask |= kp ? (2 << aj(j)) : 0;
-                dropped_with_reads = dropped_with_reads || (!kp && orc[j] != 0u);
+                kp[j] = !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
+                nk += kp[j] ? 1 : 0;
+                dropped_with_reads = dropped_with_reads || (!kp[j] && orc[j] != 0u);
             }
             bool alive = !(mincov < P.min_cov);                                        // sync.rs:227
             alive = alive && nk >= 2;                                                  // sync.rs:284
@@ -508,18 +607,10 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
             alive = alive && l < L;
             const bool again = alive && dropped_with_reads;
 #ifdef LN_EXP_NOSTORE
-            if (l < L && mask == 12345) {
-#else
-            if (l < L) {
+            if (nk == 12345)
 #endif
-                const int64_t slot = unit_of(cur.chunk, cur.q) * 64 + lane;
-                rec_flags[slot] = mask | (alive ? FLAG_ALIVE : 0) | (again ? FLAG_SECOND : 0);
-#ifdef LN_EXP_SMALLREC
-                store_record<OP, NJ, K>(A, n_missing > 0, rec, rec_base(slot) & 0xFFFFu, aj);
-#else
-                store_record<OP, NJ, K>(A, n_missing > 0, rec, rec_base(slot), aj);
-#endif
-            }
+            emit_record<OP, NJ, K>(A, n_missing > 0, kp, alive, again, l < L, rec_flags, rec,
+                                   unit_of(cur.chunk, cur.q) * 64 + lane, aj);
             // which lanes of this unit need the second pass: one 64-bit mask per unit, expanded into the
             // dense list by k_locus_compact (no returning atomic here: its wait would drain the loads in flight)
             const unsigned long long bal = __ballot(again);
@@ -582,7 +673,7 @@ __global__ __launch_bounds__(256) void k_locus_compact(const unsigned long long 
 // One lane per listed locus (rows gathered through the list), sums over the SURVIVING alleles only.
 template <int OP, int PB, int K>
 __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
-    const uint32_t *__restrict__ counts, const double *__restrict__ Y, const int32_t *__restrict__ rec_flags,
+    const uint32_t *__restrict__ counts, const double *__restrict__ Y, int32_t *__restrict__ rec_flags,
     double *__restrict__ rec, const int64_t *__restrict__ second,
     const unsigned long long *__restrict__ second_count, const LocusParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -644,11 +735,220 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (e < cnt) store_record<OP, NA, K>(A, n_missing > 0, rec, rec_base(slot), aj);
+        emit_record<OP, NA, K>(A, n_missing > 0, keep, true, false, e < cnt, rec_flags, rec, slot, aj);
     }
 }
 
-// Closing kernels: one thread per locus, from the record the streaming kernel left.
+// ---- closing kernels: one thread per locus, from the compact record (see emit_record) ----------------
+// ols_iter: literal normal equations in the reference's column order (ols.rs:58-160) on the PN = nk
+// columns [1 | f_ord[1] | ... | f_ord[nk-1]], specialised on PN so that the common biallelic locus pays
+// for a 2 x 2 factorisation only.
+template <int PN>
+__device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t rb, int k, int ordbits, bool alive,
+                                          const double *__restrict__ tcoef, int32_t *__restrict__ n_out,
+                                          int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
+                                          double *__restrict__ stat_out, double *__restrict__ pv_out, int64_t l,
+                                          const LocusParams &P) {
+    constexpr int D = PN - 1;
+    const int n = P.n;
+    const int kk = k; // 1 or 2 traits in this launch: the record was laid out with K = k
+    double cs[D], xxs[D][D], xy[D][MAXK];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int f0 = d * (1 + kk) + d * (d + 1) / 2;
+        cs[d] = rec[rb + (size_t)f0 * 64];
+#pragma unroll
+        for (int t = 0; t < MAXK; ++t) xy[d][t] = (t < kk) ? rec[rb + (size_t)(f0 + 1 + t) * 64] : 0.0;
+#pragma unroll
+        for (int c = 0; c <= d; ++c) {
+            const double v = rec[rb + (size_t)(f0 + 1 + kk + c) * 64];
+            xxs[d][c] = v;
+            xxs[c][d] = v;
+        }
+    }
+    double A[PN][PN];
+    auto xtx = [&](int r, int c) -> double {
+        if (r == 0 && c == 0) return (double)n;
+        if (r == 0) return cs[c - 1];
+        if (c == 0) return cs[r - 1];
+        return xxs[r - 1][c - 1];
+    };
+#pragma unroll
+    for (int r = 0; r < PN; ++r)
+#pragma unroll
+        for (int c = 0; c < PN; ++c) A[r][c] = xtx(r, c);
+    // LU with partial pivoting, first max |a| in the column (the oracle's lu_factor; LAPACK dgetf2)
+    bool singular = false;
+    int piv[PN];
+#pragma unroll
+    for (int kq = 0; kq < PN; ++kq) {
+        int pi = kq;
+        double pm = fabs(A[kq][kq]);
+#pragma unroll
+        for (int i2 = kq + 1; i2 < PN; ++i2) {
+            const double v = fabs(A[i2][kq]);
+            const bool g = v > pm;
+            pm = g ? v : pm;
+            pi = g ? i2 : pi;
+        }
+        piv[kq] = pi;
+#pragma unroll
+        for (int i2 = kq + 1; i2 < PN; ++i2) {
+            const bool sw = (pi == i2);
+#pragma unroll
+            for (int j = 0; j < PN; ++j) {
+                const double x1 = A[kq][j], x2 = A[i2][j];
+                A[kq][j] = sw ? x2 : x1;
+                A[i2][j] = sw ? x1 : x2;
+            }
+        }
+        if (A[kq][kq] == 0.0) singular = true;
+        const double inv = 1.0 / A[kq][kq];
+#pragma unroll
+        for (int i2 = kq + 1; i2 < PN; ++i2) A[i2][kq] = A[i2][kq] * inv;
+#pragma unroll
+        for (int i2 = kq + 1; i2 < PN; ++i2) {
+            const double lf = A[i2][kq];
+#pragma unroll
+            for (int j = kq + 1; j < PN; ++j) A[i2][j] = A[i2][j] - lf * A[kq][j];
+        }
+    }
+    // x = (X'X)^-1 rhs through the factorisation (P A = L U)
+    auto lu_solve = [&](double (&col)[PN]) {
+#pragma unroll
+        for (int kq = 0; kq < PN; ++kq) {
+#pragma unroll
+            for (int i2 = kq + 1; i2 < PN; ++i2) {
+                const bool sw = (piv[kq] == i2);
+                const double x1 = col[kq], x2 = col[i2];
+                col[kq] = sw ? x2 : x1;
+                col[i2] = sw ? x1 : x2;
+            }
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < PN; ++i2) {
+            double sacc = col[i2];
+#pragma unroll
+            for (int j = 0; j < i2; ++j) sacc = sacc - A[i2][j] * col[j];
+            col[i2] = sacc;
+        }
+#pragma unroll
+        for (int i2 = PN - 1; i2 >= 0; --i2) {
+            double sacc = col[i2];
+#pragma unroll
+            for (int j = i2 + 1; j < PN; ++j) sacc = sacc - A[i2][j] * col[j];
+            col[i2] = sacc / A[i2][i2];
+        }
+    };
+    // full inverse, column by column in the oracle's order: its diagonal gives var(b)
+    // (ols.rs:111-116) and its determinant feeds the second singularity test (ols.rs:81-83)
+    double Inv[PN][PN], dinv[PN];
+#pragma unroll
+    for (int c2 = 0; c2 < PN; ++c2) {
+        double col[PN];
+#pragma unroll
+        for (int i2 = 0; i2 < PN; ++i2) col[i2] = (i2 == c2) ? 1.0 : 0.0;
+        lu_solve(col);
+#pragma unroll
+        for (int i2 = 0; i2 < PN; ++i2) Inv[i2][c2] = col[i2];
+        dinv[c2] = col[c2];
+    }
+    // `inv.det() == 0.0` (ols.rs:81): LU of the inverse, singular factorisation -> det 0.
+    // Loci with duplicated allele columns pass the first LU by a rounding residue and are
+    // caught here, exactly as in the reference.
+    {
+        double det = 1.0;
+        bool zero_piv = false;
+#pragma unroll
+        for (int kq = 0; kq < PN; ++kq) {
+            int pi = kq;
+            double pm = fabs(Inv[kq][kq]);
+#pragma unroll
+            for (int i2 = kq + 1; i2 < PN; ++i2) {
+                const double v = fabs(Inv[i2][kq]);
+                const bool g = v > pm;
+                pm = g ? v : pm;
+                pi = g ? i2 : pi;
+            }
+#pragma unroll
+            for (int i2 = kq + 1; i2 < PN; ++i2) {
+                const bool sw = (pi == i2);
+#pragma unroll
+                for (int j = 0; j < PN; ++j) {
+                    const double x1 = Inv[kq][j], x2 = Inv[i2][j];
+                    Inv[kq][j] = sw ? x2 : x1;
+                    Inv[i2][j] = sw ? x1 : x2;
+                }
+            }
+            const double pvt = Inv[kq][kq];
+            zero_piv = zero_piv || (pvt == 0.0);
+            const double ipv = 1.0 / pvt;
+#pragma unroll
+            for (int i2 = kq + 1; i2 < PN; ++i2) {
+                const double lf = (pvt != 0.0) ? Inv[i2][kq] * ipv : 0.0;
+                if (lf != 0.0) {
+#pragma unroll
+                    for (int j = kq + 1; j < PN; ++j) Inv[i2][j] = Inv[i2][j] - lf * Inv[kq][j];
+                }
+            }
+            det = det * pvt;
+        }
+        if (zero_piv || det == 0.0) singular = true;
+    }
+    const bool ok = alive && !singular; // Err -> the whole locus is dropped (ols.rs:250-253)
+    if (P.t0 == 0) {
+        n_out[l] = ok ? D : 0;
+#pragma unroll
+        for (int r = 0; r < PG_MAX_OUT; ++r) {
+            const bool on = ok && r < D;
+            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * (r + 1))) & 7) : -1;
+            mf_out[l * PG_MAX_OUT + r] = (on && r < D) ? cs[r < D ? r : 0] / (double)n : NAN; // ols.rs:266
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < MAXK; ++tt) {
+        if (tt >= k) continue;
+        // X'y with the centred phenotype (slopes are invariant to the shift; it removes the
+        // y-bar^2 cancellation from the residual sum of squares)
+        double xty[PN], b[PN];
+        xty[0] = P.sy[tt];
+#pragma unroll
+        for (int r = 1; r < PN; ++r) xty[r] = xy[r - 1][tt];
+#pragma unroll
+        for (int r = 0; r < PN; ++r) b[r] = xty[r];
+        lu_solve(b);
+        // RSS = y'y - 2 b'X'y + b'(X'X) b: the form that is stationary in b, so the O(cond*eps)
+        // error of the solve enters only to second order
+        double bxy = 0.0;
+#pragma unroll
+        for (int r = 0; r < PN; ++r) {
+            double ab = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < PN; ++c2) ab = fma(xtx(r, c2), b[c2], ab);
+            bxy = fma(b[r], 2.0 * xty[r] - ab, bxy);
+        }
+        double rss = P.syy[tt] - bxy;
+        rss = rss < 0.0 ? 0.0 : rss;
+        const double ve = rss / ((double)n - (double)PN); // ols.rs:103
+#pragma unroll
+        for (int r = 0; r < PG_MAX_OUT; ++r) {
+            double pv = NAN, bb = NAN;
+            if (r < D) {
+                if (ok) {
+                    bb = b[r + 1 < PN ? r + 1 : 0];
+                    const double vb = ve * dinv[r + 1 < PN ? r + 1 : 0];             // ols.rs:111-116
+                    const double tstat = (fabs(bb) <= PG_EPS) ? 0.0 : bb / sqrt(vb); // ols.rs:143-147
+                    if (fabs(tstat) <= PG_EPS) pv = 1.0;
+                    else if (isnan(tstat)) pv = 1.0;
+                    else pv = pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef);
+                }
+            }
+            stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = bb;
+            pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pv;
+        }
+    }
+}
+
 template <int OP>
 __global__ __launch_bounds__(64) void k_locus_close(const int32_t *__restrict__ rec_flags,
                                                     const double *__restrict__ rec,
@@ -657,349 +957,90 @@ __global__ __launch_bounds__(64) void k_locus_close(const int32_t *__restrict__ 
                                                     double *__restrict__ stat_out, double *__restrict__ pv_out,
                                                     const LocusParams P) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= P.L) return;
+    const bool inr = l < P.L;
     const int n = P.n, k = P.k;
-    const int64_t slot = unit_slot(l, P.pshift);
+    const int64_t slot = unit_slot(inr ? l : P.L - 1, P.pshift);
     const size_t rb = rec_base(slot);
-    const int mask = rec_flags[slot];
-    const bool alive = (mask & 1) != 0;
-    bool keep[NA];
-    int nk = 0;
-    double cs[NA], xx[21], xy[NA * MAXK], px[NA * MAXK], pxx[NA * MAXK], py[MAXK], pyy[MAXK], pn[MAXK];
-    double total = 0.0;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        keep[j] = (mask & (2 << j)) != 0;
-        nk += keep[j] ? 1 : 0;
-        cs[j] = rec[rb + (size_t)(R_CS + j) * 64];
-    }
-#pragma unroll
-    for (int j = 0; j < 21; ++j) xx[j] = 0.0;
-    if (OP == OP_OLS) {
-#pragma unroll
-        for (int j = 0; j < 21; ++j) xx[j] = rec[rb + (size_t)(R_XX + j) * 64];
-    } else if (OP == OP_CHISQ) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) xx[tri(j, j)] = rec[rb + (size_t)(R_XX + tri(j, j)) * 64];
-        total = rec[rb + (size_t)(R_TOTAL) * 64];
-    }
-#pragma unroll
-    for (int j = 0; j < NA * MAXK; ++j) {
-        xy[j] = (OP == OP_OLS || OP == OP_PEARSON) ? rec[rb + (size_t)(R_XY + j) * 64] : 0.0;
-        px[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PX + j) * 64] : 0.0;
-        pxx[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PXX + j) * 64] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < MAXK; ++j) {
-        py[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PY + j) * 64] : 0.0;
-        pyy[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PYY + j) * 64] : 0.0;
-        pn[j] = (OP == OP_PEARSON) ? rec[rb + (size_t)(R_PN + j) * 64] : 0.0;
-    }
-        // ================= closing arithmetic per locus ==========================================
-        if (OP == OP_CHISQ) {
-            // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
-            int cnt = 0;
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                if (keep[j]) {
-                    ids_out[l * PG_MAX_OUT + (cnt < PG_MAX_OUT ? cnt : PG_MAX_OUT - 1)] = j;
-                    acc += xx[tri(j, j)] / cs[j];
-                    ++cnt;
-                }
-            }
-            const double chi2 = total * (acc - 1.0);
-            const double df = (double)(n * nk) - 1.0;
-            n_out[l] = alive ? nk : 0;
-            stat_out[l] = alive ? chi2 : NAN;
-            pv_out[l] = alive ? pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)) : NAN;
-            return;
-        }
+    const int hdr = rec_flags[slot];
+    const bool alive = inr && (hdr & FLAG_ALIVE) != 0;
+    const int nk = (hdr >> H_NK_SHIFT) & 7;
+    const int ordbits = hdr >> H_ORD_SHIFT;
 
-        // order of the surviving alleles
-        int ord[NA]; // ord[r] = allele id at rank r (only the first nk entries are meaningful)
-        if (OP == OP_OLS) {
-            // stable sort by decreasing column sum (sync.rs:477-506), then drop rank 0 (ols.rs:227-230)
-            int rank[NA];
+    if (OP == OP_CHISQ) {
+        if (!inr) return;
+        // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                int r = 0;
+        for (int r = 0; r < PG_MAX_OUT; ++r) ids_out[l * PG_MAX_OUT + r] = (r < nk) ? ((ordbits >> (3 * r)) & 7) : -1;
+        const double chi2 = alive ? rec[rb] : NAN;
+        const double df = (double)(n * nk) - 1.0;
+        n_out[l] = alive ? nk : 0;
+        stat_out[l] = chi2;
+        pv_out[l] = alive ? pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)) : NAN;
+        return;
+    }
+
+    if (OP == OP_PEARSON) {
+        if (!inr) return;
+        // gwas/correlation_test.rs:94-126: all surviving alleles but the LAST, unsorted
+        const int nout = alive ? (nk >= 2 ? nk - 1 : nk) : 0;
+        n_out[l] = nout;
 #pragma unroll
-                for (int i2 = 0; i2 < NA; ++i2)
-                    if (i2 != j && keep[i2]) r += (cs[i2] > cs[j] || (cs[i2] == cs[j] && i2 < j)) ? 1 : 0;
-                rank[j] = keep[j] ? r : NA;
-            }
+        for (int r = 0; r < PG_MAX_OUT; ++r) {
+            const bool on = r < nout;
+            const int f0 = 3 * k + r * (1 + 3 * k);
+            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * r)) & 7) : -1;
+            mf_out[l * PG_MAX_OUT + r] = on ? rec[rb + (size_t)f0 * 64] / (double)n : NAN; // x.mean(), :119
 #pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                int id = 0;
-#pragma unroll
-                for (int j = 0; j < NA; ++j) id = (rank[j] == r) ? j : id;
-                ord[r] = id;
-            }
-        } else {
-            int r = 0;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) ord[j] = 0;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                if (keep[j]) {
-#pragma unroll
-                    for (int s = 0; s < NA; ++s) ord[s] = (s == r) ? j : ord[s];
-                    ++r;
+            for (int tt = 0; tt < MAXK; ++tt) {
+                if (tt >= k) continue;
+                double rr = NAN, pp = NAN;
+                if (on) {
+                    const double sy = rec[rb + (size_t)(3 * tt) * 64], syy = rec[rb + (size_t)(3 * tt + 1) * 64],
+                                 m = rec[rb + (size_t)(3 * tt + 2) * 64];
+                    const double sx = rec[rb + (size_t)(f0 + 1 + 3 * tt) * 64], sxx = rec[rb + (size_t)(f0 + 2 + 3 * tt) * 64],
+                                 sxy = rec[rb + (size_t)(f0 + 3 + 3 * tt) * 64];
+                    const double cxy = sxy - sx * sy / m;
+                    const double cxx = sxx - sx * sx / m;
+                    const double cyy = syy - sy * sy / m;
+                    const double r0 = cxy / (sqrt(cxx) * sqrt(cyy));      // :50-52
+                    if (isnan(r0)) { rr = NAN; pp = NAN; }                // :53-56
+                    else {
+                        const double sden = (1.0 - r0 * r0) / ((double)n - 2.0); // :57
+                        if (sden <= 0.0) { rr = r0; pp = PG_EPS; }         // :58-61
+                        else {
+                            const double tstat = r0 / sqrt(sden);
+                            pp = (n > 2) ? pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef) : NAN;
+                            rr = round(r0 * 1e7) / 1e7; // sensible_round(r, 7), :70 (half away from zero)
+                        }
+                    }
                 }
+                stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = rr;
+                pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
             }
         }
+        return;
+    }
 
-        if (OP == OP_PEARSON) {
-            // gwas/correlation_test.rs:94-126: all surviving alleles but the LAST, unsorted
-            const int nout = nk >= 2 ? nk - 1 : nk;
-            n_out[l] = alive ? nout : 0;
+    // ---------------- OP_OLS ----------------------------------------------------------------------
+    const int pn = alive ? nk : 0;
+    if (inr && pn < 2) { // not emitted: ols.rs:215-237
+        if (P.t0 == 0) {
+            n_out[l] = 0;
+#pragma unroll
+            for (int r = 0; r < PG_MAX_OUT; ++r) { ids_out[l * PG_MAX_OUT + r] = -1; mf_out[l * PG_MAX_OUT + r] = NAN; }
+        }
+        for (int tt = 0; tt < k; ++tt)
 #pragma unroll
             for (int r = 0; r < PG_MAX_OUT; ++r) {
-                const int j = ord[r];
-                const bool on = alive && r < nout;
-                ids_out[l * PG_MAX_OUT + r] = on ? j : -1;
-                mf_out[l * PG_MAX_OUT + r] = on ? pick6(cs, j) / (double)n : NAN; // x.mean(), :119
-#pragma unroll
-                for (int tt = 0; tt < MAXK; ++tt) {
-                    if (tt >= k) continue;
-                    double rr = NAN, pp = NAN;
-                    if (on) {
-                        double sx = 0, sxx = 0, sxy = 0;
-                        const double sy = py[tt], syy = pyy[tt], m = pn[tt];
-#pragma unroll
-                        for (int jj = 0; jj < NA; ++jj) {
-                            const int e = jj * MAXK + tt;
-                            sx = (jj == j) ? px[e] : sx; sxx = (jj == j) ? pxx[e] : sxx;
-                            sxy = (jj == j) ? xy[e] : sxy;
-                        }
-                        const double cxy = sxy - sx * sy / m;
-                        const double cxx = sxx - sx * sx / m;
-                        const double cyy = syy - sy * sy / m;
-                        const double r0 = cxy / (sqrt(cxx) * sqrt(cyy));      // :50-52
-                        if (isnan(r0)) { rr = NAN; pp = NAN; }                // :53-56
-                        else {
-                            const double sden = (1.0 - r0 * r0) / ((double)n - 2.0); // :57
-                            if (sden <= 0.0) { rr = r0; pp = PG_EPS; }         // :58-61
-                            else {
-                                const double tstat = r0 / sqrt(sden);
-                                pp = (n > 2) ? pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef) : NAN;
-                                rr = round(r0 * 1e7) / 1e7; // sensible_round(r, 7), :70 (half away from zero)
-                            }
-                        }
-                    }
-                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = rr;
-                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
-                }
+                stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
+                pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
             }
-            return;
-        }
-
-        // ---------------- OP_OLS: literal normal equations in the reference's column order -------
-        // X = [1 | f_ord[1] | ... | f_ord[nk-1]]  (ols.rs:240-246), P = nk columns
-        const int Pn = nk;
-        double A[NA][NA];
-        int sel[NA]; // sel[r] = allele id of design column r (r >= 1), -1 for the intercept / unused
-#pragma unroll
-        for (int r = 0; r < NA; ++r) sel[r] = (r >= 1 && r < Pn) ? ord[r] : -1;
-        // entry (r, c) of X'X, identity-padded beyond P so that the padding is inert in the LU
-        auto xtx = [&](int r, int c2) -> double {
-            double v;
-            if (r >= Pn || c2 >= Pn) v = (r == c2) ? 1.0 : 0.0;
-            else if (r == 0 && c2 == 0) v = (double)n;
-            else if (r == 0) v = pick6(cs, sel[c2]);
-            else if (c2 == 0) v = pick6(cs, sel[r]);
-            else {
-                const int a = min(sel[r], sel[c2]), bq = max(sel[r], sel[c2]);
-                double sacc = 0.0;
-#pragma unroll
-                for (int i2 = 0; i2 < 21; ++i2) sacc = (i2 == tri(a, bq)) ? xx[i2] : sacc;
-                v = sacc;
-            }
-            return v;
-        };
-#pragma unroll
-        for (int r = 0; r < NA; ++r)
-#pragma unroll
-            for (int c2 = 0; c2 < NA; ++c2) A[r][c2] = xtx(r, c2);
-        // LU with partial pivoting, first max |a| in the column (the oracle's lu_factor; LAPACK dgetf2)
-        bool singular = false;
-        int piv[NA];
-#pragma unroll
-        for (int kk = 0; kk < NA; ++kk) {
-            int pi = kk;
-            double pm = fabs(A[kk][kk]);
-#pragma unroll
-            for (int i2 = kk + 1; i2 < NA; ++i2) {
-                const double v = fabs(A[i2][kk]);
-                const bool g = v > pm;
-                pm = g ? v : pm;
-                pi = g ? i2 : pi;
-            }
-            piv[kk] = pi;
-#pragma unroll
-            for (int i2 = kk + 1; i2 < NA; ++i2) {
-                const bool sw = (pi == i2);
-#pragma unroll
-                for (int j = 0; j < NA; ++j) {
-                    const double x1 = A[kk][j], x2 = A[i2][j];
-                    A[kk][j] = sw ? x2 : x1;
-                    A[i2][j] = sw ? x1 : x2;
-                }
-            }
-            if (A[kk][kk] == 0.0) singular = true;
-            const double inv = 1.0 / A[kk][kk];
-#pragma unroll
-            for (int i2 = kk + 1; i2 < NA; ++i2) A[i2][kk] = A[i2][kk] * inv;
-#pragma unroll
-            for (int i2 = kk + 1; i2 < NA; ++i2) {
-                const double lf = A[i2][kk];
-#pragma unroll
-                for (int j = kk + 1; j < NA; ++j) A[i2][j] = A[i2][j] - lf * A[kk][j];
-            }
-        }
-        // x = (X'X)^-1 rhs through the factorisation (P A = L U)
-        auto lu_solve = [&](double (&col)[NA]) {
-#pragma unroll
-            for (int kk = 0; kk < NA; ++kk) {
-#pragma unroll
-                for (int i2 = kk + 1; i2 < NA; ++i2) {
-                    const bool sw = (piv[kk] == i2);
-                    const double x1 = col[kk], x2 = col[i2];
-                    col[kk] = sw ? x2 : x1;
-                    col[i2] = sw ? x1 : x2;
-                }
-            }
-#pragma unroll
-            for (int i2 = 0; i2 < NA; ++i2) {
-                double sacc = col[i2];
-#pragma unroll
-                for (int j = 0; j < i2; ++j) sacc = sacc - A[i2][j] * col[j];
-                col[i2] = sacc;
-            }
-#pragma unroll
-            for (int i2 = NA - 1; i2 >= 0; --i2) {
-                double sacc = col[i2];
-#pragma unroll
-                for (int j = i2 + 1; j < NA; ++j) sacc = sacc - A[i2][j] * col[j];
-                col[i2] = sacc / A[i2][i2];
-            }
-        };
-        // full inverse, column by column in the oracle's order: its diagonal gives var(b)
-        // (ols.rs:111-116) and its determinant feeds the second singularity test (ols.rs:81-83)
-        double Inv[NA][NA], dinv[NA];
-#pragma unroll
-        for (int c2 = 0; c2 < NA; ++c2) {
-            double col[NA];
-#pragma unroll
-            for (int i2 = 0; i2 < NA; ++i2) col[i2] = (i2 == c2) ? 1.0 : 0.0;
-            lu_solve(col);
-#pragma unroll
-            for (int i2 = 0; i2 < NA; ++i2) Inv[i2][c2] = col[i2];
-            dinv[c2] = col[c2];
-        }
-        // `inv.det() == 0.0` (ols.rs:81): LU of the inverse, singular factorisation -> det 0.
-        // Loci with duplicated allele columns pass the first LU by a rounding residue and are
-        // caught here, exactly as in the reference.
-        {
-            double det = 1.0;
-            bool zero_piv = false;
-#pragma unroll
-            for (int kk = 0; kk < NA; ++kk) {
-                int pi = kk;
-                double pm = fabs(Inv[kk][kk]);
-#pragma unroll
-                for (int i2 = kk + 1; i2 < NA; ++i2) {
-                    const double v = fabs(Inv[i2][kk]);
-                    const bool g = v > pm;
-                    pm = g ? v : pm;
-                    pi = g ? i2 : pi;
-                }
-#pragma unroll
-                for (int i2 = kk + 1; i2 < NA; ++i2) {
-                    const bool sw = (pi == i2);
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) {
-                        const double x1 = Inv[kk][j], x2 = Inv[i2][j];
-                        Inv[kk][j] = sw ? x2 : x1;
-                        Inv[i2][j] = sw ? x1 : x2;
-                    }
-                }
-                const double pvt = Inv[kk][kk];
-                zero_piv = zero_piv || (pvt == 0.0);
-                const double ipv = 1.0 / pvt;
-#pragma unroll
-                for (int i2 = kk + 1; i2 < NA; ++i2) {
-                    const double lf = (pvt != 0.0) ? Inv[i2][kk] * ipv : 0.0;
-                    if (lf != 0.0) {
-#pragma unroll
-                        for (int j = kk + 1; j < NA; ++j) Inv[i2][j] = Inv[i2][j] - lf * Inv[kk][j];
-                    }
-                }
-                det = det * pvt;
-            }
-            if (zero_piv || det == 0.0) singular = true;
-        }
-        const bool ok = alive && !singular; // Err -> the whole locus is dropped (ols.rs:250-253)
-        if (P.t0 == 0) {
-            n_out[l] = ok ? Pn - 1 : 0;
-#pragma unroll
-            for (int r = 1; r < NA; ++r) {
-                const bool on = ok && r < Pn;
-                if (r - 1 < PG_MAX_OUT) {
-                    ids_out[l * PG_MAX_OUT + r - 1] = on ? sel[r] : -1;
-                    mf_out[l * PG_MAX_OUT + r - 1] = on ? pick6(cs, sel[r]) / (double)n : NAN; // ols.rs:266
-                }
-            }
-        }
-#pragma unroll
-        for (int tt = 0; tt < MAXK; ++tt) {
-            if (tt >= k) continue;
-            // X'y with the centred phenotype (slopes are invariant to the shift; it removes the
-            // y-bar^2 cancellation from the residual sum of squares)
-            double xty[NA], b[NA];
-#pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                double v = 0.0;
-                if (r == 0) v = P.sy[tt];
-                else {
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) v = (sel[r] == j) ? xy[j * MAXK + tt] : v;
-                }
-                xty[r] = (r < Pn) ? v : 0.0;
-                b[r] = xty[r];
-            }
-            lu_solve(b);
-            // RSS = y'y - 2 b'X'y + b'(X'X) b: the form that is stationary in b, so the O(cond*eps)
-            // error of the solve enters only to second order
-            double bxy = 0.0;
-#pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                double ab = 0.0;
-#pragma unroll
-                for (int c2 = 0; c2 < NA; ++c2) ab = (r < Pn && c2 < Pn) ? fma(xtx(r, c2), b[c2], ab) : ab;
-                bxy = (r < Pn) ? fma(b[r], 2.0 * xty[r] - ab, bxy) : bxy;
-            }
-            double rss = P.syy[tt] - bxy;
-            rss = rss < 0.0 ? 0.0 : rss;
-            const double ve = rss / ((double)n - (double)Pn); // ols.rs:103
-#pragma unroll
-            for (int r = 1; r < NA; ++r) {
-                if (r - 1 >= PG_MAX_OUT) continue;
-                const bool on = ok && r < Pn;
-                double pv = NAN, bb = NAN;
-                if (on) {
-                    bb = b[r];
-                    const double vb = ve * dinv[r];                                  // ols.rs:111-116
-                    const double tstat = (fabs(bb) <= PG_EPS) ? 0.0 : bb / sqrt(vb); // ols.rs:143-147
-                    if (fabs(tstat) <= PG_EPS) pv = 1.0;
-                    else if (isnan(tstat)) pv = 1.0;
-                    else pv = pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef);
-                }
-                stat_out[(l * PG_MAX_OUT + r - 1) * P.k_total + P.t0 + tt] = bb;
-                pv_out[(l * PG_MAX_OUT + r - 1) * P.k_total + P.t0 + tt] = pv;
-            }
-        }
+    }
+    static_for<2, NA + 1>([&](auto pc) {
+        constexpr int PNc = decltype(pc)::value;
+        if (inr && pn == PNc)
+            ols_close<PNc>(rec, rb, k, ordbits, alive, tcoef, n_out, ids_out, mf_out, stat_out, pv_out, l, P);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
