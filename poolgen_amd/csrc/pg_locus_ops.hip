@@ -363,7 +363,7 @@ __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poiso
         if (OP == OP_OLS) {
             const int f0 = ols_field<K>(d);
             const double c = pickn<NJ>(S.cs, a);
-            if (on) rec[rb + (size_t)f0 * 64] = c;
+            if (on) rec[rb + (size_t)f0 * 64] = c + pz; // the plain column sum / mean (ols.rs:266, correlation_test.rs:119)
 #pragma unroll
             for (int t = 0; t < K; ++t) {
                 const double v = pick_trait<NJ, K>(S.xy, a, t);
@@ -380,7 +380,7 @@ __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poiso
         } else { // OP_PEARSON
             const int f0 = prs_field<K>(d);
             const double c = pickn<NJ>(S.cs, a);
-            if (on) rec[rb + (size_t)f0 * 64] = c;
+            if (on) rec[rb + (size_t)f0 * 64] = c + pz; // the plain column sum / mean (ols.rs:266, correlation_test.rs:119)
 #pragma unroll
             for (int t = 0; t < K; ++t) {
                 const double vx = pick_trait<NJ, K>(S.px, a, t), vxx = pick_trait<NJ, K>(S.pxx, a, t),

@@ -59,7 +59,7 @@ def check_stat_op(gpu, ref_fn, rows_counts, Y, ps, fo, stat_rtol=1e-10, stat_ato
         if na == 0:
             continue
         assert ids[l, :na].tolist() == rid, f"locus {l}: allele order"
-        assert mf[l, :na].tolist() == rmf, f"locus {l}: mean frequency not bit-exact"
+        assert np.array_equal(mf[l, :na], np.asarray(rmf), equal_nan=True), f"locus {l}: mean frequency not bit-exact"
         g, r = stat[l, :na], rs
         err = np.abs(g - r) - stat_rtol * np.abs(r)
         err[np.isnan(g) & np.isnan(r)] = 0.0
@@ -137,7 +137,8 @@ def test_reference_unit_test_vectors_through_the_gpu(engine, oracle):
 
 
 @pytest.mark.parametrize("n,L,kw", [(200, 3000, dict()), (33, 2000, dict(maf=0.05)), (100, 2500, dict(remove_ns=False)),
-                                    (7, 1500, dict(min_cov=30))])
+                                    (7, 1500, dict(min_cov=30)), (24, 1500, dict(min_cov=0, miss=0.2)),
+                                    (16, 700, dict(min_cov=0, miss=0.5, remove_ns=False))])
 def test_synthetic_batches(engine, oracle, n, L, kw):
     from poolgen_amd import synth
     counts = synth.sync_counts(L, n, "cuda", seed=99)
@@ -148,6 +149,7 @@ def test_synthetic_batches(engine, oracle, n, L, kw):
     counts[::97, :, 5] = 3
     counts[5::211, :, 1] = 0; counts[5::211, :, 2] = 0       # monomorphic -> dropped (< 2 alleles)
     counts[11::307, 0, :] = 0                                # a pool without coverage -> dropped by min depth
+    counts[17::131, :min(6, n - 1), :] = 0                   # several uncovered pools: the missingness threshold
     counts[13::401, :, 0] = 10; counts[13::401, :, 1] = 10; counts[13::401, :, 2] = 0   # constant frequency: singular
     Y = synth.phenotypes(synth.genotype_matrix(64, n, "cuda", seed=99), n, k=3, seed=4)
     ps = np.linspace(10, 30, n)
@@ -162,4 +164,7 @@ def test_synthetic_batches(engine, oracle, n, L, kw):
         assert n_out[l] == a
         if a:
             assert ids[l, :min(a, 5)].tolist() == rid.tolist()[:5]
+            if np.isnan(rc):   # an uncovered pool (allowed by max_missingness_rate) makes the table NaN on both sides
+                assert np.isnan(chi2[l]) and np.isnan(pv[l]) and np.isnan(rp)
+                continue
             assert abs(chi2[l] - rc) <= 1e-10 * max(1.0, abs(rc)) and abs(pv[l] - rp) <= 1e-10
