@@ -267,20 +267,23 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     // instantiated once per wave with COMPILE-TIME tile coordinates, so every fragment address is
     // "lane base + immediate" (no per-item address arithmetic, A/B pairs merge into ds_read2_b64).
     // W = -1: run-time tile tables, any shape.
-    auto run = [&](auto wc) {
+    // TPW = tile slots per wave actually run (2..6): a work-group with few tiles (small n, or a
+    // diagonal block pair) would otherwise spend most of its matrix-core time on dead slots.
+    auto run = [&](auto wc, auto tc) {
         constexpr int W = decltype(wc)::value;
+        constexpr int TPW = decltype(tc)::value;
         constexpr int KS = KIN_KC / 4;
-        constexpr int NQ = KS * KIN_TPW; // items per stage
+        constexpr int NQ = KS * TPW; // items per stage
         constexpr int D = KIN_RING_D, R = KIN_RING_D + 1;
         static_assert(NQ % R == 0 && NQ > 2 * D, "ring indexing assumes the stage length is a multiple of the ring");
-        double4_t acc[KIN_TPW];
+        double4_t acc[TPW];
 #pragma unroll
-        for (int u = 0; u < KIN_TPW; ++u) acc[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int u = 0; u < TPW; ++u) acc[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
         double fa[R], fb[R];
         const double *lanebase = lds + kq * ldsld + fi; // + buffer + 4 s ldsld + tile column
         auto frag_load = [&](const double *bufbase, auto qc) {
             constexpr int q = decltype(qc)::value;
-            constexpr int s = q / KIN_TPW, u = q % KIN_TPW;
+            constexpr int s = q / TPW, u = q % TPW;
             if constexpr (W >= 0) {
                 if constexpr (W + KIN_WAVES * u >= 91) return; // no such tile: the slot is simply skipped
                 constexpr int t = kin_slot_tile(W, u, 13);
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         };
         auto mfma_item = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            constexpr int u = q % KIN_TPW;
+            constexpr int u = q % TPW;
             if constexpr (W >= 0 && W + KIN_WAVES * u >= 91) return;
             acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q % R], fb[q % R], acc[u], 0, 0, 0);
         };
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         // ---- write this workgroup's partial tiles -----------------------------------------------
         // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
         double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
-        static_for<KIN_TPW>([&](auto uc) {
+        static_for<TPW>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             bool on;
             int r0, c0;
@@ -344,29 +347,36 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     };
     if constexpr (SPEC13) {
         switch (wave) {
-        case 0: run(std::integral_constant<int, 0>{}); break;
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 3: run(std::integral_constant<int, 3>{}); break;
-        case 4: run(std::integral_constant<int, 4>{}); break;
-        case 5: run(std::integral_constant<int, 5>{}); break;
-        case 6: run(std::integral_constant<int, 6>{}); break;
+        case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 5: run(std::integral_constant<int, 5>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 6: run(std::integral_constant<int, 6>{}, std::integral_constant<int, KIN_TPW>{}); break;
 #if KIN_WAVES_DEF == 8
-        default: run(std::integral_constant<int, 7>{}); break;
+        default: run(std::integral_constant<int, 7>{}, std::integral_constant<int, KIN_TPW>{}); break;
 #else
-        case 7: run(std::integral_constant<int, 7>{}); break;
-        case 8: run(std::integral_constant<int, 8>{}); break;
-        case 9: run(std::integral_constant<int, 9>{}); break;
-        case 10: run(std::integral_constant<int, 10>{}); break;
-        case 11: run(std::integral_constant<int, 11>{}); break;
-        case 12: run(std::integral_constant<int, 12>{}); break;
-        case 13: run(std::integral_constant<int, 13>{}); break;
-        case 14: run(std::integral_constant<int, 14>{}); break;
-        default: run(std::integral_constant<int, 15>{}); break;
+        case 7: run(std::integral_constant<int, 7>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 9: run(std::integral_constant<int, 9>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 10: run(std::integral_constant<int, 10>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 11: run(std::integral_constant<int, 11>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 12: run(std::integral_constant<int, 12>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 13: run(std::integral_constant<int, 13>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        case 14: run(std::integral_constant<int, 14>{}, std::integral_constant<int, KIN_TPW>{}); break;
+        default: run(std::integral_constant<int, 15>{}, std::integral_constant<int, KIN_TPW>{}); break;
 #endif
         }
     } else {
-        run(std::integral_constant<int, -1>{});
+        constexpr std::integral_constant<int, -1> any{};
+        switch ((ntiles + KIN_WAVES - 1) / KIN_WAVES) {
+        case 0: case 1: case 2: run(any, std::integral_constant<int, 2>{}); break;
+        case 3: run(any, std::integral_constant<int, 3>{}); break;
+        case 4: run(any, std::integral_constant<int, 4>{}); break;
+        case 5: run(any, std::integral_constant<int, 5>{}); break;
+        default: run(any, std::integral_constant<int, KIN_TPW>{}); break;
+        }
     }
 }
 
