@@ -49,6 +49,7 @@ struct pg_ctx {
     int spec_n = 0, spec_k = 0;
     bool spec_valid = false;
     bool st_Y_matches_ph = false;
+    std::vector<double> st_Y;    // phenotypes of the last m = 0 covariate state (lets an identical call skip the upload)
     // small pinned host staging
     void *pin = nullptr;
     size_t pin_bytes = 0;

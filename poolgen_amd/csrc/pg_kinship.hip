@@ -16,6 +16,7 @@
 // of G.  Each workgroup finally writes its partial tiles to a slab; a second tiny kernel sums
 // the slabs in a fixed order (deterministic, no atomics) and mirrors the lower triangle.
 #include "pg_common.h"
+#include <cstring>
 #include <utility>
 
 namespace {
@@ -380,20 +381,30 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     }
 }
 
-// Sum the per-workgroup slabs in slab order and mirror: S[i][j] = S[j][i] = sum_w slab_w[i][j]
-// for i <= j (only upper-triangular tiles were written).
-__global__ void k_kinship_reduce(const double *__restrict__ slabs, int nslabs, int npad, int n,
-                                 double add_const, double *__restrict__ S) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// Sum the per-workgroup slabs in a FIXED order and mirror: S[i][j] = S[j][i] = sum_w slab_w[i][j] for
+// i <= j (only upper-triangular tiles were written).  256 threads = 64 columns x 4 slab groups: group g
+// adds slabs g, g+4, ... in order, then (g0 + g1) + (g2 + g3) -- deterministic, no atomics, and four
+// times the loads in flight of a one-thread-per-entry loop (the slabs are 88 MB at n = 200).
+__global__ __launch_bounds__(256) void k_kinship_reduce(const double *__restrict__ slabs, int nslabs, int npad, int n,
+                                                        double add_const, double *__restrict__ S) {
+    __shared__ double part[4][64];
+    const int jj = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
     const int i = blockIdx.y;
-    if (i >= n || j >= n || i > j) return;
-    const size_t off = (size_t)i * npad + j;
-    const size_t stride = (size_t)npad * npad;
+    const bool on = i < n && j < n && i <= j;
     double s = 0.0;
-    for (int w = 0; w < nslabs; ++w) s += slabs[w * stride + off];
-    s += add_const;
-    S[(size_t)i * n + j] = s;
-    S[(size_t)j * n + i] = s;
+    if (on) {
+        const size_t off = (size_t)i * npad + j;
+        const size_t stride = (size_t)npad * npad;
+        for (int w = grp; w < nslabs; w += 4) s += slabs[w * stride + off];
+    }
+    part[grp][jj] = s;
+    __syncthreads();
+    if (on && grp == 0) {
+        const double t = ((part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj])) + add_const;
+        S[(size_t)i * n + j] = t;
+        S[(size_t)j * n + i] = t;
+    }
 }
 
 } // namespace
@@ -474,7 +485,7 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     }
     PG_HIP(ctx, hipGetLastError());
     pg_prof_begin(ctx, PG_K_KINSHIP_REDUCE);
-    hipLaunchKernelGGL(k_kinship_reduce, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_kinship_reduce, dim3((n + 63) / 64, n), dim3(256), 0, ctx->stream,
                        P.slabs, nslab, P.npad, n, add_intercept ? 1.0 : 0.0, S);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipGetLastError());
@@ -497,6 +508,9 @@ extern "C" int pg_gp_xxt_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
 extern "C" int pg_set_phenotypes(pg_ctx *ctx, int n, const double *Y, int k) {
     if (!ctx) return PG_ERR_INVALID;
     ctx->spec_valid = false;
+    if (n > 0 && Y && ctx->ph_n == n && ctx->ph_k == k && ctx->ph_ytil_dev && ctx->ph_Y.size() == (size_t)n * k &&
+        std::memcmp(ctx->ph_Y.data(), Y, sizeof(double) * n * k) == 0)
+        return PG_OK; // same phenotypes as last time: the centred copy is already on the device
     ctx->ph_n = 0; ctx->ph_k = 0; ctx->ph_Y.clear();
     if (n == 0 || !Y) return PG_OK; // switched off
     PG_CHECK(ctx, n >= 2 && k >= 1, "set_phenotypes: bad shape n=%d k=%d", n, k);
