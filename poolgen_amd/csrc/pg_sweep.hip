@@ -363,54 +363,52 @@ extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total,
     PG_HIP(ctx, hipMemcpyAsync(K.data(), S_dev, sizeof(double) * n * n, hipMemcpyDeviceToHost,
                                ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const double inv_p = (double)p_total;
-    for (auto &x : K) x = x / inv_p; // kinship = G G^T / p  (gwas/ols.rs:295)
+    const double pd = (double)p_total;
+    auto scale_K = [&]() { for (auto &x : K) x = x / pd; }; // kinship = G G^T / p  (gwas/ols.rs:295)
     int m = force_m;
     if (force_m < 0 && !evals_out) {
-        // Fast exit of the n_eigenvecs rule (gwas/ols.rs:297-311): with eigenvalues descending,
+        // Fast exits of the n_eigenvecs rule (gwas/ols.rs:297-311): with eigenvalues descending,
         // cum[0] = lambda_1 / sum(lambda) >= threshold already gives m = 0, and sum(lambda) is
-        // trace(K).  lambda_1 by power iteration (the uncentred kinship has lambda_2/lambda_1
-        // ~ 1e-3, a handful of n^2 mat-vecs) instead of the O(n^3) decomposition.  Anything not
-        // clearly above the threshold falls through to the full solver.
-        double tr = 0.0;
+        // trace(K).  Both ratios are scale-free, so they are formed on S itself.
+        // (1) lambda_1 >= v'Kv for ANY unit v: with v = 1/sqrt(n) that is sum(K)/n, one pass over K,
+        //     and for an uncentred kinship it is already within ~1e-3 of lambda_1.
+        // (2) lambda_1 by power iteration (lambda_2/lambda_1 ~ 1e-3: a handful of n^2 mat-vecs) instead
+        //     of the O(n^3) decomposition.  Anything not clearly above the threshold falls through to
+        //     the full solver.
+        double tr = 0.0, tot = 0.0;
         for (int i = 0; i < n; ++i) tr += K[(size_t)i * n + i];
-        // lambda_1 >= v'Kv for ANY unit v: with v = 1/sqrt(n) that is sum(K)/n, one pass over K, and for
-        // an uncentred kinship it is already within ~1e-3 of lambda_1 -- usually enough to decide m = 0
-        {
-            double tot = 0.0;
-            for (size_t i = 0; i < (size_t)n * n; ++i) tot += K[i];
-            if (tr > 0.0 && (tot / n) / tr >= var_explained + 1e-9) {
-                if (m_out) *m_out = 0;
-                if (K_out) std::memcpy(K_out, K.data(), sizeof(double) * n * n);
-                return pg_covariates_set(ctx, n, nullptr, 0, Y, k);
+        for (size_t i = 0; i < (size_t)n * n; ++i) tot += K[i];
+        bool zero = tr > 0.0 && (tot / n) / tr >= var_explained + 1e-9;
+        if (!zero) {
+            std::vector<double> v(n, 1.0 / std::sqrt((double)n)), w(n);
+            double lam = 0.0, prev = -1.0;
+            bool conv = false;
+            for (int it = 0; it < 60 && !conv; ++it) {
+                double nrm = 0.0, rq = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double sacc = 0.0;
+                    const double *row = &K[(size_t)i * n];
+                    for (int j = 0; j < n; ++j) sacc += row[j] * v[j];
+                    w[i] = sacc;
+                    rq += sacc * v[i];
+                    nrm += sacc * sacc;
+                }
+                nrm = std::sqrt(nrm);
+                if (!(nrm > 0.0)) break;
+                for (int i = 0; i < n; ++i) v[i] = w[i] / nrm;
+                lam = rq;
+                conv = std::fabs(lam - prev) <= 1e-14 * std::fabs(lam);
+                prev = lam;
             }
+            zero = conv && tr > 0.0 && lam / tr >= var_explained + 1e-9;
         }
-        std::vector<double> v(n, 1.0 / std::sqrt((double)n)), w(n);
-        double lam = 0.0, prev = -1.0;
-        bool conv = false;
-        for (int it = 0; it < 60 && !conv; ++it) {
-            double nrm = 0.0, rq = 0.0;
-            for (int i = 0; i < n; ++i) {
-                double s = 0.0;
-                const double *row = &K[(size_t)i * n];
-                for (int j = 0; j < n; ++j) s += row[j] * v[j];
-                w[i] = s;
-                rq += s * v[i];
-                nrm += s * s;
-            }
-            nrm = std::sqrt(nrm);
-            if (!(nrm > 0.0)) break;
-            for (int i = 0; i < n; ++i) v[i] = w[i] / nrm;
-            lam = rq;
-            conv = std::fabs(lam - prev) <= 1e-14 * std::fabs(lam);
-            prev = lam;
-        }
-        if (conv && tr > 0.0 && lam / tr >= var_explained + 1e-9) {
+        if (zero) {
             if (m_out) *m_out = 0;
-            if (K_out) std::memcpy(K_out, K.data(), sizeof(double) * n * n);
+            if (K_out) { scale_K(); std::memcpy(K_out, K.data(), sizeof(double) * n * n); }
             return pg_covariates_set(ctx, n, nullptr, 0, Y, k);
         }
     }
+    scale_K();
     const bool need_vec_first = force_m > 0;
     if (need_vec_first) V.resize((size_t)n * n);
     if (pg_sym_eig(K.data(), n, ev.data(), need_vec_first ? V.data() : nullptr, need_vec_first) != 0)

@@ -22,15 +22,16 @@ def shard_range(p_total: int, rank: int, world: int):
 
 
 def ols_with_covariate_sharded(engine, G_local: torch.Tensor, p_total: int, Y, var_explained=0.75,
-                               force_m: int = -1, n: int | None = None, out=None, group=None):
-    """One step of the sharded path.  Returns (m, K, beta_local, var_local, pval_local)."""
+                               force_m: int = -1, n: int | None = None, out=None, group=None, want_K: bool = False):
+    """One step of the sharded path.  Returns (m, K, beta_local, var_local, pval_local); K is None unless
+    want_K (the caller rarely needs the kinship matrix itself)."""
     if hasattr(engine, "set_phenotypes"):
         # POOLGEN_TWO_PASS=1 keeps the plain two-pass path (kinship, then a full sweep) for measurement
         engine.set_phenotypes(None if os.environ.get("POOLGEN_TWO_PASS") == "1" or force_m > 0 else Y)  # lets the kinship pass pre-compute the intercept-only fits
     S = engine.kinship_partial(G_local, n)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
-    m, K, _ = engine.kinship_set(S, p_total, Y, var_explained, force_m)
+    m, K, _ = engine.kinship_set(S, p_total, Y, var_explained, force_m, want_K=want_K)
     k = 1 if getattr(Y, "ndim", 1) == 1 else Y.shape[1]
     beta, var, pval = engine.ols_sweep(G_local, k, n, out)
     return m, K, beta, var, pval

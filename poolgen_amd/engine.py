@@ -114,16 +114,17 @@ class Engine:
         return S
 
     def kinship_set(self, S: torch.Tensor, p_total: int, Y, var_explained: float = 0.75,
-                    force_m: int = -1, want_evals: bool = False):
+                    force_m: int = -1, want_evals: bool = False, want_K: bool = True):
         """K = S / p_total, eigen rule, covariates, projected phenotypes.  Returns (m, K, evals);
-        evals is None unless want_evals (asking for them forces the full eigen-decomposition)."""
+        evals is None unless want_evals (asking for them forces the full eigen-decomposition); K is None
+        unless want_K."""
         n = S.shape[0]
         Yh = _host_f64(Y).reshape(n, -1)
-        K = np.empty((n, n)); m = C.c_int()
+        K = np.empty((n, n)) if want_K else None; m = C.c_int()
         ev = np.empty(n) if want_evals else None
         self._check(self._lib.pg_kinship_set(self._ctx, self._dev(S, torch.float64), int(p_total), n,
                                              Yh.ctypes.data, Yh.shape[1], float(var_explained),
-                                             int(force_m), C.byref(m), K.ctypes.data,
+                                             int(force_m), C.byref(m), K.ctypes.data if want_K else None,
                                              ev.ctypes.data if want_evals else None),
                     "pg_kinship_set")
         return m.value, K, ev

@@ -25,7 +25,7 @@ class OracleEngine:
         Gn = G.numpy()
         return torch.from_numpy(self.o.kinship(Gn, threads=1) * Gn.shape[0])
 
-    def kinship_set(self, S, p_total, Y, var_explained=0.75, force_m=-1):
+    def kinship_set(self, S, p_total, Y, var_explained=0.75, force_m=-1, want_K=True):
         K = S.numpy() / p_total
         ev, V = self.o.sym_eig(K)
         m = force_m if force_m >= 0 else self.o.n_eigenvecs(ev, var_explained)
@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
     lo, hi = shard_range(G.shape[0], rank, world)
     eng = OracleEngine()
     m, K, beta, var, pval = ols_with_covariate_sharded(eng, torch.from_numpy(G[lo:hi].copy()), G.shape[0], Y,
-                                                       var_explained=0.995)
+                                                       var_explained=0.995, want_K=True)
     q.put((rank, lo, hi, m, K, beta.numpy(), var.numpy(), pval.numpy()))
     dist.barrier()
     dist.destroy_process_group()
