@@ -143,6 +143,22 @@ int pg_pearson_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int
 int pg_chisq_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n,
                        const double *pool_sizes, const pg_filter *filter, int32_t *n_out_dev,
                        int32_t *allele_ids_dev, double *chi2_dev, double *pval_dev);
+/* The loader, FileSyncPhen::load + into_genotypes_and_phenotypes (base/sync.rs:972-1180), on counts that
+ * are already in HBM: per locus LocusCounts::filter (:195-303) -> to_frequencies over the surviving
+ * alleles (:166-192) -> with keep_p_minus_1 sort by decreasing frequency and drop the first allele
+ * (:1033-1037).  One column of G per surviving allele, loci in the caller's order (`order_dev`: a
+ * permutation of 0..L-1, e.g. the (chromosome, position) sort of :1092-1101; NULL = input order).
+ * Two calls because the column count is a result:
+ *   pg_load_plan_dev  runs the filter for every locus and returns the number of columns p;
+ *   pg_load_emit_dev  (directly afterwards, same ctx) writes G (p x ld, locus-major, pools kept =
+ *                     pool_map[i] >= 0 at row position pool_map[i]; NULL = all pools), and for every
+ *                     column the locus it came from and its allele (index into "ATCGND").
+ * The coverage matrix the reference also fills (:1157-1167) is not produced (nothing on this path
+ * reads it). */
+int pg_load_plan_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const double *pool_sizes,
+                     const pg_filter *filter, int keep_p_minus_1, const int64_t *order_dev, int64_t *p_out);
+int pg_load_emit_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,
+                     int64_t *col_locus_dev, int32_t *col_allele_dev);
 /* Host-buffer forms of the three batch operators (H2D/D2H inside). */
 int pg_ols_iter_batch(pg_ctx *ctx, const uint32_t *counts, int64_t L, int n,
                       const double *pool_sizes, const pg_filter *filter, const double *Y, int k,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "pg_ols_iter_batch_dev": (_i, _batch),
     "pg_pearson_batch_dev": (_i, _batch),
     "pg_chisq_batch_dev": (_i, [_vp, _vp, _i64, _i, _vp, _pf, _vp, _vp, _vp, _vp]),
+    "pg_load_plan_dev": (_i, [_vp, _vp, _i64, _i, _vp, _pf, _i, _vp, _vp]),
+    "pg_load_emit_dev": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "pg_ols_iter_batch": (_i, _batch),
     "pg_pearson_batch": (_i, _batch),
     "pg_chisq_batch": (_i, [_vp, _vp, _i64, _i, _vp, _pf, _vp, _vp, _vp, _vp]),

@@ -196,63 +196,4 @@ SyncBatch parse_sync_file(const std::string &fname, int n_threads) {
     return all;
 }
 
-std::vector<int> filter_to_frequencies(const uint32_t *counts, int n, const FilterStats &f,
-                                       bool keep_p_minus_1, std::vector<double> &freq) {
-    int ids[6], a = 0;
-    for (int j = 0; j < 6; ++j)
-        if (!(f.remove_ns && j == 4)) ids[a++] = j; // sync.rs:200-213
-    double min_cov = 0.0;
-    int n_missing = 0;
-    std::vector<double> rs5(n);
-    for (int i = 0; i < n; ++i) {
-        double s = 0.0;
-        for (int j = 0; j < a; ++j) s = s + (double)counts[i * 6 + ids[j]];
-        rs5[i] = s;
-        if (i == 0 || s < min_cov) min_cov = s;
-        if (s == 0.0) ++n_missing;
-    }
-    if (min_cov < (double)f.min_coverage_depth) return {}; // sync.rs:227
-    double total = 0.0;
-    for (int i = 0; i < n; ++i) total = total + f.pool_sizes[i];
-    std::vector<int> kept;
-    for (int j = 0; j < a; ++j) {
-        double q = 0.0;
-        for (int i = 0; i < n; ++i) {
-            if (rs5[i] == 0.0) continue; // NaN frequency contributes 0 (sync.rs:263-265)
-            const double fr = (double)counts[i * 6 + ids[j]] / rs5[i];
-            q += fr * (f.pool_sizes[i] / total);
-        }
-        if ((q < f.min_allele_frequency) | (q > (1.00 - f.min_allele_frequency))) continue;
-        kept.push_back(ids[j]);
-    }
-    if (kept.size() < 2) return {};
-    if (n_missing == n) return {};
-    if (((double)n_missing / (double)n) > f.max_missingness_rate) return {};
-    const int na = (int)kept.size();
-    freq.assign((size_t)n * na, 0.0);
-    for (int i = 0; i < n; ++i) {
-        double rs = 0.0;
-        for (int j = 0; j < na; ++j) rs = rs + (double)counts[i * 6 + kept[j]];
-        for (int j = 0; j < na; ++j) freq[(size_t)i * na + j] = (rs == 0.0) ? NAN : (double)counts[i * 6 + kept[j]] / rs;
-    }
-    if (keep_p_minus_1) { // sort descending (stable) and drop the most frequent allele (sync.rs:1033-1037)
-        std::vector<double> cs(na, 0.0);
-        for (int j = 0; j < na; ++j)
-            for (int i = 0; i < n; ++i)
-                if (!std::isnan(freq[(size_t)i * na + j])) cs[j] = cs[j] + freq[(size_t)i * na + j];
-        std::vector<int> idx(na);
-        for (int j = 0; j < na; ++j) idx[j] = j;
-        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return cs[x] > cs[y]; });
-        std::vector<double> f2((size_t)n * (na - 1));
-        std::vector<int> k2;
-        for (int r = 1; r < na; ++r) {
-            k2.push_back(kept[idx[r]]);
-            for (int i = 0; i < n; ++i) f2[(size_t)i * (na - 1) + r - 1] = freq[(size_t)i * na + idx[r]];
-        }
-        freq.swap(f2);
-        kept.swap(k2);
-    }
-    return kept;
-}
-
 } // namespace pgh

@@ -35,19 +35,6 @@ struct SyncBatch {
 // (helpers.rs:74-91); loci come back in file order.  Comment lines are skipped (sync.rs:111-114).
 SyncBatch parse_sync_file(const std::string &fname, int n_threads);
 
-struct FilterStats {
-    bool remove_ns = true;
-    uint64_t min_coverage_depth = 1;
-    double min_allele_frequency = 0.001;
-    double max_missingness_rate = 0.0;
-    std::vector<double> pool_sizes;
-};
-// LocusCounts::filter + to_frequencies (+ sort desc & drop major when keep_p_minus_1) for one
-// locus (sync.rs:195-303, :166-192, :1024-1037).  Returns kept allele ids (0..5 into "ATCGND") in
-// output order; freq is n x a row-major.  Empty result = locus dropped.
-std::vector<int> filter_to_frequencies(const uint32_t *counts, int n, const FilterStats &f,
-                                       bool keep_p_minus_1, std::vector<double> &freq);
-
 extern const char ALLELES[7];
 
 } // namespace pgh

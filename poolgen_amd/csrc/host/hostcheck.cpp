@@ -1,7 +1,7 @@
 // hostcheck.cpp -- GPU-free driver over the CLI's host logic, used by the CPU test-suite:
 //   hostcheck fmt                      : stdin "x n_digits" per line -> "display(x) roundup_own(x,n)"
 //   hostcheck phen <file> <delim> <name_col> <size_col> <c1,c2,..>
-//   hostcheck load <sync> <threads> <keep_p_minus_1> <remove_ns> <min_cov> <maf> <miss> <pool sizes,..>
+//   hostcheck parse <sync> <threads>   : "L n" then one line per locus: chrom pos counts[n*6]
 #include "host_util.h"
 #include <cstdio>
 #include <cstdlib>
@@ -34,22 +34,12 @@ int main(int argc, char **argv) {
                 for (int j = 0; j < ph.k; ++j) std::cout << " " << rust_display(ph.phen[(size_t)i * ph.k + j]);
                 std::cout << "\n";
             }
-        } else if (mode == "load") {
+        } else if (mode == "parse") {
             const SyncBatch sb = parse_sync_file(argv[2], std::atoi(argv[3]));
-            FilterStats fs;
-            const bool keep1 = std::atoi(argv[4]) != 0;
-            fs.remove_ns = std::atoi(argv[5]) != 0;
-            fs.min_coverage_depth = std::strtoull(argv[6], nullptr, 10);
-            fs.min_allele_frequency = std::strtod(argv[7], nullptr);
-            fs.max_missingness_rate = std::strtod(argv[8], nullptr);
-            for (auto &t : splitc(argv[9])) fs.pool_sizes.push_back(std::strtod(t.c_str(), nullptr));
-            std::vector<double> freq;
             std::cout << sb.size() << " " << sb.n << "\n";
             for (int64_t l = 0; l < sb.size(); ++l) {
-                const std::vector<int> al = filter_to_frequencies(&sb.counts[(size_t)l * sb.n * 6], sb.n, fs, keep1, freq);
-                std::cout << sb.chrom[l] << " " << sb.pos[l] << " ";
-                for (int a : al) std::cout << ALLELES[a];
-                for (size_t i = 0; i < (al.empty() ? 0 : freq.size()); ++i) { char b[40]; std::snprintf(b, sizeof b, " %a", freq[i]); std::cout << b; }
+                std::cout << sb.chrom[l] << " " << sb.pos[l];
+                for (int i = 0; i < sb.n * 6; ++i) std::cout << " " << sb.counts[(size_t)l * sb.n * 6 + i];
                 std::cout << "\n";
             }
         } else return 2;

@@ -6,6 +6,7 @@
 // of scope and reported as such.
 #include "host_util.h"
 #include "../../../include/poolgen_hip.h"
+#include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -226,47 +227,68 @@ static int run(int argc, char **argv) {
     }
 
     // ---------------- ols_iter_with_kinship (main.rs:280-298) -------------------------------------
-    FilterStats fs;
-    fs.remove_ns = !a.keep_ns;
-    fs.min_coverage_depth = a.min_coverage_depth;
-    fs.min_allele_frequency = a.min_allele_frequency;
-    fs.max_missingness_rate = a.max_missingness_rate;
-    fs.pool_sizes = ph.pool_sizes;
-    // load(): filter + frequencies per locus, then sort by (chromosome, position) (sync.rs:1092-1101)
+    // load(): filter + frequencies per locus, then sort by (chromosome, position) (sync.rs:1092-1101).  The
+    // host only sorts the locus order; filter, frequencies and the column layout run on the GPU from the
+    // parsed counts (pg_load_plan_dev / pg_load_emit_dev), and G never exists in host memory.
     std::vector<int64_t> order(L);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
         const int c = sb.chrom[x].compare(sb.chrom[y]);
         return c != 0 ? c < 0 : sb.pos[x] < sb.pos[y];
     });
-    // labels carry the leading "intercept" entry of the reference matrix (sync.rs:1121-1126)
-    std::vector<std::string> lab_chr{"intercept"}, lab_al{"intercept"};
-    std::vector<uint64_t> lab_pos{0};
     const std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
     if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
     const int n2 = (int)keep.size();
     const int64_t ld = n2 + (n2 & 1);
-    std::vector<double> G, freq;
-    for (int64_t oi = 0; oi < L; ++oi) {
-        const int64_t l = order[oi];
-        const std::vector<int> al = filter_to_frequencies(&sb.counts[(size_t)l * n * 6], n, fs, a.keep_p_minus_1, freq);
-        const int na = (int)al.size();
-        for (int j = 0; j < na; ++j) {
-            lab_chr.push_back(sb.chrom[l]); lab_pos.push_back(sb.pos[l]); lab_al.push_back(std::string(1, ALLELES[al[j]]));
-            const size_t base = G.size();
-            G.resize(base + ld, 0.0);
-            for (int i = 0; i < n2; ++i) G[base + i] = freq[(size_t)keep[i] * na + j];
-        }
-    }
-    const int64_t p = (int64_t)lab_chr.size() - 1;
+    std::vector<int32_t> pool_map(n, -1);
+    for (int i = 0; i < n2; ++i) pool_map[keep[i]] = i;
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    };
+    uint32_t *counts_dev = nullptr;
+    int64_t *order_dev = nullptr;
+    hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * sb.counts.size()), "device memory for the counts");
+    hip_ok(hipMalloc((void **)&order_dev, sizeof(int64_t) * L), "device memory");
+    hip_ok(hipMemcpy(counts_dev, sb.counts.data(), sizeof(uint32_t) * sb.counts.size(), hipMemcpyHostToDevice), "H2D counts");
+    hip_ok(hipMemcpy(order_dev, order.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice), "H2D order");
+    int64_t p = 0;
+    gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, L, n, ph.pool_sizes.data(), &flt, a.keep_p_minus_1 ? 1 : 0, order_dev, &p),
+           "load");
     if (p <= 0) throw std::runtime_error("no loci passed the filters");
+    double *G_dev = nullptr, *out_dev = nullptr;
+    int64_t *col_locus_dev = nullptr;
+    int32_t *col_allele_dev = nullptr;
+    hip_ok(hipMalloc((void **)&G_dev, sizeof(double) * (size_t)p * ld), "device memory for the genotype matrix");
+    hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * p), "device memory");
+    hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * p), "device memory");
+    gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G_dev, ld, col_locus_dev, col_allele_dev), "load");
+    hip_ok(hipFree(counts_dev), "free");
+    hip_ok(hipFree(order_dev), "free");
+    std::vector<int64_t> col_locus(p);
+    std::vector<int32_t> col_allele(p);
+    hip_ok(hipMemcpy(col_locus.data(), col_locus_dev, sizeof(int64_t) * p, hipMemcpyDeviceToHost), "D2H labels");
+    hip_ok(hipMemcpy(col_allele.data(), col_allele_dev, sizeof(int32_t) * p, hipMemcpyDeviceToHost), "D2H labels");
+    // labels carry the leading "intercept" entry of the reference matrix (sync.rs:1121-1126)
+    std::vector<std::string> lab_chr{"intercept"}, lab_al{"intercept"};
+    std::vector<uint64_t> lab_pos{0};
+    lab_chr.reserve(p + 1); lab_al.reserve(p + 1); lab_pos.reserve(p + 1);
+    for (int64_t c = 0; c < p; ++c) {
+        lab_chr.push_back(sb.chrom[col_locus[c]]); lab_pos.push_back(sb.pos[col_locus[c]]);
+        lab_al.push_back(std::string(1, ALLELES[col_allele[c]]));
+    }
     std::vector<double> Y;
     for (int i : keep) for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]);
     if (!a.output.empty()) { FILE *t = create_new(a.output); fclose(t); ::unlink(a.output.c_str()); } // ols.rs:285
     std::vector<double> beta((size_t)p * k), var((size_t)p * k), pval((size_t)p * k);
     int m = 0;
-    gpu.ok(pg_ols_kinship(gpu.c, G.data(), p, n2, ld, Y.data(), k, a.xxt, -1, &m, nullptr, beta.data(), var.data(),
-                          pval.data()), "ols_iter_with_kinship");
+    hip_ok(hipMalloc((void **)&out_dev, sizeof(double) * 3 * (size_t)p * k), "device memory for the results");
+    gpu.ok(pg_ols_kinship_dev(gpu.c, G_dev, p, n2, ld, Y.data(), k, a.xxt, -1, &m, nullptr, out_dev, out_dev + (size_t)p * k,
+                              out_dev + 2 * (size_t)p * k), "ols_iter_with_kinship");
+    gpu.ok(pg_synchronize(gpu.c), "ols_iter_with_kinship");
+    hip_ok(hipMemcpy(beta.data(), out_dev, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
+    hip_ok(hipMemcpy(var.data(), out_dev + (size_t)p * k, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
+    hip_ok(hipMemcpy(pval.data(), out_dev + 2 * (size_t)p * k, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
+    (void)hipFree(G_dev); (void)hipFree(out_dev); (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
     std::string out = a.output;
     if (out.empty()) // ols.rs:393-398
         out = basename_no_ext(a.fname) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";

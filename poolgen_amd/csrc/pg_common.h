@@ -49,6 +49,13 @@ struct pg_ctx {
     int spec_n = 0, spec_k = 0;
     bool spec_valid = false;
     bool st_Y_matches_ph = false;
+    // loader plan (pg_load_plan_dev -> pg_load_emit_dev); lives in ws, so any other ws user invalidates it
+    bool load_valid = false;
+    const uint32_t *load_counts = nullptr;
+    const int64_t *load_order = nullptr;
+    int64_t load_L = 0, load_total = 0, load_nunits = 0;
+    int load_n = 0, load_kpm1 = 0, load_pshift = 0;
+    size_t load_off_flags = 0, load_off_local = 0, load_off_blockoff = 0, load_off_poolmap = 0;
     std::vector<double> st_Y;    // phenotypes of the last m = 0 covariate state (lets an identical call skip the upload)
     // small pinned host staging
     void *pin = nullptr;

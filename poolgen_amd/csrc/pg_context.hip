@@ -85,6 +85,7 @@ extern "C" int pg_synchronize(pg_ctx *ctx) {
 }
 
 int pg_ws_reserve(pg_ctx *ctx, size_t bytes) {
+    ctx->load_valid = false; // whoever asks for the workspace is about to overwrite it
     if (bytes <= ctx->ws_bytes) return PG_OK;
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->ws) PG_HIP(ctx, hipFree(ctx->ws));

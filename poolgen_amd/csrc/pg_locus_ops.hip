@@ -40,7 +40,7 @@ constexpr int LO_TILEB = 64 * LO_PITCH;   // bytes per wave
 constexpr int NA = 6;                     // sync alleles
 constexpr int MAXK = 2;                   // traits per launch (the host loops over trait pairs)
 
-enum { OP_OLS = 0, OP_PEARSON = 1, OP_CHISQ = 2 };
+enum { OP_OLS = 0, OP_PEARSON = 1, OP_CHISQ = 2, OP_LOAD = 3 }; // OP_LOAD: filter decisions + column order only (the loader)
 
 struct LocusParams {
     int64_t L;
@@ -48,6 +48,7 @@ struct LocusParams {
     int k_total, t0; // output layout: trait t0 + tt of k_total
     int remove_ns;
     int pshift;      // log2(period), see k_locus_first / unit_slot
+    int sort_desc;   // OP_LOAD: order the surviving alleles by decreasing column sum (--keep-p-minus-1)
     double min_cov, maf, max_miss;
     int tdf, ntcoef;     // t-test degrees of freedom (OLS: n-1, Pearson: n-2)
     double syy[MAXK];    // OLS: sum of centred y^2
@@ -241,7 +242,7 @@ struct Sums {
                     }
                 }
             }
-        } else { // OP_CHISQ: chi2 = total * (sum_j A_j / cs_j - 1), A_j = sum_i f_ij^2 / rowsum_i
+        } else if (OP == OP_CHISQ) { // chi2 = total * (sum_j A_j / cs_j - 1), A_j = sum_i f_ij^2 / rowsum_i
             double rsum = 0.0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) rsum = rsum + f[j]; // row sum of the frequencies (~1)
@@ -296,7 +297,7 @@ __device__ __forceinline__ double pick_trait(const double (&a)[NJ * K], int idx,
 template <int OP, int NJ, int K, typename AJ>
 __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poisoned, const bool (&kp)[NJ], bool alive,
                                             bool again, bool valid, int32_t *__restrict__ rec_flags,
-                                            double *__restrict__ rec, int64_t slot, AJ aj) {
+                                            double *__restrict__ rec, int64_t slot, AJ aj, bool sort_desc = false) {
     const size_t rb = rec_base(slot);
     const double pz = poisoned ? NAN : 0.0; // x + NaN = NaN: an uncovered pool makes the plain sums NaN
     int nk = 0, keepmask = 0;
@@ -314,7 +315,8 @@ __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poiso
             for (int i = 0; i < NJ; ++i) {
                 if (i == j) continue;
                 bool before;
-                if (OP == OP_OLS) before = S.cs[i] > S.cs[j] || (S.cs[i] == S.cs[j] && i < j);
+                if (OP == OP_OLS || (OP == OP_LOAD && sort_desc))
+                    before = S.cs[i] > S.cs[j] || (S.cs[i] == S.cs[j] && i < j);
                 else before = i < j;
                 r += (kp[i] && before) ? 1 : 0;
             }
@@ -335,6 +337,7 @@ __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poiso
     if (valid)
         rec_flags[slot] = (alive ? FLAG_ALIVE : 0) | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT) |
                           (ordbits << H_ORD_SHIFT);
+    if (OP == OP_LOAD) return; // the header is all the loader needs
     const int D = (valid && alive && !again) ? nk - 1 : 0; // a locus the second pass redoes gets its sums there
     if (OP == OP_CHISQ) {
         if (D > 0) {
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
             if (nk == 12345)
 #endif
             emit_record<OP, NJ, K>(A, n_missing > 0, kp, alive, again, l < L, rec_flags, rec,
-                                   unit_of(cur.chunk, cur.q) * 64 + lane, aj);
+                                   unit_of(cur.chunk, cur.q) * 64 + lane, aj, P.sort_desc != 0);
             // which lanes of this unit need the second pass: one 64-bit mask per unit, expanded into the
             // dense list by k_locus_compact (no returning atomic here: its wait would drain the loads in flight)
             const unsigned long long bal = __ballot(again);
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
             }
             __builtin_amdgcn_wave_barrier();
         }
-        emit_record<OP, NA, K>(A, n_missing > 0, keep, true, false, e < cnt, rec_flags, rec, slot, aj);
+        emit_record<OP, NA, K>(A, n_missing > 0, keep, true, false, e < cnt, rec_flags, rec, slot, aj, P.sort_desc != 0);
     }
 }
 
@@ -1217,6 +1220,224 @@ int run_locus_op_host(pg_ctx *ctx, int kid, const uint32_t *counts, int64_t L, i
     return rc;
 }
 
+// ---- loader: filter + frequencies for every locus, one column of G per surviving allele ---------------
+// FileSyncPhen::load / into_genotypes_and_phenotypes (base/sync.rs:972-1180): per locus filter
+// (:195-303) -> to_frequencies over the surviving alleles (:166-192) -> with --keep-p-minus-1 sort by
+// decreasing frequency and drop the first allele (:1033-1037); columns are laid out locus after locus
+// in the caller's locus order.  Plan = the streaming first/second pass in OP_LOAD mode (headers only)
+// + an exclusive scan of the column counts; emit = one thread per (locus, pool) that re-reads its six
+// counts and writes its frequencies, consecutive threads to consecutive doubles of a G row.
+__device__ __forceinline__ int load_ncols(int hdr, int kpm1) {
+    const int nk = (hdr >> H_NK_SHIFT) & 7;
+    const int c = (hdr & FLAG_ALIVE) ? nk - kpm1 : 0;
+    return c > 0 ? c : 0;
+}
+
+__global__ __launch_bounds__(256) void k_load_count(const int32_t *__restrict__ flags, const int64_t *__restrict__ order,
+                                                    int64_t L, int pshift, int kpm1, int32_t *__restrict__ local,
+                                                    int64_t *__restrict__ blocksum) {
+    __shared__ int sc[256];
+    const int tid = threadIdx.x;
+    const int64_t oi = (int64_t)blockIdx.x * 256 + tid;
+    int c = 0;
+    if (oi < L) c = load_ncols(flags[unit_slot(order ? order[oi] : oi, pshift)], kpm1);
+    sc[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid >= d ? sc[tid - d] : 0;
+        __syncthreads();
+        sc[tid] += v;
+        __syncthreads();
+    }
+    if (oi < L) local[oi] = sc[tid] - c;
+    if (tid == 255) blocksum[blockIdx.x] = sc[255];
+}
+
+__global__ __launch_bounds__(1024) void k_load_scan(const int64_t *__restrict__ blocksum, int64_t nb,
+                                                    int64_t *__restrict__ blockoff, int64_t *__restrict__ total) {
+    __shared__ int64_t sc[1024];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t i = base + tid;
+        const int64_t c = i < nb ? blocksum[i] : 0;
+        sc[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int64_t v = tid >= d ? sc[tid - d] : 0;
+            __syncthreads();
+            sc[tid] += v;
+            __syncthreads();
+        }
+        if (i < nb) blockoff[i] = carry + sc[tid] - c;
+        __syncthreads();
+        if (tid == 1023) carry += sc[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_load_emit(const uint32_t *__restrict__ counts, const int32_t *__restrict__ flags,
+                                                   const int64_t *__restrict__ order, const int32_t *__restrict__ local,
+                                                   const int64_t *__restrict__ blockoff, int64_t L, int n, int pshift,
+                                                   int kpm1, const int32_t *__restrict__ pool_map, int n_out,
+                                                   double *__restrict__ G, int64_t ld, int64_t *__restrict__ col_locus,
+                                                   int32_t *__restrict__ col_allele) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t oi = gid / n;
+    if (oi >= L) return;
+    const int pool = (int)(gid - oi * n);
+    const int64_t l = order ? order[oi] : oi;
+    const int hdr = flags[unit_slot(l, pshift)];
+    const int ncols = load_ncols(hdr, kpm1);
+    if (ncols == 0) return;
+    const int64_t off = blockoff[oi >> 8] + local[oi];
+    const uint2_t *cp = reinterpret_cast<const uint2_t *>(counts + ((size_t)l * n + pool) * 6);
+    const uint2_t a = cp[0], b = cp[1], d = cp[2];
+    const uint32_t c[NA] = {a.x, a.y, b.x, b.y, d.x, d.y};
+    double rs = 0.0; // row sum over the surviving alleles in column order (sync.rs:170-175)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) rs = (hdr & (2 << j)) ? rs + (double)c[j] : rs;
+    const int ordbits = hdr >> H_ORD_SHIFT;
+    const int po = pool_map ? pool_map[pool] : pool;
+    for (int r = 0; r < ncols; ++r) {
+        const int al = (ordbits >> (3 * (r + kpm1))) & 7;
+        uint32_t cv = c[0];
+#pragma unroll
+        for (int j = 1; j < NA; ++j) cv = (al == j) ? c[j] : cv;
+        const double f = (rs == 0.0) ? NAN : (double)cv / rs; // sync.rs:176-183
+        double *row = G + (size_t)(off + r) * ld;
+        if (po >= 0) row[po] = f;
+        if (pool == 0) {
+            col_locus[off + r] = l;
+            col_allele[off + r] = al;
+            for (int64_t q = n_out; q < ld; ++q) row[q] = 0.0; // padding columns of the locus-major layout
+        }
+    }
+}
+
+int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const double *pool_sizes,
+              const pg_filter *flt, int keep_p_minus_1, const int64_t *order_dev, int64_t *p_out) {
+    PG_CHECK(ctx, counts_dev && pool_sizes && flt && p_out, "load: null pointer");
+    PG_CHECK(ctx, L > 0 && n >= 1, "load: bad shape L=%lld n=%d", (long long)L, n);
+    PG_CHECK(ctx, (reinterpret_cast<uintptr_t>(counts_dev) & 15) == 0, "load: counts must be 16-byte aligned");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> w(n);
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total = total + pool_sizes[i];
+    for (int i = 0; i < n; ++i) w[i] = pool_sizes[i] / total; // sync.rs:266-268
+    int period = 1;
+    while ((((int64_t)n * 24 * period) & 127) != 0) period *= 2;
+    PG_CHECK(ctx, (int64_t)64 * period * n * 24 < ((int64_t)1 << 31), "load: too many pools (%d) for one batch row group", n);
+    const int64_t nunits = ((L + 64 * (int64_t)period - 1) / (64 * (int64_t)period)) * period;
+    const int64_t nb = (L + 255) / 256;
+    // workspace: [w][flags: i32 per slot][second list: L x i64][its length][unit masks][local: L x i32][blocksum][blockoff][total][pool map]
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off = 0;
+    const size_t o_w = off; off = al16(off + sizeof(double) * n);
+    const size_t o_flags = off; off = al16(off + sizeof(int32_t) * (size_t)nunits * 64);
+    const size_t o_second = off; off = al16(off + sizeof(int64_t) * (size_t)L);
+    const size_t o_count = off; off = al16(off + 8);
+    const size_t o_again = off; off = al16(off + 8 * (size_t)nunits);
+    const size_t o_local = off; off = al16(off + sizeof(int32_t) * (size_t)L);
+    const size_t o_bsum = off; off = al16(off + 8 * (size_t)nb);
+    const size_t o_boff = off; off = al16(off + 8 * (size_t)nb);
+    const size_t o_total = off; off = al16(off + 8);
+    const size_t o_pmap = off; off = al16(off + sizeof(int32_t) * (size_t)n);
+    int rc = pg_ws_reserve(ctx, off);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(ctx->ws);
+    double *wd = reinterpret_cast<double *>(ws + o_w);
+    int32_t *recf = reinterpret_cast<int32_t *>(ws + o_flags);
+    int64_t *second = reinterpret_cast<int64_t *>(ws + o_second);
+    unsigned long long *second_count = reinterpret_cast<unsigned long long *>(ws + o_count);
+    unsigned long long *unit_again = reinterpret_cast<unsigned long long *>(ws + o_again);
+    int32_t *local = reinterpret_cast<int32_t *>(ws + o_local);
+    int64_t *bsum = reinterpret_cast<int64_t *>(ws + o_bsum), *boff = reinterpret_cast<int64_t *>(ws + o_boff);
+    int64_t *tot_dev = reinterpret_cast<int64_t *>(ws + o_total);
+    PG_HIP(ctx, hipMemcpyAsync(wd, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(second_count, 0, 8, ctx->stream));
+    LocusParams P;
+    std::memset(&P, 0, sizeof P);
+    P.L = L; P.n = n; P.k = 1; P.k_total = 1; P.t0 = 0;
+    P.remove_ns = flt->remove_ns ? 1 : 0;
+    P.pshift = __builtin_ctz((unsigned)period);
+    P.sort_desc = keep_p_minus_1 ? 1 : 0;
+    P.min_cov = (double)flt->min_coverage_depth;
+    P.maf = flt->min_allele_frequency;
+    P.max_miss = flt->max_missingness_rate;
+    const bool p16 = ((int64_t)n * 24) % 16 == 0;
+    const bool rns = flt->remove_ns != 0;
+    const void *kfirst = rns ? (const void *)k_locus_first<OP_LOAD, true, 1> : (const void *)k_locus_first<OP_LOAD, false, 1>;
+    const void *ksecond = p16 ? (const void *)k_locus_second<OP_LOAD, 16, 1> : (const void *)k_locus_second<OP_LOAD, 8, 1>;
+    const size_t shmem = (size_t)LO_WAVES * LN_TILEB;
+    const size_t shmem2 = (size_t)LO_WAVES * LO_TILEB + (size_t)LO_WAVES * 64 * sizeof(int64_t);
+    PG_HIP(ctx, hipFuncSetAttribute(kfirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    PG_HIP(ctx, hipFuncSetAttribute(ksecond, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+    const int64_t blocks = ((L + 63) / 64 + LO_WAVES - 1) / LO_WAVES;
+    const int64_t cap = (int64_t)ctx->cus * 2;
+    const int grid = (int)(blocks < cap ? blocks : cap);
+    {
+        const uint32_t *a0 = counts_dev;
+        const double *a1 = wd, *a2 = nullptr;
+        double *recp = nullptr;
+        void *args1[] = {&a0, &a1, &a2, &recf, &recp, &unit_again, &P, &period};
+        PG_HIP(ctx, hipLaunchKernel(kfirst, dim3(grid), dim3(LO_THREADS), args1, shmem, ctx->stream));
+        hipLaunchKernelGGL(k_locus_compact, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, ctx->stream, unit_again,
+                           nunits, period, second, second_count);
+        const int64_t *b1 = second;
+        const unsigned long long *b2 = second_count;
+        void *args2[] = {&a0, &a2, &recf, &recp, &b1, &b2, &P};
+        PG_HIP(ctx, hipLaunchKernel(ksecond, dim3(grid), dim3(LO_THREADS), args2, shmem2, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_load_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, recf, order_dev, L, P.pshift,
+                       P.sort_desc, local, bsum);
+    hipLaunchKernelGGL(k_load_scan, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb, boff, tot_dev);
+    PG_HIP(ctx, hipGetLastError());
+    int64_t tot = 0;
+    PG_HIP(ctx, hipMemcpyAsync(&tot, tot_dev, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *p_out = tot;
+    ctx->load_valid = true;
+    ctx->load_counts = counts_dev; ctx->load_order = order_dev;
+    ctx->load_L = L; ctx->load_total = tot; ctx->load_nunits = nunits;
+    ctx->load_n = n; ctx->load_kpm1 = P.sort_desc; ctx->load_pshift = P.pshift;
+    ctx->load_off_flags = o_flags; ctx->load_off_local = o_local; ctx->load_off_blockoff = o_boff;
+    ctx->load_off_poolmap = o_pmap;
+    return PG_OK;
+}
+
+int load_emit(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld, int64_t *col_locus_dev,
+              int32_t *col_allele_dev) {
+    if (!ctx->load_valid) return pg_fail(ctx, PG_ERR_STATE, "load_emit: call pg_load_plan_dev first (and nothing else in between)");
+    PG_CHECK(ctx, G_dev && col_locus_dev && col_allele_dev, "load_emit: null pointer");
+    const int n = ctx->load_n;
+    if (!pool_map) n_out = n;
+    PG_CHECK(ctx, n_out >= 1 && ld >= n_out && (ld % 2) == 0, "load_emit: ld (%lld) must be even and >= the pools kept (%d)",
+             (long long)ld, n_out);
+    if (pool_map)
+        for (int i = 0; i < n; ++i) PG_CHECK(ctx, pool_map[i] >= -1 && pool_map[i] < n_out, "load_emit: pool_map[%d] out of range", i);
+    if (ctx->load_total == 0) return PG_OK;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    char *ws = static_cast<char *>(ctx->ws);
+    int32_t *pmap_dev = nullptr;
+    if (pool_map) {
+        pmap_dev = reinterpret_cast<int32_t *>(ws + ctx->load_off_poolmap);
+        PG_HIP(ctx, hipMemcpyAsync(pmap_dev, pool_map, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const int64_t threads = ctx->load_L * n;
+    hipLaunchKernelGGL(k_load_emit, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->load_counts,
+                       reinterpret_cast<const int32_t *>(ws + ctx->load_off_flags), ctx->load_order,
+                       reinterpret_cast<const int32_t *>(ws + ctx->load_off_local),
+                       reinterpret_cast<const int64_t *>(ws + ctx->load_off_blockoff), ctx->load_L, n, ctx->load_pshift,
+                       ctx->load_kpm1, pmap_dev, n_out, G_dev, ld, col_locus_dev, col_allele_dev);
+    PG_HIP(ctx, hipGetLastError());
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // pool_map is the caller's
+    return PG_OK;
+}
+
 } // namespace
 
 extern "C" int pg_ols_iter_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n,
@@ -1271,4 +1492,16 @@ extern "C" int pg_chisq_batch(pg_ctx *ctx, const uint32_t *counts, int64_t L, in
     if (!ctx) return PG_ERR_INVALID;
     return run_locus_op_host<OP_CHISQ>(ctx, PG_K_CHISQ, counts, L, n, pool_sizes, filter, nullptr, 1, n_out,
                                        allele_ids, nullptr, chi2, pval);
+}
+
+extern "C" int pg_load_plan_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const double *pool_sizes,
+                                const pg_filter *filter, int keep_p_minus_1, const int64_t *order_dev, int64_t *p_out) {
+    if (!ctx) return PG_ERR_INVALID;
+    return load_plan(ctx, counts_dev, L, n, pool_sizes, filter, keep_p_minus_1, order_dev, p_out);
+}
+
+extern "C" int pg_load_emit_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,
+                                int64_t *col_locus_dev, int32_t *col_allele_dev) {
+    if (!ctx) return PG_ERR_INVALID;
+    return load_emit(ctx, pool_map, n_out, G_dev, ld, col_locus_dev, col_allele_dev);
 }

@@ -206,6 +206,37 @@ class Engine:
                                                  chi2.data_ptr(), pv.data_ptr()), "pg_chisq_batch_dev")
         return n_out, ids, chi2, pv
 
+    def load_frequencies(self, counts, pool_sizes, flt: Filter, keep_p_minus_1: bool = False, order=None,
+                         pool_keep=None, ld: int | None = None):
+        """The reference loader (base/sync.rs:972-1180) on a counts batch in HBM: filter, frequencies over the
+        surviving alleles, optionally drop the major allele; one column of G per surviving allele.  Returns
+        (G [p x ld], col_locus [p], col_allele [p]); `pool_keep` (bool per pool) selects the rows written."""
+        L, n, _ = counts.shape
+        ps = _host_f64(pool_sizes)
+        dev = counts.device
+        f = flt.to_c()
+        p = C.c_int64()
+        optr = None
+        if order is not None:
+            order = order.to(device=dev, dtype=torch.int64).contiguous()
+            optr = order.data_ptr()
+        self._check(self._lib.pg_load_plan_dev(self._ctx, self._dev(counts, torch.int32), L, n, ps.ctypes.data,
+                                               C.byref(f), int(keep_p_minus_1), optr, C.byref(p)), "pg_load_plan_dev")
+        if pool_keep is None:
+            pmap, n_out = None, n
+        else:
+            keep = np.asarray(pool_keep, dtype=bool)
+            pmap = np.where(keep, np.cumsum(keep) - 1, -1).astype(np.int32)
+            n_out = int(keep.sum())
+        ld = (n_out + (n_out & 1)) if ld is None else int(ld)
+        G = torch.empty((p.value, ld), dtype=torch.float64, device=dev)
+        col_locus = torch.empty(p.value, dtype=torch.int64, device=dev)
+        col_allele = torch.empty(p.value, dtype=torch.int32, device=dev)
+        self._check(self._lib.pg_load_emit_dev(self._ctx, pmap.ctypes.data if pmap is not None else None, n_out,
+                                               G.data_ptr(), ld, col_locus.data_ptr(), col_allele.data_ptr()),
+                    "pg_load_emit_dev")
+        return G, col_locus, col_allele
+
     # ---- genomic prediction -------------------------------------------------------------------
     def gp_xxt(self, G: torch.Tensor, n: int | None = None) -> torch.Tensor:
         p, ld, n = self._g_dims(G, n)

@@ -168,3 +168,63 @@ def test_synthetic_batches(engine, oracle, n, L, kw):
                 assert np.isnan(chi2[l]) and np.isnan(pv[l]) and np.isnan(rp)
                 continue
             assert abs(chi2[l] - rc) <= 1e-10 * max(1.0, abs(rc)) and abs(pv[l] - rp) <= 1e-10
+
+
+@pytest.mark.parametrize("n,L,kpm1,kw", [(5, None, False, dict()), (5, None, True, dict(min_cov=10, maf=0.01)),
+                                         (40, 1200, True, dict(maf=0.02)), (33, 900, False, dict(remove_ns=False)),
+                                         (24, 700, True, dict(min_cov=0, miss=0.3))])
+def test_loader_against_oracle(engine, oracle, n, L, kpm1, kw):
+    """pg_load_plan_dev / pg_load_emit_dev = FileSyncPhen::load + into_genotypes_and_phenotypes (sync.rs:972-1180):
+    the set of columns, their alleles and every frequency are bit-exact (integer counts, IEEE divisions)."""
+    from poolgen_amd import synth
+    if L is None:
+        rows, _, ps = load_fixture(oracle)
+        counts = to_dev(rows)
+        host = [r[2] for r in rows]
+    else:
+        counts = synth.sync_counts(L, n, "cuda", seed=7)
+        g = torch.Generator(device="cuda"); g.manual_seed(11)
+        counts[:, :, 2] = (torch.rand(L, n, generator=g, device="cuda") < 0.2).int() * torch.randint(0, 7, (L, n), generator=g, device="cuda", dtype=torch.int32)
+        counts[:, :, 4] = (torch.rand(L, n, generator=g, device="cuda") < 0.05).int()
+        counts[3::101, 0, :] = 0
+        counts[9::57, :, 1] = 0; counts[9::57, :, 2] = 0
+        ps = np.linspace(10, 30, n)
+        host = list(counts.cpu().numpy().astype(np.uint64))
+    f, fo = flt_pair(oracle, **kw)
+    nloc = len(host)
+    rng = np.random.default_rng(3)
+    order = rng.permutation(nloc)
+    pool_keep = np.ones(n, dtype=bool); pool_keep[1::4] = False
+    G, col_locus, col_allele = engine.load_frequencies(counts, ps, f, keep_p_minus_1=kpm1, order=torch.from_numpy(order),
+                                                       pool_keep=pool_keep)
+    G, col_locus, col_allele = G.cpu().numpy(), col_locus.cpu().numpy(), col_allele.cpu().numpy()
+    want_cols, want_loc, want_al = [], [], []
+    for l in order:
+        res = oracle.filter_locus(host[l], ps, fo)
+        if res is None:
+            continue
+        ids, fc = res
+        fr = oracle.to_frequencies(fc)
+        if kpm1:
+            fr, ids = oracle.sort_by_allele_freq(fr, ids, True)
+            fr, ids = fr[:, 1:], ids[1:]
+        for j, a in enumerate(ids):
+            want_cols.append(fr[pool_keep, j]); want_loc.append(int(l)); want_al.append(int(a))
+    assert len(want_cols) == G.shape[0] > 0
+    assert col_locus.tolist() == want_loc and col_allele.tolist() == want_al
+    nk = int(pool_keep.sum())
+    assert np.array_equal(G[:, :nk], np.stack(want_cols), equal_nan=True)
+    assert np.all(G[:, nk:] == 0.0)
+
+
+def test_loader_first_locus_reference_literal(engine, oracle):
+    """base/sync.rs:1516-1535, :1616: the first locus of tests/test.sync as the reference's own loader test sees it."""
+    import json
+    g = json.loads((GOLD / "reference_literals.json").read_text())["loaded_first_locus"]
+    rows, _, ps = load_fixture(oracle)
+    from poolgen_amd import Filter
+    G, col_locus, col_allele = engine.load_frequencies(to_dev(rows), ps, Filter(min_allele_frequency=0.005), keep_p_minus_1=True)
+    first = (col_locus == 0).nonzero().flatten().tolist()
+    assert (rows[0][0], rows[0][1]) == (g["chromosome"], g["position"])
+    assert "".join(AL[int(col_allele[c])] for c in first) == g["alleles"]
+    assert G[first, :5].T.reshape(-1).tolist() == g["freq"]

@@ -50,43 +50,16 @@ def test_phen_parser_missing_values(tmp_path):
     assert [r[2] for r in rows] == ["NaN", "2.5", "NaN"] and [r[3] for r in rows] == ["1.5", "NaN", "-1000"]
 
 
-def _loader_check(oracle, threads, keep1, **kw):
-    f = oracle.filt(kw.get("remove_ns", True), kw.get("min_cov", 1), kw.get("maf", 0.001), kw.get("miss", 0.0))
-    ps = [20.0, 20.0, 20.0, 20.0, 20.0]
-    out = run("load", GOLD / "test.sync", threads, int(keep1), int(kw.get("remove_ns", True)), kw.get("min_cov", 1),
-              kw.get("maf", 0.001), kw.get("miss", 0.0), ",".join(map(str, ps))).splitlines()
-    L, n = map(int, out[0].split())
+def test_sync_parser_matches_oracle_and_keeps_file_order(oracle):
+    """parse_sync_file (threads over byte ranges, helpers.rs:74-91) = lparse per line (sync.rs:100-156), in file
+    order.  Filter / frequencies / column layout of the loader run on the GPU (tests/test_gpu_locus_ops.py)."""
     lines = [l for l in (GOLD / "test.sync").read_text().splitlines() if not l.startswith("#")]
-    assert (L, n) == (len(lines), 5) == (6674, 5)
-    for line, got in zip(lines, out[1:]):
-        _, chrom, pos, counts = oracle.parse_sync_line(line)
-        parts = got.split(" ")
-        assert parts[0] == chrom and int(parts[1]) == pos                      # file order kept across threads
-        res = oracle.filter_locus(counts, ps, f)
-        if res is None:
-            assert parts[2] == "" and len(parts) == 3
-            continue
-        ids, fc = res
-        fr = oracle.to_frequencies(fc)
-        if keep1:
-            fr, ids = oracle.sort_by_allele_freq(fr, ids, True)
-            fr, ids = fr[:, 1:], ids[1:]
-        assert parts[2] == "".join("ATCGND"[i] for i in ids)
-        vals = np.array([float.fromhex(x) for x in parts[3:]]).reshape(5, len(ids))
-        assert np.array_equal(vals, fr)                                           # bit-exact frequencies
-    return out
-
-
-def test_loader_matches_oracle_bit_exact(oracle):
-    _loader_check(oracle, 1, False)
-    _loader_check(oracle, 3, True)
-    _loader_check(oracle, 2, True, min_cov=10, maf=0.01)
-    _loader_check(oracle, 2, False, remove_ns=False, maf=0.0)
-
-
-def test_loader_first_locus_reference_literal(oracle):
-    g = LIT["loaded_first_locus"]  # base/sync.rs:1516-1535, 1616
-    out = run("load", GOLD / "test.sync", 2, 1, 1, 1, 0.005, 0.0, "20,20,20,20,20").splitlines()
-    parts = out[1].split(" ")
-    assert (parts[0], int(parts[1]), parts[2]) == (g["chromosome"], g["position"], g["alleles"])
-    assert [float.fromhex(x) for x in parts[3:]] == g["freq"]
+    for threads in (1, 2, 3, 7):
+        out = run("parse", GOLD / "test.sync", threads).splitlines()
+        L, n = map(int, out[0].split())
+        assert (L, n) == (len(lines), 5) == (6674, 5)
+        for line, got in zip(lines, out[1:]):
+            _, chrom, pos, counts = oracle.parse_sync_line(line)
+            parts = got.split(" ")
+            assert parts[0] == chrom and int(parts[1]) == pos
+            assert [int(x) for x in parts[2:]] == np.asarray(counts).reshape(-1).tolist()
