@@ -34,6 +34,15 @@ def main():
         print(json.dumps({"op": name, "pools": n, "loci": L, "wall_ms": dt * 1e3, "kernel_ms": kms,
                           "loci_per_s": L / dt, "gbs_algorithmic": 24.0 * n * L / (kms * 1e-3) / 1e9,
                           "frac_of_hbm_peak": 24.0 * n * L / (kms * 1e-3) / 8e12}))
+    # the loader (counts -> G): plan + emit, all loci survive with two alleles each on this synthetic batch
+    t = timeit(lambda: eng.load_frequencies(counts, ps, f), reps=3)
+    Gl, _, _ = eng.load_frequencies(counts, ps, f)
+    moved = 2 * 24.0 * n * L + 8.0 * Gl.shape[0] * Gl.shape[1]   # counts are read by the plan and by the emit pass
+    print(json.dumps({"op": "load_frequencies", "pools": n, "loci": L, "columns": int(Gl.shape[0]), "wall_ms": t * 1e3,
+                      "loci_per_s": L / t, "gbs_moved": moved / t / 1e9}))
+    del Gl
+    if G.shape[1] != n:
+        return   # gp_ols below assumes ld == n
     idx = np.arange(n)
     eng.profile_reset()
     dt = timeit(lambda: eng.gp_ols(G, Y, idx), reps=3)
