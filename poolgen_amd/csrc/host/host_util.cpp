@@ -3,6 +3,7 @@
 #include "host_util.h"
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +11,11 @@
 #include <fstream>
 #include <stdexcept>
 #include <thread>
+#include <utility>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace pgh {
 
@@ -96,104 +102,248 @@ Phen parse_phen(const std::string &fname, const std::string &delim, int name_col
 }
 
 // ---- sync parsing -----------------------------------------------------------------------------
-static bool parse_u64(const char *b, const char *e, uint64_t &out) {
-    if (b == e) return false;
-    auto r = std::from_chars(b, e, out);
-    return r.ec == std::errc() && r.ptr == e;
-}
-
-// one line [b, e) without the trailing newline; returns pools parsed, 0 for comments
-static int parse_line(const char *b, const char *e, std::string &chrom, uint64_t &pos,
-                      std::vector<uint32_t> &counts, int expect_n) {
-    if (e > b && e[-1] == '\r') --e;
-    if (b == e) throw std::runtime_error("empty line in sync file");
-    if (*b == '#') return 0;
-    int field = 0, n = 0;
-    const char *p = b;
-    while (p <= e) {
-        const char *t = (const char *)std::memchr(p, '\t', e - p);
-        const char *fe = t ? t : e;
-        if (field == 0) chrom.assign(p, fe);
-        else if (field == 1) {
-            if (!parse_u64(p, fe, pos))
-                throw std::runtime_error("Please check format of the file: position is not and integer.");
-        } else if (field >= 3) {
-            const char *q = p;
-            for (int j = 0; j < 6; ++j) {
-                const char *c = (const char *)std::memchr(q, ':', fe - q);
-                const char *ce = c ? c : fe;
-                uint64_t v;
-                if (!parse_u64(q, ce, v) || v > 0xFFFFFFFFull)
-                    throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
-                counts.push_back((uint32_t)v);
-                if (!c && j < 5)
-                    throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
-                q = c ? c + 1 : fe;
-            }
-            ++n;
-        }
-        ++field;
-        if (!t) break;
-        p = t + 1;
+SyncBatch &SyncBatch::operator=(SyncBatch &&o) noexcept {
+    if (this != &o) {
+        if (counts) (release ? release : std::free)(counts);
+        n = o.n; L = o.L;
+        chrom_id = std::move(o.chrom_id); chrom_names = std::move(o.chrom_names); pos = std::move(o.pos);
+        counts = o.counts; release = o.release;
+        o.counts = nullptr; o.L = 0;
     }
-    if (expect_n > 0 && n != expect_n) throw std::runtime_error("sync file: inconsistent number of pools");
-    return n;
+    return *this;
+}
+SyncBatch::~SyncBatch() {
+    if (counts) (release ? release : std::free)(counts);
 }
 
-SyncBatch parse_sync_file(const std::string &fname, int n_threads) {
-    std::ifstream in(fname, std::ios::binary | std::ios::ate);
-    if (!in) throw std::runtime_error("The input file: " + fname + " does not exist. Please make sure you are entering the correct filename and/or the correct path.");
-    const size_t sz = (size_t)in.tellg();
-    std::string buf(sz, '\0');
-    in.seekg(0);
-    in.read(&buf[0], sz);
+namespace {
+
+struct Mapped { // the file, read-only, mapped
+    const char *p = nullptr;
+    size_t sz = 0;
+    ~Mapped() { if (p && sz) ::munmap(const_cast<char *>(p), sz); }
+};
+
+inline const char *line_end(const char *p, const char *end) {
+    const void *nl = std::memchr(p, '\n', (size_t)(end - p));
+    return nl ? (const char *)nl : end;
+}
+
+// A run of decimal digits -> value; false when there is no digit (Rust's `parse::<u64>` also accepts
+// one leading '+', so does this).
+inline bool digits(const char *&p, const char *e, uint64_t &v) {
+    if (p < e && *p == '+') ++p;
+    const char *b = p;
+    uint64_t x = 0;
+    while (p < e) {
+        const unsigned c = (unsigned)(unsigned char)*p - (unsigned)'0';
+        if (c > 9u) break;
+        x = x * 10u + c;
+        ++p;
+    }
+    v = x;
+    return p != b && p - b <= 19;
+}
+
+struct ThreadOut {
+    std::vector<std::string> names; // chromosome names met by this worker, in order
+    int64_t lines = 0;              // data lines written
+    std::string err;
+};
+
+// Parses the data lines of [b, e) into counts[(base + i) * n * 6 ...], chrom_local, pos.  n == 0: only
+// count the candidate lines (non-empty, not starting with '#') and return that count.
+int64_t parse_range(const char *b, const char *e, int n, uint32_t *counts, int32_t *chrom_local, uint64_t *pos,
+                    ThreadOut &out) {
+    int64_t li = 0;
+    const char *p = b;
+    int last = -1;
+    while (p < e) {
+        const char *le = line_end(p, e);
+        const char *next = le < e ? le + 1 : e;
+        const char *q = le;
+        if (q > p && q[-1] == '\r') --q;
+        if (q == p) throw std::runtime_error("empty line in sync file"); // the reference indexes byte 0 of the line
+        if (*p == '#') { p = next; continue; }
+        if (n == 0) { ++li; p = next; continue; }
+        // chromosome
+        const char *t = (const char *)std::memchr(p, '\t', (size_t)(q - p));
+        if (!t) throw std::runtime_error("sync file: a line has fewer than four tab-separated fields");
+        const size_t clen = (size_t)(t - p);
+        if (last < 0 || out.names[last].size() != clen || std::memcmp(out.names[last].data(), p, clen) != 0) {
+            last = -1;
+            for (size_t i = 0; i < out.names.size(); ++i)
+                if (out.names[i].size() == clen && std::memcmp(out.names[i].data(), p, clen) == 0) { last = (int)i; break; }
+            if (last < 0) { out.names.emplace_back(p, clen); last = (int)out.names.size() - 1; }
+        }
+        // position: not an integer -> the line is skipped (ErrorKind::Other, see the header)
+        const char *c = t + 1;
+        uint64_t pv = 0;
+        const bool pos_ok = digits(c, q, pv) && c < q && *c == '\t';
+        if (!pos_ok) {
+            const char *t2 = (const char *)std::memchr(t + 1, '\t', (size_t)(q - t - 1));
+            if (!t2) throw std::runtime_error("sync file: a line has fewer than four tab-separated fields");
+            p = next;
+            continue;
+        }
+        // reference allele: ignored
+        const char *t3 = (const char *)std::memchr(c + 1, '\t', (size_t)(q - c - 1));
+        if (!t3) throw std::runtime_error("sync file: a line has fewer than four tab-separated fields");
+        c = t3 + 1;
+        uint32_t *dst = counts + (size_t)li * n * 6;
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < 6; ++j) {
+                uint64_t v;
+                if (!digits(c, q, v) || v > 0xFFFFFFFFull)
+                    throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
+                dst[i * 6 + j] = (uint32_t)v;
+                if (j < 5) {
+                    if (c >= q || *c != ':')
+                        throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
+                    ++c;
+                }
+            }
+            // anything after the sixth count of a pool is ignored up to the next tab, as long as it is a
+            // well-formed ':'-separated list of integers (the reference parses, then uses the first six)
+            while (c < q && *c == ':') {
+                ++c;
+                uint64_t v;
+                if (!digits(c, q, v))
+                    throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
+            }
+            if (i + 1 < n) {
+                if (c >= q || *c != '\t') throw std::runtime_error("sync file: inconsistent number of pools");
+                ++c;
+            }
+        }
+        if (c != q) {
+            if (*c == '\t') throw std::runtime_error("sync file: inconsistent number of pools");
+            throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
+        }
+        chrom_local[li] = last;
+        pos[li] = pv;
+        ++li;
+        p = next;
+    }
+    return li;
+}
+
+} // namespace
+
+SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc alloc) {
+    const std::string notfound = "The input file: " + fname + " does not exist. Please make sure you are entering the correct filename and/or the correct path.";
+    const bool timing = std::getenv("PGH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_last = now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto t = now();
+        std::fprintf(stderr, "parse_sync_file: %-12s %.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+        t_last = t;
+    };
+    const int fd = ::open(fname.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error(notfound);
+    struct stat st;
+    if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error(notfound); }
+    Mapped mp;
+    mp.sz = (size_t)st.st_size;
+    if (mp.sz) {
+        // MAP_POPULATE: one batched population of the page tables instead of a trap per 4 KiB page
+        void *m = ::mmap(nullptr, mp.sz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot map " + fname); }
+        mp.p = (const char *)m;
+    }
+    ::close(fd);
+    lap("map");
+    const char *buf = mp.p;
+    const size_t sz = mp.sz;
     if (n_threads < 1) n_threads = 1;
     // byte ranges split at line starts (helpers.rs:74-91)
     std::vector<size_t> cuts{0};
     for (int t = 1; t < n_threads; ++t) {
         size_t c = sz / n_threads * t;
         if (c <= cuts.back()) continue;
-        const void *nl = std::memchr(buf.data() + c, '\n', sz - c);
-        c = nl ? (const char *)nl - buf.data() + 1 : sz;
+        const void *nl = std::memchr(buf + c, '\n', sz - c);
+        c = nl ? (size_t)((const char *)nl - buf) + 1 : sz;
         if (c > cuts.back() && c < sz) cuts.push_back(c);
     }
     cuts.push_back(sz);
     const int parts = (int)cuts.size() - 1;
-    std::vector<SyncBatch> out(parts);
-    std::vector<std::string> err(parts);
-    auto work = [&](int t) {
-        try {
-            SyncBatch &sb = out[t];
-            const char *p = buf.data() + cuts[t], *end = buf.data() + cuts[t + 1];
-            std::string chrom;
-            while (p < end) {
-                const char *nl = (const char *)std::memchr(p, '\n', end - p);
-                const char *le = nl ? nl : end;
-                uint64_t pos = 0;
-                const int n = parse_line(p, le, chrom, pos, sb.counts, sb.n);
-                if (n > 0) {
-                    sb.n = n;
-                    sb.chrom.push_back(chrom);
-                    sb.pos.push_back(pos);
-                }
-                p = nl ? nl + 1 : end;
+    SyncBatch sb;
+    // pools per line: from the first data line
+    {
+        const char *p = buf, *end = buf + sz;
+        while (p < end) {
+            const char *le = line_end(p, end);
+            if (le > p && *p != '#') {
+                int tabs = 0;
+                for (const char *c = p; c < le; ++c) tabs += (*c == '\t');
+                if (tabs < 3) throw std::runtime_error("sync file: a line has fewer than four tab-separated fields");
+                sb.n = tabs - 2;
+                break;
             }
-        } catch (const std::exception &e) { err[t] = e.what(); }
-    };
-    std::vector<std::thread> th;
-    for (int t = 0; t < parts; ++t) th.emplace_back(work, t);
-    for (auto &x : th) x.join();
-    SyncBatch all;
-    for (int t = 0; t < parts; ++t) {
-        if (!err[t].empty()) throw std::runtime_error(err[t]);
-        if (out[t].size() == 0) continue;
-        if (all.n && out[t].n != all.n) throw std::runtime_error("sync file: inconsistent number of pools");
-        all.n = out[t].n;
-        all.chrom.insert(all.chrom.end(), out[t].chrom.begin(), out[t].chrom.end());
-        all.pos.insert(all.pos.end(), out[t].pos.begin(), out[t].pos.end());
-        all.counts.insert(all.counts.end(), out[t].counts.begin(), out[t].counts.end());
+            if (le == p) throw std::runtime_error("empty line in sync file");
+            p = le < end ? le + 1 : end;
+        }
     }
-    return all;
+    if (sb.n == 0) return sb;
+    std::vector<ThreadOut> out(parts);
+    std::vector<int64_t> cand(parts, 0), base(parts + 1, 0);
+    auto run_all = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < parts; ++t)
+            th.emplace_back([&, t] {
+                try { fn(t); } catch (const std::exception &e) { out[t].err = e.what(); }
+            });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < parts; ++t)
+            if (!out[t].err.empty()) throw std::runtime_error(out[t].err);
+    };
+    // pass 1: candidate lines per range, so that every worker can write straight into its slice
+    run_all([&](int t) { cand[t] = parse_range(buf + cuts[t], buf + cuts[t + 1], 0, nullptr, nullptr, nullptr, out[t]); });
+    lap("count lines");
+    for (int t = 0; t < parts; ++t) base[t + 1] = base[t] + cand[t];
+    const int64_t Lcand = base[parts];
+    const size_t bytes = sizeof(uint32_t) * (size_t)Lcand * sb.n * 6;
+    sb.counts = static_cast<uint32_t *>(alloc.alloc ? alloc.alloc(bytes ? bytes : 1) : std::malloc(bytes ? bytes : 1));
+    sb.release = alloc.alloc ? alloc.release : nullptr;
+    if (!sb.counts) throw std::runtime_error("out of memory for the allele counts of " + fname);
+    sb.chrom_id.resize(Lcand);
+    sb.pos.resize(Lcand);
+    lap("allocate");
+    // pass 2: parse
+    run_all([&](int t) {
+        out[t].lines = parse_range(buf + cuts[t], buf + cuts[t + 1], sb.n, sb.counts + (size_t)base[t] * sb.n * 6,
+                                   sb.chrom_id.data() + base[t], sb.pos.data() + base[t], out[t]);
+    });
+    lap("parse");
+    // chromosome names: worker-local ids -> global ids in order of first appearance
+    std::vector<std::vector<int32_t>> remap(parts);
+    for (int t = 0; t < parts; ++t)
+        for (const std::string &nm : out[t].names) {
+            int g = -1;
+            for (size_t i = 0; i < sb.chrom_names.size(); ++i)
+                if (sb.chrom_names[i] == nm) { g = (int)i; break; }
+            if (g < 0) { sb.chrom_names.push_back(nm); g = (int)sb.chrom_names.size() - 1; }
+            remap[t].push_back(g);
+        }
+    // lines skipped for a bad position leave holes at the end of a slice: close them (rare)
+    int64_t w = 0;
+    for (int t = 0; t < parts; ++t) {
+        const int64_t r0 = base[t], cnt = out[t].lines;
+        for (int64_t i = 0; i < cnt; ++i) sb.chrom_id[r0 + i] = remap[t][sb.chrom_id[r0 + i]];
+        if (w != r0 && cnt > 0) {
+            std::memmove(sb.counts + (size_t)w * sb.n * 6, sb.counts + (size_t)r0 * sb.n * 6, sizeof(uint32_t) * (size_t)cnt * sb.n * 6);
+            std::memmove(sb.chrom_id.data() + w, sb.chrom_id.data() + r0, sizeof(int32_t) * cnt);
+            std::memmove(sb.pos.data() + w, sb.pos.data() + r0, sizeof(uint64_t) * cnt);
+        }
+        w += cnt;
+    }
+    lap("merge");
+    sb.L = w;
+    sb.chrom_id.resize(w);
+    sb.pos.resize(w);
+    return sb;
 }
 
 } // namespace pgh

@@ -3,6 +3,7 @@
 //   hostcheck phen <file> <delim> <name_col> <size_col> <c1,c2,..>
 //   hostcheck parse <sync> <threads>   : "L n" then one line per locus: chrom pos counts[n*6]
 #include "host_util.h"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,10 +39,15 @@ int main(int argc, char **argv) {
             const SyncBatch sb = parse_sync_file(argv[2], std::atoi(argv[3]));
             std::cout << sb.size() << " " << sb.n << "\n";
             for (int64_t l = 0; l < sb.size(); ++l) {
-                std::cout << sb.chrom[l] << " " << sb.pos[l];
+                std::cout << sb.chrom(l) << " " << sb.pos[l];
                 for (int i = 0; i < sb.n * 6; ++i) std::cout << " " << sb.counts[(size_t)l * sb.n * 6 + i];
                 std::cout << "\n";
             }
+        } else if (mode == "parsetime") { // throughput of parse_sync_file: hostcheck parsetime <sync> <threads>
+            const auto t0 = std::chrono::steady_clock::now();
+            const SyncBatch sb = parse_sync_file(argv[2], std::atoi(argv[3]));
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::cout << sb.size() << " loci x " << sb.n << " pools in " << dt << " s\n";
         } else return 2;
         return 0;
     } catch (const std::exception &e) { std::cerr << "hostcheck: " << e.what() << "\n"; return 1; }

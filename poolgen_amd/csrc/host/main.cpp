@@ -18,6 +18,7 @@
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -128,8 +129,44 @@ static std::vector<int> complete_pools(const Phen &ph) {
     return idx;
 }
 
+// Formats items [0, count) with `fn(i, text)` on `n_threads` workers, each over a contiguous range and into
+// its own buffer, and writes the buffers in range order: the file is byte-identical to a sequential loop.
+template <typename F>
+static void write_rows_parallel(FILE *fo, int64_t count, int n_threads, F fn) {
+    if (n_threads < 1) n_threads = 1;
+    const int64_t chunk = 1 << 16; // items per work unit: bounds the memory held in text form
+    for (int64_t base = 0; base < count; base += chunk * n_threads) {
+        const int64_t end = std::min(count, base + chunk * n_threads);
+        const int parts = (int)std::min<int64_t>(n_threads, (end - base + chunk - 1) / chunk);
+        std::vector<std::string> text(parts);
+        std::vector<std::thread> th;
+        for (int t = 0; t < parts; ++t)
+            th.emplace_back([&, t] {
+                const int64_t lo = base + t * chunk, hi = std::min(end, lo + chunk);
+                std::string &out = text[t];
+                out.reserve((size_t)(hi - lo) * 64);
+                for (int64_t i = lo; i < hi; ++i) fn(i, out);
+            });
+        for (auto &x : th) x.join();
+        for (const std::string &x : text) fwrite(x.data(), 1, x.size(), fo);
+    }
+}
+
+// PGH_TIMING=1: wall-clock of the CLI's phases on stderr
+struct Lap {
+    bool on = std::getenv("PGH_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "poolgen: %-24s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+
 static int run(int argc, char **argv) {
     const Args a = parse_args(argc, argv);
+    Lap lap;
     const std::map<std::string, int> known{{"chisq_test", 0}, {"pearson_corr", 1}, {"ols_iter", 2},
                                            {"ols_iter_with_kinship", 3}};
     if (!known.count(a.analysis))
@@ -138,7 +175,17 @@ static int run(int argc, char **argv) {
     if (a.generate_plots || a.sig_only)
         throw std::runtime_error("--generate-plots / --output-sig-snps-only call the reference's python scripts and are out of scope here");
     Phen ph = parse_phen(a.phen_fname, a.phen_delim, a.phen_name_col, a.phen_pool_size_col, a.phen_value_col);
-    SyncBatch sb = parse_sync_file(a.fname, a.n_threads);
+    // the counts are parsed straight into pinned memory: the copy to the device needs no staging pass
+    SyncAlloc pinned;
+    pinned.alloc = [](size_t bytes) -> void * {
+        void *p = nullptr;
+        return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    };
+    pinned.release = [](void *p) { (void)hipHostFree(p); };
+    Ctx gpu; // first: the pinned allocator below needs a HIP context
+    lap("start-up");
+    SyncBatch sb = parse_sync_file(a.fname, a.n_threads, pinned);
+    lap("parse sync");
     if (sb.size() == 0) throw std::runtime_error("no loci in " + a.fname);
     if (sb.n != ph.n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
     pg_filter flt{};
@@ -149,7 +196,6 @@ static int run(int argc, char **argv) {
     const int n = sb.n, k = ph.k;
     const int64_t L = sb.size();
     const int mode = known.at(a.analysis);
-    Ctx gpu;
 
     if (mode <= 2) {
         std::string out = a.output;
@@ -161,7 +207,7 @@ static int run(int argc, char **argv) {
         std::string header;
         if (mode == 0) {
             stat.resize(L); pv.resize(L);
-            gpu.ok(pg_chisq_batch(gpu.c, sb.counts.data(), L, n, ph.pool_sizes.data(), &flt, n_out.data(), ids.data(),
+            gpu.ok(pg_chisq_batch(gpu.c, sb.counts, L, n, ph.pool_sizes.data(), &flt, n_out.data(), ids.data(),
                                   stat.data(), pv.data()), "chisq_test");
             header = "#chr,pos,alleles,statistic,pvalue\n"; // sync.rs:766
         } else {
@@ -169,7 +215,7 @@ static int run(int argc, char **argv) {
             std::vector<uint32_t> counts2;
             std::vector<double> Y = ph.phen, ps = ph.pool_sizes;
             int n2 = n;
-            const uint32_t *cptr = sb.counts.data();
+            const uint32_t *cptr = sb.counts;
             if (mode == 2) {
                 const std::vector<int> keep = complete_pools(ph);
                 if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
@@ -194,23 +240,22 @@ static int run(int argc, char **argv) {
                                          mf.data(), stat.data(), pv.data()), "ols_iter");
             header = "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n"; // sync.rs:950
         }
+        lap("GPU operator (incl. H2D/D2H)");
         FILE *fo = create_new(out);
         fputs(header.c_str(), fo);
-        std::string line;
-        for (int64_t l = 0; l < L; ++l) {
-            if (n_out[l] <= 0) continue;
-            line.clear();
+        write_rows_parallel(fo, L, a.n_threads, [&](int64_t l, std::string &line) {
+            if (n_out[l] <= 0) return;
             if (mode == 0) { // chisq_test.rs:37-45
                 std::string al;
                 for (int j = 0; j < n_out[l] && j < PG_MAX_OUT; ++j) al.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + j]]);
-                line = sb.chrom[l] + "," + std::to_string(sb.pos[l]) + "," + al + "," + roundup_own(stat[l], 6) + "," +
-                       rust_display(pv[l]) + "\n";
+                line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + al + "," + roundup_own(stat[l], 6) + "," +
+                        rust_display(pv[l]) + "\n";
             } else {
                 for (int i = 0; i < n_out[l]; ++i)
                     for (int j = 0; j < k; ++j) {
                         const size_t e = ((size_t)l * PG_MAX_OUT + i) * k + j;
                         const double f = mf[(size_t)l * PG_MAX_OUT + i];
-                        line += sb.chrom[l] + "," + std::to_string(sb.pos[l]) + "," + ALLELES[ids[(size_t)l * PG_MAX_OUT + i]] + ",";
+                        line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + ALLELES[ids[(size_t)l * PG_MAX_OUT + i]] + ",";
                         if (mode == 2) // ols.rs:263-271
                             line += roundup_own(f, 8) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
                                     roundup_own(pv[e], 12) + "\n";
@@ -219,9 +264,9 @@ static int run(int argc, char **argv) {
                                     rust_display(pv[e]) + "\n";
                     }
             }
-            fputs(line.c_str(), fo);
-        }
+        });
         fclose(fo);
+        lap("format + write CSV");
         std::cout << out << "\n"; // main.rs:507
         return 0;
     }
@@ -233,7 +278,7 @@ static int run(int argc, char **argv) {
     std::vector<int64_t> order(L);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
-        const int c = sb.chrom[x].compare(sb.chrom[y]);
+        const int c = sb.chrom(x).compare(sb.chrom(y));
         return c != 0 ? c < 0 : sb.pos[x] < sb.pos[y];
     });
     const std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
@@ -247,9 +292,9 @@ static int run(int argc, char **argv) {
     };
     uint32_t *counts_dev = nullptr;
     int64_t *order_dev = nullptr;
-    hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * sb.counts.size()), "device memory for the counts");
+    hip_ok(hipMalloc((void **)&counts_dev, sb.counts_bytes()), "device memory for the counts");
     hip_ok(hipMalloc((void **)&order_dev, sizeof(int64_t) * L), "device memory");
-    hip_ok(hipMemcpy(counts_dev, sb.counts.data(), sizeof(uint32_t) * sb.counts.size(), hipMemcpyHostToDevice), "H2D counts");
+    hip_ok(hipMemcpy(counts_dev, sb.counts, sb.counts_bytes(), hipMemcpyHostToDevice), "H2D counts");
     hip_ok(hipMemcpy(order_dev, order.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice), "H2D order");
     int64_t p = 0;
     gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, L, n, ph.pool_sizes.data(), &flt, a.keep_p_minus_1 ? 1 : 0, order_dev, &p),
@@ -262,6 +307,7 @@ static int run(int argc, char **argv) {
     hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * p), "device memory");
     hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * p), "device memory");
     gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G_dev, ld, col_locus_dev, col_allele_dev), "load");
+    lap("sort + H2D + GPU loader");
     hip_ok(hipFree(counts_dev), "free");
     hip_ok(hipFree(order_dev), "free");
     std::vector<int64_t> col_locus(p);
@@ -273,7 +319,7 @@ static int run(int argc, char **argv) {
     std::vector<uint64_t> lab_pos{0};
     lab_chr.reserve(p + 1); lab_al.reserve(p + 1); lab_pos.reserve(p + 1);
     for (int64_t c = 0; c < p; ++c) {
-        lab_chr.push_back(sb.chrom[col_locus[c]]); lab_pos.push_back(sb.pos[col_locus[c]]);
+        lab_chr.push_back(sb.chrom(col_locus[c])); lab_pos.push_back(sb.pos[col_locus[c]]);
         lab_al.push_back(std::string(1, ALLELES[col_allele[c]]));
     }
     std::vector<double> Y;
@@ -289,21 +335,21 @@ static int run(int argc, char **argv) {
     hip_ok(hipMemcpy(var.data(), out_dev + (size_t)p * k, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
     hip_ok(hipMemcpy(pval.data(), out_dev + 2 * (size_t)p * k, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
     (void)hipFree(G_dev); (void)hipFree(out_dev); (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
+    lap("kinship + fits + D2H");
     std::string out = a.output;
     if (out.empty()) // ols.rs:393-398
         out = basename_no_ext(a.fname) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";
     FILE *fo = create_new(out);
     fputs("#chr,pos,alleles,phenotype,statistic,pvalue\n", fo); // ols.rs:409
-    for (int j = 0; j < k; ++j)
-        for (int64_t i = 0; i < p; ++i) {
-            // the reference labels coefficient i with entry i of the (1+p)-long label vectors, i.e.
-            // shifted by the intercept entry (ols.rs:421-425) -- reproduced as is
-            const std::string line = lab_chr[i] + "," + std::to_string(lab_pos[i]) + "," + lab_al[i] + ",Pheno_" +
-                                     std::to_string(j) + "," + rust_display(beta[(size_t)i * k + j]) + "," +
-                                     rust_display(pval[(size_t)i * k + j]) + "\n";
-            fputs(line.c_str(), fo);
-        }
+    write_rows_parallel(fo, (int64_t)k * p, a.n_threads, [&](int64_t r, std::string &text) {
+        const int64_t j = r / p, i = r - j * p; // rows are trait-major (ols.rs:411-433)
+        // the reference labels coefficient i with entry i of the (1+p)-long label vectors, i.e.
+        // shifted by the intercept entry (ols.rs:421-425) -- reproduced as is
+        text += lab_chr[i] + "," + std::to_string(lab_pos[i]) + "," + lab_al[i] + ",Pheno_" + std::to_string(j) + "," +
+                rust_display(beta[(size_t)i * k + j]) + "," + rust_display(pval[(size_t)i * k + j]) + "\n";
+    });
     fclose(fo);
+    lap("format + write CSV");
     std::cout << out << "\n";
     return 0;
 }
