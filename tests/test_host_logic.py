@@ -63,3 +63,30 @@ def test_sync_parser_matches_oracle_and_keeps_file_order(oracle):
             parts = got.split(" ")
             assert parts[0] == chrom and int(parts[1]) == pos
             assert [int(x) for x in parts[2:]] == np.asarray(counts).reshape(-1).tolist()
+
+
+def _parse_text(tmp_path, text, threads=2):
+    f = tmp_path / "t.sync"
+    f.write_bytes(text.encode())
+    r = subprocess.run([str(HC), "parse", str(f), str(threads)], capture_output=True, text=True)
+    return r.returncode, r.stdout.splitlines(), r.stderr
+
+
+def test_sync_parser_edge_cases(tmp_path):
+    """Comment lines and lines whose position is not an integer are skipped (both ErrorKind::Other -> `continue`,
+    sync.rs:111-128, :829-846); CRLF is stripped (:104-109); only the first six counts of a pool are used (:141-146);
+    a last line without newline still counts; malformed counts and ragged lines are errors."""
+    run("fmt", stdin="")  # builds hostcheck if needed
+    rc, out, _ = _parse_text(tmp_path, "#c\nchr1\t10\tN\t1:2:3:4:5:6\t7:8:9:10:11:12\r\nchr1\tx\tN\t1:1:1:1:1:1\t1:1:1:1:1:1\n"
+                                      "chr2\t+30\tA\t0:0:0:0:0:4294967295:77\t1:0:0:0:0:0")
+    assert rc == 0
+    assert out == ["2 2", "chr1 10 1 2 3 4 5 6 7 8 9 10 11 12", "chr2 30 0 0 0 0 0 4294967295 1 0 0 0 0 0"]
+    for bad in ("chr1\t1\tN\t1:2:3:4:5\t1:2:3:4:5:6\n",            # five counts
+                "chr1\t1\tN\t1:2:3:4:5:x\t1:2:3:4:5:6\n",          # not an integer
+                "chr1\t1\tN\t1:2:3:4:5:6\t1:2:3:4:5:6\nchr1\t2\tN\t1:2:3:4:5:6\n",   # ragged
+                "chr1\t1\tN\t1:2:3:4:5:4294967296\n",              # beyond the u32 of the device layout
+                "chr1\t1\tN\t1:2:3:4:5:6\n\nchr1\t2\tN\t1:2:3:4:5:6\n"):            # empty line (reference panics)
+        rc, _, err = _parse_text(tmp_path, bad)
+        assert rc != 0 and "hostcheck:" in err, bad
+    rc, out, _ = _parse_text(tmp_path, "# only comments\n#\n")
+    assert rc == 0 and out == ["0 0"]
