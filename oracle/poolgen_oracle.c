@@ -1240,3 +1240,172 @@ int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, co
     if (!perf) free(perf_l);
     return L;
 }
+
+/* ============================================================================================
+ * base/pileup.rs: String::lparse -> PileupLine (:11-155), PileupLine::filter (:239-337),
+ * to_counts (:160-214), pileup_to_sync (:340-371).  Literal restatement, one line at a time.
+ * Return: length of the sync line written to out (> 0), 0 = the reference returns None (locus
+ * dropped; `filter` errors are swallowed by `_ => return None`, :343-346), < 0 = the reference
+ * PANICS for this line (lparse error under .expect(), :425-431):
+ *   -1 position, -2 reference allele, -3 coverage field, -4 coverage / codes / qualities mismatch
+ *   (or a ragged pool triplet), -5 indel length is not a digit.
+ * ============================================================================================ */
+#define ORC_PILEUP_MAXF 4096
+int orc_pileup_to_sync(const char *line, int remove_ns, double max_base_error_rate, uint64_t min_coverage_depth,
+                       double min_coverage_breadth, double min_allele_frequency, const double *pool_sizes,
+                       int n_pool_sizes, char *out, int cap) {
+    /* split("\t") */
+    const char *fs[ORC_PILEUP_MAXF];
+    int fl[ORC_PILEUP_MAXF], nf = 0;
+    {
+        const char *p = line;
+        for (;;) {
+            const char *t = strchr(p, '\t');
+            if (nf >= ORC_PILEUP_MAXF) return -4;
+            fs[nf] = p; fl[nf] = t ? (int)(t - p) : (int)strlen(p); nf++;
+            if (!t) break;
+            p = t + 1;
+        }
+    }
+    if (nf < 3) return -4;
+    /* position: parse::<u64> (digits, optional leading '+') */
+    uint64_t position = 0;
+    {
+        int i = 0, nd = 0;
+        if (fl[1] > 0 && fs[1][0] == '+') i = 1;
+        for (; i < fl[1]; i++) { if (fs[1][i] < '0' || fs[1][i] > '9') return -1; position = position * 10u + (uint64_t)(fs[1][i] - '0'); nd++; }
+        if (nd == 0) return -1;
+    }
+    if (fl[2] != 1 || (unsigned char)fs[2][0] >= 128) return -2; /* parse::<char>: exactly one character */
+    const char ref = fs[2][0];
+    int n = 0;
+    for (int i = 3; i < nf; i += 3) n++;
+    uint64_t *cov = (uint64_t *)calloc(n > 0 ? n : 1, sizeof(uint64_t));
+    unsigned char **codes = (unsigned char **)calloc(n > 0 ? n : 1, sizeof(unsigned char *));
+    unsigned char **quals = (unsigned char **)calloc(n > 0 ? n : 1, sizeof(unsigned char *));
+    int *ncode = (int *)calloc(n > 0 ? n : 1, sizeof(int)), *nqual = (int *)calloc(n > 0 ? n : 1, sizeof(int));
+    int rc = 0, ncodes_parsed = 0, nquals_parsed = 0;
+    for (int i = 3, pool = 0; i < nf; i += 3, pool++) {
+        int j = 0, nd = 0;
+        uint64_t v = 0;
+        if (fl[i] > 0 && fs[i][0] == '+') j = 1;
+        for (; j < fl[i]; j++) { if (fs[i][j] < '0' || fs[i][j] > '9') { rc = -3; goto done; } v = v * 10u + (uint64_t)(fs[i][j] - '0'); nd++; }
+        if (nd == 0) { rc = -3; goto done; }
+        cov[pool] = v;
+    }
+    for (int i = 4; i < nf; i += 3) { /* read codes (:38-128) */
+        const int pool = ((i - 1) / 3) - 1;
+        ncodes_parsed++;
+        if (cov[pool] > 0) {
+            codes[pool] = (unsigned char *)malloc(fl[i] > 0 ? fl[i] : 1);
+            int indel = 0;
+            uint64_t count = 0, left = 4294967295ull;
+            for (int j = 0; j < fl[i]; j++) {
+                const unsigned char code = (unsigned char)fs[i][j];
+                if (indel) {
+                    if (count == 0 && left == 4294967295ull) {
+                        if (code < '0' || code > '9') { rc = -5; goto done; }
+                        count = (uint64_t)(code - '0');
+                        continue;
+                    }
+                    if (count > 0 && left == 4294967295ull) {
+                        if (code >= '0' && code <= '9') { count = count * 10u + (uint64_t)(code - '0'); continue; }
+                        left = count - 1;
+                        continue;
+                    }
+                    if (left > 0) { left -= 1; continue; }
+                    indel = 0; count = 0; left = 4294967295ull;
+                }
+                if (code == 43 || code == 45) { indel = 1; count = 0; continue; }
+                if (code == 94 || code == 36) {
+                    if (code == 94) { indel = 1; count = 1; left = 1; }
+                    continue;
+                }
+                unsigned char a;
+                if (code == 44 || code == 46) a = (unsigned char)ref;
+                else switch (code) {
+                    case 65: case 97: a = 65; break;
+                    case 84: case 116: a = 84; break;
+                    case 67: case 99: a = 67; break;
+                    case 71: case 103: a = 71; break;
+                    case 42: a = 68; break;
+                    default: a = 78;
+                }
+                codes[pool][ncode[pool]++] = a;
+            }
+        }
+    }
+    for (int i = 5; i < nf; i += 3) { /* qualities (:130-139) */
+        const int pool = ((i - 1) / 3) - 1;
+        nquals_parsed++;
+        if (cov[pool] > 0) {
+            quals[pool] = (unsigned char *)malloc(fl[i] > 0 ? fl[i] : 1);
+            memcpy(quals[pool], fs[i], fl[i]);
+            nqual[pool] = fl[i];
+        }
+    }
+    if (ncodes_parsed != n || nquals_parsed != n) { rc = -4; goto done; } /* the sanity loop would index out of bounds */
+    for (int i = 0; i < n; i++)
+        if (cov[i] != (uint64_t)ncode[i] || cov[i] != (uint64_t)nqual[i]) { rc = -4; goto done; }
+    /* ---- filter (:239-337): any Err here is None for pileup_to_sync -------------------------------- */
+    if (n != n_pool_sizes) { rc = 0; goto done; }
+    for (int i = 0; i < n; i++) {
+        int j = 0;
+        while (j < ncode[i]) {
+            if (quals[i][j] < 33) { rc = 0; goto done; } /* "Phred score out of bounds." */
+            const double q = pow(10.0, -((double)quals[i][j] - 33.0) / 10.0);
+            if (q > max_base_error_rate) codes[i][j] = 78;
+            if (remove_ns && codes[i][j] == 78) {
+                memmove(codes[i] + j, codes[i] + j + 1, (size_t)(ncode[i] - j - 1));
+                memmove(quals[i] + j, quals[i] + j + 1, (size_t)(ncode[i] - j - 1));
+                ncode[i]--;
+                cov[i] -= 1;
+            } else j++;
+        }
+    }
+    {
+        const uint32_t min_breadth = (uint32_t)ceil(min_coverage_breadth * (double)n_pool_sizes);
+        uint32_t covered = 0;
+        for (int i = 0; i < n && covered < min_breadth; i++)
+            if (cov[i] >= min_coverage_depth) covered++;
+        if (covered != min_breadth) { rc = 0; goto done; }
+    }
+    {
+        /* to_counts (A,T,C,G,D,N) and to_frequencies: count / row sum (0/0 = NaN) */
+        uint64_t cnt[6];
+        double *fr = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * 6);
+        uint64_t *cm = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1) * 6);
+        for (int i = 0; i < n; i++) {
+            for (int j = 0; j < 6; j++) cnt[j] = 0;
+            for (int j = 0; j < ncode[i]; j++)
+                switch (codes[i][j]) {
+                    case 65: cnt[0]++; break; case 84: cnt[1]++; break; case 67: cnt[2]++; break;
+                    case 71: cnt[3]++; break; case 68: cnt[4]++; break; default: cnt[5]++;
+                }
+            uint64_t rs = 0;
+            for (int j = 0; j < 6; j++) { cm[i * 6 + j] = cnt[j]; rs += cnt[j]; }
+            for (int j = 0; j < 6; j++) fr[i * 6 + j] = (double)cnt[j] / (double)rs;
+        }
+        int m = 6, j = 1; /* the loop as written (:311-331): a failing column is re-tested with a smaller m */
+        while (j < m) {
+            double q = 0.0;
+            for (int i = 0; i < n; i++) q += fr[i * 6 + j] * pool_sizes[i];
+            if ((q < min_allele_frequency) | (q > (1.00 - min_allele_frequency))) m -= 1;
+            else j += 1;
+        }
+        if (m < 2) { free(fr); free(cm); rc = 0; goto done; }
+        int len = snprintf(out, cap, "%.*s\t%llu\t%c", fl[0], fs[0], (unsigned long long)position, ref);
+        for (int i = 0; i < n && len < cap; i++)
+            len += snprintf(out + len, cap - len, "\t%llu:%llu:%llu:%llu:%llu:%llu", (unsigned long long)cm[i * 6],
+                            (unsigned long long)cm[i * 6 + 1], (unsigned long long)cm[i * 6 + 2],
+                            (unsigned long long)cm[i * 6 + 3], (unsigned long long)cm[i * 6 + 4],
+                            (unsigned long long)cm[i * 6 + 5]);
+        if (len < cap) len += snprintf(out + len, cap - len, "\n");
+        rc = len;
+        free(fr); free(cm);
+    }
+done:
+    for (int i = 0; i < n; i++) { free(codes[i]); free(quals[i]); }
+    free(cov); free(codes); free(quals); free(ncode); free(nqual);
+    return rc;
+}

@@ -15,6 +15,7 @@
  *   - multiply_views_* products                       base/helpers.rs:525-540
  *   - gp::ols fit property                            gp/ols.rs:245-246
  *   - expand_and_contract vectors                     gp/penalise.rs:709-720
+ *   - pileup parse / filter / counts                  base/pileup.rs:553-659
  * `ols_with_covariate` (kinship + eig + m rule) and `ols_iterate`'s CSV have NO live reference
  * test or expected-output file: for those two the status is "parity unpinned" beyond the pinned
  * building blocks above (fit kernel via the commented golden gwas/ols.rs:534 for beta only).
@@ -154,6 +155,12 @@ int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, co
                               const int64_t *row_idx, int n_rows, const int32_t *fold_of, int r,
                               int nfolds, double alpha, double lambda_step, double *beta,
                               double *lambdas_out, double *perf, int n_threads);
+
+/* ---- base/pileup.rs: one pileup line -> one sync line (lparse, filter, to_counts, pileup_to_sync) ---------
+ * > 0 bytes written (with the trailing newline), 0 = None (dropped), < 0 = the reference panics on this line. */
+int orc_pileup_to_sync(const char *line, int remove_ns, double max_base_error_rate, uint64_t min_coverage_depth,
+                       double min_coverage_breadth, double min_allele_frequency, const double *pool_sizes,
+                       int n_pool_sizes, char *out, int cap);
 
 #ifdef __cplusplus
 }

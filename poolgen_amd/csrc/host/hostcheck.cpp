@@ -3,6 +3,8 @@
 //   hostcheck phen <file> <delim> <name_col> <size_col> <c1,c2,..>
 //   hostcheck parse <sync> <threads>   : "L n" then one line per locus: chrom pos counts[n*6]
 #include "host_util.h"
+#include "pileup.h"
+#include <fstream>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +45,38 @@ int main(int argc, char **argv) {
                 for (int i = 0; i < sb.n * 6; ++i) std::cout << " " << sb.counts[(size_t)l * sb.n * 6 + i];
                 std::cout << "\n";
             }
+        } else if (mode == "pileuplines") {
+            // hostcheck pileuplines <file> <remove_ns> <max_err> <min_depth> <breadth> <maf> <pool sizes,..>
+            // one answer per input line: "K <sync line>" kept, "D" dropped (None), "E" the reference would panic
+            PileupFilter f;
+            f.remove_ns = std::atoi(argv[3]) != 0;
+            f.max_base_error_rate = std::strtod(argv[4], nullptr);
+            f.min_coverage_depth = std::strtoull(argv[5], nullptr, 10);
+            f.min_coverage_breadth = std::strtod(argv[6], nullptr);
+            f.min_allele_frequency = std::strtod(argv[7], nullptr);
+            for (auto &t : splitc(argv[8])) f.pool_sizes.push_back(std::strtod(t.c_str(), nullptr));
+            const PileupConverter conv(f);
+            std::ifstream in(argv[2]);
+            std::string line, out;
+            while (std::getline(in, line)) {
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                out.clear();
+                try {
+                    if (conv.convert(line.data(), line.data() + line.size(), out)) std::cout << "K " << out;
+                    else std::cout << "D\n";
+                } catch (const std::exception &) { std::cout << "E\n"; }
+            }
+        } else if (mode == "pileup2sync") { // hostcheck pileup2sync <file> <out> <threads> <pool names,..> <filter as above>
+            PileupFilter f;
+            f.remove_ns = std::atoi(argv[6]) != 0;
+            f.max_base_error_rate = std::strtod(argv[7], nullptr);
+            f.min_coverage_depth = std::strtoull(argv[8], nullptr, 10);
+            f.min_coverage_breadth = std::strtod(argv[9], nullptr);
+            f.min_allele_frequency = std::strtod(argv[10], nullptr);
+            for (auto &t : splitc(argv[11])) f.pool_sizes.push_back(std::strtod(t.c_str(), nullptr));
+            const auto t0 = std::chrono::steady_clock::now();
+            const int64_t kept = pileup_to_sync_file(argv[2], splitc(argv[5]), f, argv[3], std::atoi(argv[4]));
+            std::cout << kept << " loci in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s\n";
         } else if (mode == "parsetime") { // throughput of parse_sync_file: hostcheck parsetime <sync> <threads>
             const auto t0 = std::chrono::steady_clock::now();
             const SyncBatch sb = parse_sync_file(argv[2], std::atoi(argv[3]));

@@ -1,10 +1,11 @@
-// main.cpp -- `poolgen` command line for the five hot subcommands, flag-compatible with the
-// reference CLI (src/main.rs:26-143): chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship
+// main.cpp -- `poolgen` command line for the hot subcommands, flag-compatible with the
+// reference CLI (src/main.rs:26-143): pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship
 // (and gp_ols as a plain coefficient dump).  Parsing/formatting/ordering follow the reference
 // (base/sync.rs:606-970, :972-1180; gwas/ols.rs:255-275, :372-433); all arithmetic on the loci
 // is done by libpoolgen_hip.so through its C ABI.  Anything else the reference CLI offers is out
 // of scope and reported as such.
 #include "host_util.h"
+#include "pileup.h"
 #include "../../../include/poolgen_hip.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -168,10 +169,10 @@ static int run(int argc, char **argv) {
     const Args a = parse_args(argc, argv);
     Lap lap;
     const std::map<std::string, int> known{{"chisq_test", 0}, {"pearson_corr", 1}, {"ols_iter", 2},
-                                           {"ols_iter_with_kinship", 3}};
+                                           {"ols_iter_with_kinship", 3}, {"pileup2sync", 4}};
     if (!known.count(a.analysis))
         throw std::runtime_error("Invalid analysis utility for this build: `" + a.analysis +
-                                 "` (available: chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship)");
+                                 "` (available: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship)");
     if (a.generate_plots || a.sig_only)
         throw std::runtime_error("--generate-plots / --output-sig-snps-only call the reference's python scripts and are out of scope here");
     Phen ph = parse_phen(a.phen_fname, a.phen_delim, a.phen_name_col, a.phen_pool_size_col, a.phen_value_col);
@@ -182,6 +183,22 @@ static int run(int argc, char **argv) {
         return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
     };
     pinned.release = [](void *p) { (void)hipHostFree(p); };
+    if (a.analysis == "pileup2sync") { // main.rs:212-225; text to text, no GPU involved
+        PileupFilter pf;
+        pf.remove_ns = !a.keep_ns;
+        pf.max_base_error_rate = a.max_base_error_rate;
+        pf.min_coverage_depth = a.min_coverage_depth;
+        pf.min_coverage_breadth = a.min_coverage_breadth;
+        pf.min_allele_frequency = a.min_allele_frequency;
+        pf.pool_sizes = ph.pool_sizes;
+        std::string out = a.output;
+        if (out.empty()) out = basename_no_ext(a.fname) + "-" + unix_time_string() + ".sync"; // pileup.rs:478-494
+        const int64_t kept = pileup_to_sync_file(a.fname, ph.pool_names, pf, out, a.n_threads);
+        lap("pileup2sync");
+        std::cerr << kept << " loci written\n";
+        std::cout << out << "\n"; // main.rs:507
+        return 0;
+    }
     Ctx gpu; // first: the pinned allocator below needs a HIP context
     lap("start-up");
     SyncBatch sb = parse_sync_file(a.fname, a.n_threads, pinned);

@@ -1,0 +1,43 @@
+// pileup.h -- samtools mpileup text -> sync lines, the `pileup2sync` front end (base/pileup.rs:11-371, :373-545).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pgh {
+
+struct PileupFilter {            // the FilterStats fields PileupLine::filter reads (pileup.rs:239-337)
+    bool remove_ns = true;                 // !--keep-ns
+    double max_base_error_rate = 0.01;
+    uint64_t min_coverage_depth = 1;
+    double min_coverage_breadth = 1.0;
+    double min_allele_frequency = 0.001;
+    std::vector<double> pool_sizes;        // normalised to sum 1 (phen.rs:83-84)
+};
+
+// One converter per run: the per-byte decisions (base code -> allele, phred -> "below the error rate?") are
+// table look-ups.  convert() handles one line [b, e) without its newline: appends the sync line to `out` and
+// returns true when the locus is kept, returns false when the reference returns None, throws
+// std::runtime_error where the reference panics (String::lparse errors under .expect(), pileup.rs:425-431).
+class PileupConverter {
+public:
+    explicit PileupConverter(const PileupFilter &f);
+    bool convert(const char *b, const char *e, std::string &out) const;
+    int pools() const { return (int)f_.pool_sizes.size(); }
+
+private:
+    PileupFilter f_;
+    uint32_t min_breadth_;
+    bool low_quality_[256];   // 10^(-(q-33)/10) > max_base_error_rate
+    unsigned char base_[256]; // read code -> allele byte; 0 = "the reference allele"
+    unsigned char column_[256]; // allele byte -> count column (A,T,C,G,D,N = 0..5)
+    unsigned char special_[128]; // 1 for the read codes that are not a base: + - ^ $
+};
+
+// Whole file with `n_threads` workers over byte ranges split at line starts; loci in file order; header
+// "#chr\tpos\tref\t<pool names>" (pileup.rs:519-521); refuses to overwrite (create_new, :511-517).  Returns the
+// number of loci written.
+int64_t pileup_to_sync_file(const std::string &fname, const std::vector<std::string> &pool_names,
+                            const PileupFilter &f, const std::string &out_fname, int n_threads);
+
+} // namespace pgh

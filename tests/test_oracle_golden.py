@@ -195,3 +195,28 @@ def test_sym_eig_against_numpy(oracle):
     w = np.linalg.eigvalsh(A)[::-1]
     assert np.allclose(ev, w, rtol=1e-12)
     assert np.allclose(A @ V, V * ev, atol=1e-10 * w[0])
+
+
+def test_pileup_reference_literal(oracle):
+    """base/pileup.rs:553-659: parse (indels, read starts/ends, deletions), counts in A,T,C,G,D,N order, and the
+    phred filter that turns the Q = 22 read of pool 5 into an N and removes it."""
+    g = LIT["pileup"]
+    ps = g["filter"]["pool_sizes"]
+    rc, text = oracle.pileup_to_sync(g["line"], ps, remove_ns=True, max_base_error_rate=1.0, min_allele_frequency=0.0)
+    want = "Chromosome1\t456527\tC\t" + "\t".join(":".join(map(str, r)) for r in g["counts_ATCGDN"]) + "\n"
+    assert rc == len(want) and text == want
+    f = g["filter"]
+    rc, text = oracle.pileup_to_sync(g["line"], ps, f["remove_ns"], f["max_base_error_rate"], f["min_coverage_depth"],
+                                     f["min_coverage_breadth"], f["min_allele_frequency"])
+    cov = [sum(map(int, fld.split(":"))) for fld in text.rstrip("\n").split("\t")[3:]]
+    assert rc > 0 and cov == g["filtered_coverages"]
+    assert text.rstrip("\n").split("\t")[-1] == "0:1:5:0:0:0"
+    # the reference's min-allele-frequency loop only ever tests column 1 (T) first: a locus without T reads is dropped
+    rc, _ = oracle.pileup_to_sync("c\t1\tA\t2\t.C\tJJ\t2\t..\tJJ", [0.5, 0.5], min_allele_frequency=0.01)
+    assert rc == 0
+    rc, _ = oracle.pileup_to_sync("c\t1\tA\t2\t.T\tJJ\t2\t..\tJJ", [0.5, 0.5], min_allele_frequency=0.01)
+    assert rc > 0
+    # malformed lines are fatal in the reference (lparse under .expect())
+    assert oracle.pileup_to_sync("c\tx\tA\t1\t.\tJ", [1.0])[0] == -1
+    assert oracle.pileup_to_sync("c\t1\tA\t2\t.\tJ", [1.0])[0] == -4
+    assert oracle.pileup_to_sync("c\t1\tA\t1\t.+xa\tJ", [1.0])[0] == -5
