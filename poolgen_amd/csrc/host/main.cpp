@@ -201,8 +201,27 @@ static int run(int argc, char **argv) {
     }
     Ctx gpu; // first: the pinned allocator below needs a HIP context
     lap("start-up");
-    SyncBatch sb = parse_sync_file(a.fname, a.n_threads, pinned);
-    lap("parse sync");
+    // A pileup input (*.pileup / *.mpileup) is converted in memory -- the counts pileup2sync would write and the
+    // sync reader would read back, without the text in between (an extension: the reference needs the sync file).
+    auto ends_with = [](const std::string &x, const char *suf) {
+        const size_t m = std::strlen(suf);
+        return x.size() >= m && x.compare(x.size() - m, m, suf) == 0;
+    };
+    SyncBatch sb;
+    if (ends_with(a.fname, ".pileup") || ends_with(a.fname, ".mpileup")) {
+        PileupFilter pf;
+        pf.remove_ns = !a.keep_ns;
+        pf.max_base_error_rate = a.max_base_error_rate;
+        pf.min_coverage_depth = a.min_coverage_depth;
+        pf.min_coverage_breadth = a.min_coverage_breadth;
+        pf.min_allele_frequency = a.min_allele_frequency;
+        pf.pool_sizes = ph.pool_sizes;
+        sb = parse_pileup_file(a.fname, a.n_threads, pf, pinned);
+        lap("pileup -> counts");
+    } else {
+        sb = parse_sync_file(a.fname, a.n_threads, pinned);
+        lap("parse sync");
+    }
     if (sb.size() == 0) throw std::runtime_error("no loci in " + a.fname);
     if (sb.n != ph.n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
     pg_filter flt{};

@@ -49,7 +49,7 @@ PileupConverter::PileupConverter(const PileupFilter &f) : f_(f) {
     column_[65] = 0; column_[84] = 1; column_[67] = 2; column_[71] = 3; column_[68] = 4;
 }
 
-bool PileupConverter::convert(const char *b, const char *e, std::string &out) const {
+bool PileupConverter::decode(const char *b, const char *e, Locus &L) const {
     // ---- String::lparse (pileup.rs:11-155): any defect of the line's format is fatal -------------------
     const char *t0 = field_end(b, e);
     if (t0 == e) bad("a line has fewer than three tab-separated fields");
@@ -155,18 +155,25 @@ bool PileupConverter::convert(const char *b, const char *e, std::string &out) co
         }
         if (m < 2) return false;
     }
+    L.chrom = b; L.chrom_len = (size_t)(t0 - b); L.pos = pos; L.ref = ref; L.n = n; L.counts = counts.data();
+    return true;
+}
+
+bool PileupConverter::convert(const char *b, const char *e, std::string &out) const {
+    Locus L;
+    if (!decode(b, e, L)) return false;
     // ---- pileup_to_sync (:348-371): chr, pos, ref, then A:T:C:G:D:N per pool -----------------------------
-    out.append(b, (size_t)(t0 - b));
+    out.append(L.chrom, L.chrom_len);
     out.push_back('\t');
     char num[24];
     auto put = [&](uint64_t v) { out.append(num, (size_t)(std::to_chars(num, num + sizeof num, v).ptr - num)); };
-    put(pos);
+    put(L.pos);
     out.push_back('\t');
-    out.push_back((char)ref);
-    for (int i = 0; i < n; ++i)
+    out.push_back((char)L.ref);
+    for (int i = 0; i < L.n; ++i)
         for (int j = 0; j < 6; ++j) {
             out.push_back(j == 0 ? '\t' : ':');
-            put(counts[(size_t)i * 6 + j]);
+            put(L.counts[(size_t)i * 6 + j]);
         }
     out.push_back('\n');
     return true;
@@ -231,6 +238,118 @@ int64_t pileup_to_sync_file(const std::string &fname, const std::vector<std::str
     for (int t = 0; t < parts; ++t) { std::fwrite(text[t].data(), 1, text[t].size(), fo); total += kept[t]; }
     std::fclose(fo);
     return total;
+}
+
+SyncBatch parse_pileup_file(const std::string &fname, int n_threads, const PileupFilter &f, const SyncAlloc &alloc) {
+    const int fd = ::open(fname.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("The input file: " + fname + " does not exist. Please make sure you are entering the correct filename and/or the correct path.");
+    struct stat st;
+    if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat " + fname); }
+    const size_t sz = (size_t)st.st_size;
+    const char *buf = nullptr;
+    if (sz) {
+        void *m = ::mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot map " + fname); }
+        buf = (const char *)m;
+    }
+    ::close(fd);
+    struct Unmap { const char *p; size_t n; ~Unmap() { if (p && n) ::munmap(const_cast<char *>(p), n); } } unmap{buf, sz};
+    if (n_threads < 1) n_threads = 1;
+    std::vector<size_t> cuts{0};
+    for (int t = 1; t < n_threads; ++t) {
+        size_t c = sz / n_threads * t;
+        if (c <= cuts.back()) continue;
+        const void *nl = std::memchr(buf + c, '\n', sz - c);
+        c = nl ? (size_t)((const char *)nl - buf) + 1 : sz;
+        if (c > cuts.back() && c < sz) cuts.push_back(c);
+    }
+    cuts.push_back(sz);
+    const int parts = (int)cuts.size() - 1;
+    const PileupConverter conv(f);
+    SyncBatch sb;
+    sb.n = conv.pools();
+    if (sb.n == 0 || sz == 0) return sb;
+    // pass 1: lines per range (an upper bound of the loci kept), so that every worker owns a slice
+    std::vector<int64_t> cand(parts, 0), base(parts + 1, 0), kept(parts, 0);
+    std::vector<std::string> err(parts);
+    std::vector<std::vector<std::string>> names(parts);
+    auto run_all = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < parts; ++t)
+            th.emplace_back([&, t] { try { fn(t); } catch (const std::exception &e) { err[t] = e.what(); } });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < parts; ++t) if (!err[t].empty()) throw std::runtime_error(err[t]);
+    };
+    run_all([&](int t) {
+        int64_t c = 0;
+        for (const char *p = buf + cuts[t], *end = buf + cuts[t + 1]; p < end;) {
+            const void *nl = std::memchr(p, '\n', (size_t)(end - p));
+            ++c;
+            p = nl ? (const char *)nl + 1 : end;
+        }
+        cand[t] = c;
+    });
+    for (int t = 0; t < parts; ++t) base[t + 1] = base[t] + cand[t];
+    const int64_t Lcand = base[parts];
+    const size_t bytes = sizeof(uint32_t) * (size_t)Lcand * sb.n * 6;
+    sb.counts = static_cast<uint32_t *>(alloc.alloc ? alloc.alloc(bytes ? bytes : 1) : std::malloc(bytes ? bytes : 1));
+    sb.release = alloc.alloc ? alloc.release : nullptr;
+    if (!sb.counts) throw std::runtime_error("out of memory for the allele counts of " + fname);
+    sb.chrom_id.resize(Lcand);
+    sb.pos.resize(Lcand);
+    run_all([&](int t) {
+        int64_t li = base[t];
+        int last = -1;
+        std::vector<std::string> &nm = names[t];
+        for (const char *p = buf + cuts[t], *end = buf + cuts[t + 1]; p < end;) {
+            const void *nl = std::memchr(p, '\n', (size_t)(end - p));
+            const char *le = nl ? (const char *)nl : end;
+            const char *q = le;
+            if (q > p && q[-1] == '\r') --q;
+            PileupConverter::Locus L;
+            if (conv.decode(p, q, L)) {
+                if (last < 0 || nm[last].size() != L.chrom_len || std::memcmp(nm[last].data(), L.chrom, L.chrom_len) != 0) {
+                    last = -1;
+                    for (size_t i = 0; i < nm.size(); ++i)
+                        if (nm[i].size() == L.chrom_len && std::memcmp(nm[i].data(), L.chrom, L.chrom_len) == 0) { last = (int)i; break; }
+                    if (last < 0) { nm.emplace_back(L.chrom, L.chrom_len); last = (int)nm.size() - 1; }
+                }
+                uint32_t *dst = sb.counts + (size_t)li * sb.n * 6;
+                for (int i = 0; i < sb.n * 6; ++i) {
+                    if (L.counts[i] > 0xFFFFFFFFull) throw std::runtime_error("pileup: a count exceeds 32 bits");
+                    dst[i] = (uint32_t)L.counts[i];
+                }
+                sb.chrom_id[li] = last;
+                sb.pos[li] = L.pos;
+                ++li;
+            }
+            p = nl ? le + 1 : end;
+        }
+        kept[t] = li - base[t];
+    });
+    std::vector<std::vector<int32_t>> remap(parts);
+    for (int t = 0; t < parts; ++t)
+        for (const std::string &s2 : names[t]) {
+            int g = -1;
+            for (size_t i = 0; i < sb.chrom_names.size(); ++i) if (sb.chrom_names[i] == s2) { g = (int)i; break; }
+            if (g < 0) { sb.chrom_names.push_back(s2); g = (int)sb.chrom_names.size() - 1; }
+            remap[t].push_back(g);
+        }
+    int64_t w = 0;
+    for (int t = 0; t < parts; ++t) { // close the holes the dropped loci left at the end of every slice
+        const int64_t r0 = base[t], cnt = kept[t];
+        for (int64_t i = 0; i < cnt; ++i) sb.chrom_id[r0 + i] = remap[t][sb.chrom_id[r0 + i]];
+        if (w != r0 && cnt > 0) {
+            std::memmove(sb.counts + (size_t)w * sb.n * 6, sb.counts + (size_t)r0 * sb.n * 6, sizeof(uint32_t) * (size_t)cnt * sb.n * 6);
+            std::memmove(sb.chrom_id.data() + w, sb.chrom_id.data() + r0, sizeof(int32_t) * cnt);
+            std::memmove(sb.pos.data() + w, sb.pos.data() + r0, sizeof(uint64_t) * cnt);
+        }
+        w += cnt;
+    }
+    sb.L = w;
+    sb.chrom_id.resize(w);
+    sb.pos.resize(w);
+    return sb;
 }
 
 } // namespace pgh

@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include "host_util.h"
 
 namespace pgh {
 
@@ -21,8 +22,17 @@ struct PileupFilter {            // the FilterStats fields PileupLine::filter re
 // std::runtime_error where the reference panics (String::lparse errors under .expect(), pileup.rs:425-431).
 class PileupConverter {
 public:
+    struct Locus {                      // what a kept line decodes to
+        const char *chrom = nullptr;    // into the line
+        size_t chrom_len = 0;
+        uint64_t pos = 0;
+        unsigned char ref = 0;
+        int n = 0;
+        const uint64_t *counts = nullptr; // n x 6 in pileup_to_sync's column order A,T,C,G,D,N (thread-local storage)
+    };
     explicit PileupConverter(const PileupFilter &f);
-    bool convert(const char *b, const char *e, std::string &out) const;
+    bool decode(const char *b, const char *e, Locus &out) const;           // lparse + filter + to_counts
+    bool convert(const char *b, const char *e, std::string &out) const;    // decode + the sync text line
     int pools() const { return (int)f_.pool_sizes.size(); }
 
 private:
@@ -39,5 +49,11 @@ private:
 // number of loci written.
 int64_t pileup_to_sync_file(const std::string &fname, const std::vector<std::string> &pool_names,
                             const PileupFilter &f, const std::string &out_fname, int n_threads);
+
+// The same conversion straight into a counts batch (what parse_sync_file would return for the sync file that
+// pileup_to_sync_file writes, without the text round trip): column POSITIONS are kept, i.e. position 4 holds the
+// deletion count and position 5 the N count, exactly what the sync reader finds there (and labels N and D,
+// base/sync.rs:134 vs pileup.rs:184).
+SyncBatch parse_pileup_file(const std::string &fname, int n_threads, const PileupFilter &f, const SyncAlloc &alloc);
 
 } // namespace pgh
