@@ -89,6 +89,7 @@ int pg_thin_qr(const double *Z, int n, int c, double *Q);
 std::vector<double> pg_tdist_coef(int df);
 // symmetric pseudo-inverse with the reference's tolerance (helpers.rs:463-482)
 int pg_pinv_sym(const double *A, int n, double *out);
+int pg_pinv_solve_sym(const double *A, int n, const double *B, int k, double *X); // pinv(A) B, Cholesky when A is safely SPD
 
 // launchers (defined in the .hip files)
 int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,

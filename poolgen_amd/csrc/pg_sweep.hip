@@ -596,16 +596,12 @@ extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
     }
     // every training subset's X X^T is a principal sub-block of the full-data one
     const int r = n_rows;
-    std::vector<double> A((size_t)r * r), Pi((size_t)r * r), V((size_t)r * k);
-    for (int a = 0; a < r; ++a)
+    std::vector<double> A((size_t)r * r), Ysub((size_t)r * k), V((size_t)r * k);
+    for (int a = 0; a < r; ++a) {
         for (int b = 0; b < r; ++b) A[(size_t)a * r + b] = full[(size_t)row_idx[a] * n + row_idx[b]];
-    if (pg_pinv_sym(A.data(), r, Pi.data()) != 0) return pg_fail(ctx, PG_ERR_INVALID, "gp_ols: pinv failed");
-    for (int a = 0; a < r; ++a)
-        for (int j = 0; j < k; ++j) {
-            double s = 0.0;
-            for (int b = 0; b < r; ++b) s += Pi[(size_t)a * r + b] * Y[(size_t)row_idx[b] * k + j];
-            V[(size_t)a * k + j] = s;
-        }
+        for (int j = 0; j < k; ++j) Ysub[(size_t)a * k + j] = Y[(size_t)row_idx[a] * k + j];
+    }
+    if (pg_pinv_solve_sym(A.data(), r, Ysub.data(), k, V.data()) != 0) return pg_fail(ctx, PG_ERR_INVALID, "gp_ols: pinv failed");
     const int n_even = (n + 1) & ~1;
     std::vector<double> Z((size_t)n_even * cols, 0.0), b0(k, 0.0);
     for (int a = 0; a < r; ++a)
