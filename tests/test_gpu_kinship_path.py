@@ -185,6 +185,22 @@ def test_gp_ols_matches_oracle(engine, oracle, n, p, k, rows):
     assert np.array_equal(beta, beta2)
 
 
+def test_gp_ols_with_duplicated_pools_uses_the_pseudo_inverse(engine, oracle):
+    """Two identical pools make X X^T singular: the reference's pinv (helpers.rs:463-482) drops the null
+    direction.  The product's fast path (Cholesky) must hand such a matrix to the eigen-based pseudo-inverse."""
+    n, p = 30, 2000
+    G, Y = make(p, n, 51)
+    G[:, 7] = G[:, 3]                      # pool 7 = pool 3
+    Y = Y[:, :1].copy(); Y[7] = Y[3]
+    idx = np.arange(n)
+    beta = engine.gp_ols(G, Y, idx, n=n).cpu().numpy()
+    Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])
+    rc, ref = oracle.gp_ols(Xt, Y, idx, n=n)
+    assert rc == 0
+    assert np.allclose(beta, ref, rtol=1e-6, atol=1e-8 * np.abs(ref).max())
+    assert np.allclose(Xt.T @ beta, Y, atol=1e-6 * np.abs(Y).max())
+
+
 @pytest.mark.parametrize("n,p,k,alpha", [(60, 3000, 1, 0.0), (40, 2000, 2, 0.0), (50, 1500, 1, 1.0)])
 def test_gp_ridge_path_matches_oracle(engine, oracle, n, p, k, alpha):
     """penalise_ridge_like / the lambda path with k-fold CV (gp/penalise.rs:133-159, :461-669) with the
