@@ -220,6 +220,12 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     // extra barrier (a wave's own LDS writes and reads are ordered).
     const int NV = 2 + P.k;
     double *scratch = ylds + KIN_FUSE_MAXK * 256 + wave * (4 * 64); // [4 values][64 lanes]
+    // this lane's four pools' centred phenotypes: registers, not one more LDS read per use
+    double yreg[KIN_FUSE_MAXK][4];
+#pragma unroll
+    for (int t = 0; t < KIN_FUSE_MAXK; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yreg[t][j] = (FUSE && t < P.k) ? ylds[t * 256 + lane + 64 * j] : 0.0;
     auto spec_pass = [&](const double *buf, int64_t lbase) {
 #pragma unroll
         for (int jl = 0; jl < KIN_KC / KIN_WAVES; ++jl) {
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
                 s2 = fma(d, d, s2);
 #pragma unroll
                 for (int t = 0; t < KIN_FUSE_MAXK; ++t)
-                    if (t < P.k) sy[t] = fma(d, ylds[t * 256 + pool], sy[t]);
+                    sy[t] = fma(d, yreg[t][j], sy[t]); // traits beyond P.k carry zeros
             }
             scratch[lane] = s1;
             scratch[64 + lane] = s2;
@@ -312,12 +318,20 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
             const double *buf = lds + (c & 1) * bufsz;
             const double *fb0 = lanebase + (c & 1) * bufsz;
             const double *fb1 = lanebase + ((c + 1) & 1) * bufsz;
+            // FUSE: the per-locus sums are VALU/LDS work that only overlaps the matrix cores if the waves of a
+            // SIMD do it at DIFFERENT times: with compile-time wave ids (W >= 0) wave w of SIMD w % 4 runs its
+            // spec_pass after item (w / 4) * NQ / 4 of the MFMA block instead of all four at its end.
+#ifndef KIN_SPEC_STAGGER
+#define KIN_SPEC_STAGGER 1
+#endif
+            constexpr int spec_at = (FUSE && W >= 0 && KIN_SPEC_STAGGER) ? ((W / 4) % 4) * ((NQ - D) / 4) : -1;
             static_for<NQ - D>([&](auto qc) {
+                if constexpr (decltype(qc)::value == spec_at) spec_pass(buf, l_begin + (int64_t)c * KIN_KC);
                 frag_load(fb0, std::integral_constant<int, decltype(qc)::value + D>{});
                 mfma_item(qc);
             });
             if (more) stage_store((c + 1) & 1);
-            if (FUSE) spec_pass(buf, l_begin + (int64_t)c * KIN_KC); // staging registers are free again here
+            if (FUSE && spec_at < 0) spec_pass(buf, l_begin + (int64_t)c * KIN_KC); // staging registers are free again here
             __syncthreads();
             static_for<D>([&](auto dc) {
                 constexpr int q = NQ - D + decltype(dc)::value;
