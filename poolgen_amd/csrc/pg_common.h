@@ -89,6 +89,9 @@ int pg_thin_qr(const double *Z, int n, int c, double *Q);
 std::vector<double> pg_tdist_coef(int df);
 // symmetric pseudo-inverse with the reference's tolerance (helpers.rs:463-482)
 int pg_pinv_sym(const double *A, int n, double *out);
+int pg_gp_subset_solve(const double *xxt, int n, const double *Y, int k, const int64_t *rows, int r, double *V);
+int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Z_host, int ncol,
+                    double *out_dev);
 int pg_pinv_solve_sym(const double *A, int n, const double *B, int k, double *X); // pinv(A) B, Cholesky when A is safely SPD
 
 // launchers (defined in the .hip files)

@@ -20,6 +20,8 @@
 #include "pg_common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -40,11 +42,11 @@ __device__ __forceinline__ double gp_norm(double b, double alpha) { // :259-261
 }
 
 // max over the slopes (rows 1..p of column j) of the penalty norm; partial maxima per block
-__global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k, int j, double alpha,
+__global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k, int j, int row0, double alpha,
                               double *__restrict__ part) {
     double m = 0.0;
     for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < p; l += (int64_t)gridDim.x * blockDim.x)
-        m = fmax(m, gp_norm(beta[(l + 1) * k + j], alpha));
+        m = fmax(m, gp_norm(beta[(l + row0) * k + j], alpha));
     for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
     __shared__ double sm[16];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
@@ -57,13 +59,13 @@ __global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k,
 
 // For every lambda_i: subtracted/added masses of the penalised set and the norm masses of the
 // de-penalised set, split by the sign of b (:296-326).  part: [block][4][GP_LMAX].
-__global__ void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, PathParams P,
+__global__ void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, int row0, PathParams P,
                                double *__restrict__ part) {
     double sp[GP_LMAX], ap[GP_LMAX], sd[GP_LMAX], ad[GP_LMAX];
 #pragma unroll
     for (int i = 0; i < GP_LMAX; ++i) { sp[i] = 0.0; ap[i] = 0.0; sd[i] = 0.0; ad[i] = 0.0; }
     for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < p; l += (int64_t)gridDim.x * blockDim.x) {
-        const double b = beta[(l + 1) * k + j];
+        const double b = beta[(l + row0) * k + j];
         const double nrm = gp_norm(b, P.alpha);
         const double sc = nrm / P.nmax; // normed_proxy / normed_proxy_max (:282), a true division: max/max == 1
         const bool pos = b >= 0.0;
@@ -165,6 +167,52 @@ __global__ __launch_bounds__(256) void k_gp_predict(const double *__restrict__ G
     }
 }
 
+// All folds of a repetition at once: bf (p x C) holds the slopes of every fold's training fit (column of pool i
+// for this trait = colof[i], the fold that VALIDATES pool i -- every pool is validated by exactly one fold, so one
+// pass over G serves all of them).  The contracted coefficient is formed on the fly from the fold's masses
+// (the very arithmetic of gp_contract); partials and their reduction are laid out as in k_gp_predict.
+struct FoldMasses { double nmax, sub_scale[GP_LMAX], add_scale[GP_LMAX]; };
+__global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
+                                                          int C, const int32_t *__restrict__ colof,
+                                                          const FoldMasses *__restrict__ FM, PathParams P0, int64_t p,
+                                                          int n, int64_t ld, int64_t loci_per_block,
+                                                          double *__restrict__ part) {
+    const int pool = blockIdx.y * 256 + threadIdx.x;
+    const int64_t l0 = (int64_t)blockIdx.x * loci_per_block;
+    const int64_t l1 = min(p, l0 + loci_per_block);
+    double acc[GP_LMAX];
+#pragma unroll
+    for (int i = 0; i < GP_LMAX; ++i) acc[i] = 0.0;
+    const bool inr = pool < n;
+    const int c = inr ? colof[pool] : -1;
+    const bool on = c >= 0;
+    const FoldMasses fm = FM[on ? c : 0];
+    const double *gp = G + (inr ? pool : 0);
+    const double *bp = bf + (on ? c : 0);
+    if (on) {
+        for (int64_t l = l0; l < l1; ++l) {
+            const double g = gp[l * ld];
+            const double b = bp[l * C];
+            const double nrm = gp_norm(b, P0.alpha);
+            const double sc = nrm / fm.nmax;
+            const bool pos = b >= 0.0;
+            const double pen = pos ? (((b - nrm) < 0.0) ? 0.0 : b - nrm) : (((b + nrm) > 0.0) ? 0.0 : b + nrm);
+#pragma unroll
+            for (int i = 0; i < GP_LMAX; ++i) {
+                if (i < P0.L) {
+                    const double dep = pos ? b + fm.sub_scale[i] * nrm : b - fm.add_scale[i] * nrm;
+                    acc[i] = fma(g, (sc < P0.lambda[i]) ? pen : dep, acc[i]);
+                }
+            }
+        }
+    }
+    if (inr) {
+        double *o = part + ((size_t)blockIdx.x * n + pool) * GP_LMAX;
+#pragma unroll
+        for (int i = 0; i < GP_LMAX; ++i) o[i] = acc[i];
+    }
+}
+
 __global__ void k_gp_predict_reduce(const double *__restrict__ part, int nblocks, int n, double *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x; // pool * GP_LMAX + i
     if (idx >= n * GP_LMAX) return;
@@ -196,10 +244,10 @@ struct RidgeWork {
 
 // steps 2-4 for trait j of `beta_dev`; returns the path parameters with the masses filled in
 int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int j, double alpha,
-                      const std::vector<double> &path, RidgeWork &W, PathParams &P) {
+                      const std::vector<double> &path, RidgeWork &W, PathParams &P, int row0 = 1) {
     const int nb = 1024;
     std::vector<double> h((size_t)nb * 4 * GP_LMAX);
-    hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, alpha, W.part);
+    hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, alpha, W.part);
     PG_HIP(ctx, hipGetLastError());
     PG_HIP(ctx, hipMemcpyAsync(h.data(), W.part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -210,7 +258,7 @@ int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int
     P.nmax = mx;
     P.L = (int)path.size();
     for (int i = 0; i < P.L; ++i) P.lambda[i] = path[i];
-    hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, W.part);
+    hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, P, W.part);
     PG_HIP(ctx, hipGetLastError());
     PG_HIP(ctx, hipMemcpyAsync(h.data(), W.part, sizeof(double) * nb * 4 * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -279,12 +327,115 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
 
     std::vector<double> perf((size_t)n_reps * n_folds * L * k, NAN), b0(k), yh((size_t)n * GP_LMAX);
     std::vector<int64_t> itr, iva;
-    for (int rep = 0; rep < n_reps; ++rep)
+    for (int i = 0; i < n_reps * n_rows; ++i)
+        if (fold_of[i] < 0 || fold_of[i] >= n_folds) { ctx->err = "gp_ridge: fold id out of range"; return fail(PG_ERR_INVALID); }
+    // error_index (:359-426) of trait j on the validation pools `iva`, for every lambda, from yhat (n x GP_LMAX)
+    auto score = [&](int rep, int fold, int j, double b0j, const std::vector<int64_t> &iva_) {
+        const int nv = (int)iva_.size();
+        std::vector<double> yt(nv), yp(nv);
+        double mn = 0, mx = 0;
+        for (int i = 0; i < nv; ++i) {
+            yt[i] = Y[(size_t)iva_[i] * k + j];
+            if (i == 0 || yt[i] < mn) mn = yt[i];
+            if (i == 0 || yt[i] > mx) mx = yt[i];
+        }
+        for (int li = 0; li < L; ++li) {
+            for (int i = 0; i < nv; ++i) yp[i] = b0j + yh[(size_t)iva_[i] * GP_LMAX + li];
+            const double cor = host_pearson_r(yt, yp);
+            double mae = 0, mse = 0;
+            for (int i = 0; i < nv; ++i) { const double d = yt[i] - yp[i]; mae += std::fabs(d); mse += d * d; }
+            mae /= (mx - mn);
+            mse /= ((mx - mn) * (mx - mn));
+            const double rmse = std::sqrt(mse) / (mx - mn);
+            perf[(((size_t)rep * n_folds + fold) * L + li) * k + j] = ((1.0 - std::fabs(cor)) + mae + mse + rmse) / 4.0;
+        }
+    };
+    // Every pool is validated by exactly ONE fold of a repetition, so all folds share two passes over G: one that
+    // forms the slopes of every fold's training fit (n_folds * k coefficient columns), one that predicts every
+    // pool with the coefficients of the fold that holds it out.  (Fallback below: one pair of passes per fold.)
+    const int C = n_folds * k;
+    const bool fused = C <= PG_MAX_SWEEP_COLS && !std::getenv("POOLGEN_RIDGE_PER_FOLD");
+    double *bf = nullptr;       // p x C slopes of the folds' fits
+    FoldMasses *fm_dev = nullptr;
+    int32_t *colof_dev = nullptr;
+    if (fused) {
+        if (hipMalloc((void **)&bf, sizeof(double) * (size_t)p * C) != hipSuccess ||
+            hipMalloc((void **)&fm_dev, sizeof(FoldMasses) * C) != hipSuccess ||
+            hipMalloc((void **)&colof_dev, sizeof(int32_t) * n) != hipSuccess) {
+            (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev);
+            return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: out of device memory"));
+        }
+    }
+    auto fail2 = [&](int rc) { (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev); return fail(rc); };
+    for (int rep = 0; rep < n_reps && fused; ++rep) {
+        std::vector<std::vector<int64_t>> tr(n_folds), va(n_folds);
+        for (int i = 0; i < n_rows; ++i) {
+            const int f = fold_of[(size_t)rep * n_rows + i];
+            for (int g = 0; g < n_folds; ++g) (g == f ? va[g] : tr[g]).push_back(row_idx[i]);
+        }
+        // host: pinv(X X^T) y of every fold (independent: one thread each), scattered into Z (n x C)
+        std::vector<double> Z((size_t)n * C, 0.0), b0c(C, 0.0);
+        std::vector<int> bad(n_folds, 0);
+        {
+            std::vector<std::thread> th;
+            for (int f = 0; f < n_folds; ++f) {
+                if (va[f].empty() || tr[f].empty()) continue; // an empty fold leaves NaN, as an empty slice would
+                th.emplace_back([&, f] {
+                    const int r = (int)tr[f].size();
+                    std::vector<double> V((size_t)r * k);
+                    if (pg_gp_subset_solve(xxt.data(), n, Y, k, tr[f].data(), r, V.data()) != 0) { bad[f] = 1; return; }
+                    for (int a2 = 0; a2 < r; ++a2)
+                        for (int j = 0; j < k; ++j) {
+                            Z[(size_t)tr[f][a2] * C + f * k + j] = V[(size_t)a2 * k + j];
+                            b0c[f * k + j] += V[(size_t)a2 * k + j];
+                        }
+                });
+            }
+            for (auto &x : th) x.join();
+        }
+        for (int f = 0; f < n_folds; ++f)
+            if (bad[f]) return fail2(pg_fail(ctx, PG_ERR_INVALID, "gp_ridge: pinv failed"));
+        int rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Z.data(), C, bf); // :526 for every fold at once
+        if (rc) return fail2(rc);
+        // the redistribution masses of every (fold, trait) column
+        std::vector<FoldMasses> fm(C);
+        PathParams P0;
+        std::memset(&P0, 0, sizeof P0);
+        for (int f = 0; f < n_folds; ++f)
+            for (int j = 0; j < k; ++j) {
+                if (va[f].empty() || tr[f].empty()) { std::memset(&fm[f * k + j], 0, sizeof(FoldMasses)); fm[f * k + j].nmax = 1.0; continue; }
+                PathParams P;
+                rc = ridge_path_params(ctx, bf, p, C, f * k + j, alpha, path, W, P, 0);
+                if (rc) return fail2(rc);
+                fm[f * k + j].nmax = P.nmax;
+                for (int i = 0; i < GP_LMAX; ++i) { fm[f * k + j].sub_scale[i] = P.sub_scale[i]; fm[f * k + j].add_scale[i] = P.add_scale[i]; }
+                P0 = P; // alpha, lambda[], L are the same for every column
+            }
+        if (hipMemcpyAsync(fm_dev, fm.data(), sizeof(FoldMasses) * C, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
+        for (int j = 0; j < k; ++j) {
+            std::vector<int32_t> colof(n, -1);
+            for (int f = 0; f < n_folds; ++f)
+                if (!va[f].empty() && !tr[f].empty())
+                    for (int64_t pool : va[f]) colof[pool] = f * k + j;
+            if (hipMemcpyAsync(colof_dev, colof.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
+            hipLaunchKernelGGL(k_gp_predict_folds, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, bf, C, colof_dev,
+                               fm_dev, P0, p, n, ld, lpb, W.part);
+            hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
+            for (int f = 0; f < n_folds; ++f)
+                if (!va[f].empty() && !tr[f].empty()) score(rep, f, j, b0c[f * k + j], va[f]);
+        }
+    }
+    (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev);
+    for (int rep = 0; rep < n_reps && !fused; ++rep)
         for (int fold = 0; fold < n_folds; ++fold) {
             itr.clear(); iva.clear();
             for (int i = 0; i < n_rows; ++i) {
                 const int f = fold_of[(size_t)rep * n_rows + i];
-                if (f < 0 || f >= n_folds) { ctx->err = "gp_ridge: fold id out of range"; return fail(PG_ERR_INVALID); }
                 (f == fold ? iva : itr).push_back(row_idx[i]);
             }
             if (iva.empty() || itr.empty()) continue; // an empty fold leaves NaN, as an empty slice would
@@ -302,25 +453,7 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
                 if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                     hipStreamSynchronize(ctx->stream) != hipSuccess)
                     return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
-                // error_index (:359-426) on the validation pools
-                const int nv = (int)iva.size();
-                std::vector<double> yt(nv), yp(nv);
-                double mn = 0, mx = 0;
-                for (int i = 0; i < nv; ++i) {
-                    yt[i] = Y[(size_t)iva[i] * k + j];
-                    if (i == 0 || yt[i] < mn) mn = yt[i];
-                    if (i == 0 || yt[i] > mx) mx = yt[i];
-                }
-                for (int li = 0; li < L; ++li) {
-                    for (int i = 0; i < nv; ++i) yp[i] = b0[j] + yh[(size_t)iva[i] * GP_LMAX + li];
-                    const double cor = host_pearson_r(yt, yp);
-                    double mae = 0, mse = 0;
-                    for (int i = 0; i < nv; ++i) { const double d = yt[i] - yp[i]; mae += std::fabs(d); mse += d * d; }
-                    mae /= (mx - mn);
-                    mse /= ((mx - mn) * (mx - mn));
-                    const double rmse = std::sqrt(mse) / (mx - mn);
-                    perf[(((size_t)rep * n_folds + fold) * L + li) * k + j] = ((1.0 - std::fabs(cor)) + mae + mse + rmse) / 4.0;
-                }
+                score(rep, fold, j, b0[j], iva);
             }
         }
     // all-rows fit, per trait the mode over repetitions of the per-repetition arg-min (:573-627)

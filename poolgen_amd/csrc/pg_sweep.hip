@@ -565,6 +565,60 @@ static int launch_gp_beta(pg_ctx *ctx, const double *G, const double *W, double 
     return PG_OK;
 }
 
+// ---- internal pieces of gp::ols shared with the ridge path (pg_gp.hip) ---------------------------------
+// V (r x k) = pinv(A) Y_rows with A the principal sub-block `rows` of the full-data X X^T (n x n, host)
+int pg_gp_subset_solve(const double *xxt, int n, const double *Y, int k, const int64_t *rows, int r, double *V) {
+    std::vector<double> A((size_t)r * r), Ysub((size_t)r * k);
+    for (int a = 0; a < r; ++a) {
+        for (int b = 0; b < r; ++b) A[(size_t)a * r + b] = xxt[(size_t)rows[a] * n + rows[b]];
+        for (int j = 0; j < k; ++j) Ysub[(size_t)a * k + j] = Y[(size_t)rows[a] * k + j];
+    }
+    return pg_pinv_solve_sym(A.data(), r, Ysub.data(), k, V);
+}
+
+// out (p x ncol, device) = G Z for a host Z (n x ncol row-major): the slopes of `ncol` fits in ONE pass over G
+int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Z_host, int ncol,
+                    double *out_dev) {
+    const int cols = round_cols(ncol);
+    if (cols < 0) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp: at most %d coefficient columns per pass", PG_MAX_SWEEP_COLS);
+    const int n_even = (n + 1) & ~1;
+    std::vector<double> Z((size_t)n_even * cols, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < ncol; ++c) Z[(size_t)i * cols + c] = Z_host[(size_t)i * ncol + c];
+    const size_t zbytes = Z.size() * sizeof(double);
+    if (zbytes > ctx->W_cap) {
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->W_dev) PG_HIP(ctx, hipFree(ctx->W_dev));
+        ctx->W_dev = nullptr; ctx->W_cap = 0;
+        PG_HIP(ctx, hipMalloc((void **)&ctx->W_dev, zbytes));
+        ctx->W_cap = zbytes;
+    }
+    ctx->st_m = -1; // the regression state in W_dev is gone
+    ctx->st_Y.clear();
+    PG_HIP(ctx, hipMemcpyAsync(ctx->W_dev, Z.data(), zbytes, hipMemcpyHostToDevice, ctx->stream));
+    SweepDims D;
+    std::memset(&D, 0, sizeof D);
+    D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = ncol;
+    int64_t blocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
+    const int64_t cap = (int64_t)ctx->cus * 8;
+    const int grid = (int)(blocks < cap ? blocks : cap);
+    int rc;
+    switch (cols) {
+    case 2: rc = launch_gp_beta<2>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    case 3: rc = launch_gp_beta<3>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    case 4: rc = launch_gp_beta<4>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    case 6: rc = launch_gp_beta<6>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    case 8: rc = launch_gp_beta<8>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    case 12: rc = launch_gp_beta<12>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    case 16: rc = launch_gp_beta<16>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    case 24: rc = launch_gp_beta<24>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    default: rc = launch_gp_beta<PG_MAX_SWEEP_COLS>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
+    }
+    if (rc) return rc;
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Z is stack-owned
+    return PG_OK;
+}
+
 extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
                              int k, const int64_t *row_idx, int n_rows, const double *XXt_host_or_null,
                              double *beta_dev) {
@@ -574,8 +628,7 @@ extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
     PG_CHECK(ctx, ld >= n && (ld % 2) == 0, "gp_ols: ld must be even and >= n");
     if ((int64_t)n >= p + 1)
         return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: tall design (n >= 1 + p) is not a GPU problem");
-    const int cols = round_cols(k);
-    if (cols < 0) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: at most %d traits per call", PG_MAX_SWEEP_COLS);
+    if (k > 8) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: at most 8 traits per call");
     for (int a = 0; a < n_rows; ++a) PG_CHECK(ctx, row_idx[a] >= 0 && row_idx[a] < n, "gp_ols: row index out of range");
     PG_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<double> full((size_t)n * n);
@@ -596,48 +649,16 @@ extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
     }
     // every training subset's X X^T is a principal sub-block of the full-data one
     const int r = n_rows;
-    std::vector<double> A((size_t)r * r), Ysub((size_t)r * k), V((size_t)r * k);
-    for (int a = 0; a < r; ++a) {
-        for (int b = 0; b < r; ++b) A[(size_t)a * r + b] = full[(size_t)row_idx[a] * n + row_idx[b]];
-        for (int j = 0; j < k; ++j) Ysub[(size_t)a * k + j] = Y[(size_t)row_idx[a] * k + j];
-    }
-    if (pg_pinv_solve_sym(A.data(), r, Ysub.data(), k, V.data()) != 0) return pg_fail(ctx, PG_ERR_INVALID, "gp_ols: pinv failed");
-    const int n_even = (n + 1) & ~1;
-    std::vector<double> Z((size_t)n_even * cols, 0.0), b0(k, 0.0);
+    std::vector<double> V((size_t)r * k);
+    if (pg_gp_subset_solve(full.data(), n, Y, k, row_idx, r, V.data()) != 0) return pg_fail(ctx, PG_ERR_INVALID, "gp_ols: pinv failed");
+    std::vector<double> Z((size_t)n * k, 0.0), b0(k, 0.0);
     for (int a = 0; a < r; ++a)
         for (int j = 0; j < k; ++j) {
-            Z[(size_t)row_idx[a] * cols + j] = V[(size_t)a * k + j];
+            Z[(size_t)row_idx[a] * k + j] = V[(size_t)a * k + j];
             b0[j] += V[(size_t)a * k + j]; // intercept column of X is all ones
         }
-    const size_t zbytes = Z.size() * sizeof(double);
-    if (zbytes > ctx->W_cap) {
-        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->W_dev) PG_HIP(ctx, hipFree(ctx->W_dev));
-        ctx->W_dev = nullptr; ctx->W_cap = 0;
-        PG_HIP(ctx, hipMalloc((void **)&ctx->W_dev, zbytes));
-        ctx->W_cap = zbytes;
-    }
-    ctx->st_m = -1; // the regression state in W_dev is gone
-    PG_HIP(ctx, hipMemcpyAsync(ctx->W_dev, Z.data(), zbytes, hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(beta_dev, b0.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
-    const int cus = ctx->cus;
-    SweepDims D;
-    std::memset(&D, 0, sizeof D);
-    D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = k;
-    int64_t blocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
-    const int64_t cap = (int64_t)cus * 8;
-    const int grid = (int)(blocks < cap ? blocks : cap);
-    double *out = beta_dev + k; // rows 1..p
-    int rc;
-    switch (cols) {
-    case 2: rc = launch_gp_beta<2>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
-    case 3: rc = launch_gp_beta<3>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
-    case 4: rc = launch_gp_beta<4>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
-    case 6: rc = launch_gp_beta<6>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
-    case 8: rc = launch_gp_beta<8>(ctx, G_dev, ctx->W_dev, out, D, grid); break;
-    default: return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: at most 8 traits per call");
-    }
+    int rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Z.data(), k, beta_dev + k); // rows 1..p
     if (rc) return rc;
-    PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Z / b0 are stack-owned
     return PG_OK;
 }

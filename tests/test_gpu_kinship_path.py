@@ -222,6 +222,15 @@ def test_gp_ridge_path_matches_oracle(engine, oracle, n, p, k, alpha):
     # the reference's unit vectors (gp/penalise.rs:709-720) through the same device code path: alpha = 1,
     # lambda = 0.5 contracts the small coefficients and moves their mass to the large ones
     assert len(np.unique(lam)) >= 1 and np.all((lam >= 0) & (lam <= 1))
+    # all folds of a repetition share two passes over G (the default); one pair of passes per fold must agree
+    import os
+    os.environ["POOLGEN_RIDGE_PER_FOLD"] = "1"
+    try:
+        beta2, lam2, perf2 = engine.gp_ridge(G, Y, rows, folds, n_folds, alpha=alpha, n=n)
+    finally:
+        del os.environ["POOLGEN_RIDGE_PER_FOLD"]
+    assert np.array_equal(lam2, lam) and np.allclose(perf2, perf, rtol=1e-12, atol=1e-13)
+    assert np.allclose(beta2.cpu().numpy(), b, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("p,n,k", [(6000, 200, 2), (5000, 200, 3), (3000, 33, 1), (2000, 100, 2), (4000, 208, 1), (1500, 193, 1)])
