@@ -104,25 +104,48 @@ Phen parse_phen(const std::string &fname, const std::string &delim, int name_col
 // ---- sync parsing -----------------------------------------------------------------------------
 SyncBatch &SyncBatch::operator=(SyncBatch &&o) noexcept {
     if (this != &o) {
-        if (counts) (release ? release : std::free)(counts);
+        if (counts) { if (release) release(counts); else std::free(counts); }
         n = o.n; L = o.L;
         chrom_id = std::move(o.chrom_id); chrom_names = std::move(o.chrom_names); pos = std::move(o.pos);
-        counts = o.counts; release = o.release;
+        counts = o.counts; release = std::move(o.release);
         o.counts = nullptr; o.L = 0;
     }
     return *this;
 }
 SyncBatch::~SyncBatch() {
-    if (counts) (release ? release : std::free)(counts);
+    if (counts) { if (release) release(counts); else std::free(counts); }
+}
+
+MappedFile::MappedFile(const std::string &fname) {
+    const std::string notfound = "The input file: " + fname + " does not exist. Please make sure you are entering the correct filename and/or the correct path.";
+    const int fd = ::open(fname.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error(notfound);
+    struct stat st;
+    if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error(notfound); }
+    n_ = (size_t)st.st_size;
+    if (n_) {
+        void *m = ::mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot map " + fname); }
+        p_ = (const char *)m;
+    }
+    ::close(fd);
+}
+MappedFile::~MappedFile() { if (p_ && n_) ::munmap(const_cast<char *>(p_), n_); }
+std::vector<size_t> MappedFile::cuts(size_t pieces) const {
+    if (pieces < 1) pieces = 1;
+    std::vector<size_t> c{0};
+    for (size_t t = 1; t < pieces; ++t) {
+        size_t x = n_ / pieces * t;
+        if (x <= c.back()) continue;
+        const void *nl = std::memchr(p_ + x, '\n', n_ - x);
+        x = nl ? (size_t)((const char *)nl - p_) + 1 : n_;
+        if (x > c.back() && x < n_) c.push_back(x);
+    }
+    c.push_back(n_);
+    return c;
 }
 
 namespace {
-
-struct Mapped { // the file, read-only, mapped
-    const char *p = nullptr;
-    size_t sz = 0;
-    ~Mapped() { if (p && sz) ::munmap(const_cast<char *>(p), sz); }
-};
 
 inline const char *line_end(const char *p, const char *end) {
     const void *nl = std::memchr(p, '\n', (size_t)(end - p));
@@ -231,7 +254,11 @@ int64_t parse_range(const char *b, const char *e, int n, uint32_t *counts, int32
 } // namespace
 
 SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc alloc) {
-    const std::string notfound = "The input file: " + fname + " does not exist. Please make sure you are entering the correct filename and/or the correct path.";
+    const MappedFile mf(fname);
+    return parse_sync_buffer(mf.data(), mf.data() + mf.size(), n_threads, 0, std::move(alloc));
+}
+
+SyncBatch parse_sync_buffer(const char *bb, const char *be, int n_threads, int expect_n, SyncAlloc alloc) {
     const bool timing = std::getenv("PGH_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_last = now();
@@ -241,22 +268,9 @@ SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc all
         std::fprintf(stderr, "parse_sync_file: %-12s %.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
         t_last = t;
     };
-    const int fd = ::open(fname.c_str(), O_RDONLY);
-    if (fd < 0) throw std::runtime_error(notfound);
-    struct stat st;
-    if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error(notfound); }
-    Mapped mp;
-    mp.sz = (size_t)st.st_size;
-    if (mp.sz) {
-        // MAP_POPULATE: one batched population of the page tables instead of a trap per 4 KiB page
-        void *m = ::mmap(nullptr, mp.sz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-        if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot map " + fname); }
-        mp.p = (const char *)m;
-    }
-    ::close(fd);
-    lap("map");
-    const char *buf = mp.p;
-    const size_t sz = mp.sz;
+    const char *buf = bb;
+    const size_t sz = (size_t)(be - bb);
+    const std::string fname = "the sync input";
     if (n_threads < 1) n_threads = 1;
     // byte ranges split at line starts (helpers.rs:74-91)
     std::vector<size_t> cuts{0};
@@ -280,6 +294,7 @@ SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc all
                 for (const char *c = p; c < le; ++c) tabs += (*c == '\t');
                 if (tabs < 3) throw std::runtime_error("sync file: a line has fewer than four tab-separated fields");
                 sb.n = tabs - 2;
+                if (expect_n > 0 && sb.n != expect_n) throw std::runtime_error("sync file: inconsistent number of pools");
                 break;
             }
             if (le == p) throw std::runtime_error("empty line in sync file");
@@ -306,7 +321,7 @@ SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc all
     const int64_t Lcand = base[parts];
     const size_t bytes = sizeof(uint32_t) * (size_t)Lcand * sb.n * 6;
     sb.counts = static_cast<uint32_t *>(alloc.alloc ? alloc.alloc(bytes ? bytes : 1) : std::malloc(bytes ? bytes : 1));
-    sb.release = alloc.alloc ? alloc.release : nullptr;
+    if (alloc.alloc) sb.release = alloc.release ? alloc.release : [](void *) {};
     if (!sb.counts) throw std::runtime_error("out of memory for the allele counts of " + fname);
     sb.chrom_id.resize(Lcand);
     sb.pos.resize(Lcand);

@@ -3,6 +3,7 @@
 // locus filter (base/sync.rs:100-304, :477-506), all in the reference's operation order.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -34,7 +35,7 @@ struct SyncBatch {
     std::vector<std::string> chrom_names;   // distinct chromosome names in order of first appearance
     std::vector<uint64_t> pos;
     uint32_t *counts = nullptr;
-    void (*release)(void *) = nullptr;
+    std::function<void(void *)> release;   // empty = free()
     int64_t size() const { return L; }
     const std::string &chrom(int64_t l) const { return chrom_names[chrom_id[l]]; }
     size_t counts_bytes() const { return sizeof(uint32_t) * (size_t)L * n * 6; }
@@ -46,8 +47,22 @@ struct SyncBatch {
     ~SyncBatch();
 };
 struct SyncAlloc {
-    void *(*alloc)(size_t) = nullptr;   // nullptr = malloc / free
-    void (*release)(void *) = nullptr;
+    std::function<void *(size_t)> alloc;    // empty = malloc / free
+    std::function<void(void *)> release;
+};
+// A read-only mapping of a file, and its cut points at line starts (helpers.rs:74-91) for a target piece size.
+class MappedFile {
+public:
+    explicit MappedFile(const std::string &fname);
+    ~MappedFile();
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+    const char *data() const { return p_; }
+    size_t size() const { return n_; }
+    std::vector<size_t> cuts(size_t pieces) const; // pieces + 1 offsets (fewer if lines are long), first 0, last size()
+private:
+    const char *p_ = nullptr;
+    size_t n_ = 0;
 };
 // String::lparse for every line of the file (base/sync.rs:100-156): `n_threads` workers over byte
 // ranges split at line starts (helpers.rs:74-91), loci in file order.  Lines starting with '#' and
@@ -55,6 +70,9 @@ struct SyncAlloc {
 // answers with `continue`, sync.rs:111-128, :829-846); allele counts that are not integers are an error
 // (`expect`, :141).  Only the first six ':'-separated counts of a pool are used, as in the reference.
 SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc alloc = SyncAlloc());
+// the same for a byte range [b, e) that starts at a line start (a chunk of a file streamed in pieces); expect_n > 0
+// fixes the number of pools (0 = take it from the first data line of the range)
+SyncBatch parse_sync_buffer(const char *b, const char *e, int n_threads, int expect_n, SyncAlloc alloc = SyncAlloc());
 
 extern const char ALLELES[7];
 

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <numeric>
@@ -33,6 +34,7 @@ struct Args {
     uint64_t min_coverage_depth = 1;
     bool keep_ns = false, keep_p_minus_1 = false, generate_plots = false, sig_only = false;
     int phen_name_col = 0, phen_pool_size_col = 1, n_threads = 1;
+    long stream_chunk_mb = -1; // ols_iter_with_kinship: pieces of this size are parsed / copied / loaded in turn (-1 = automatic)
     std::vector<int> phen_value_col{2};
 };
 
@@ -80,6 +82,7 @@ static Args parse_args(int argc, char **argv) {
         else if (k == "--generate-plots") a.generate_plots = true;
         else if (k == "--output-sig-snps-only") a.sig_only = true;
         else if (k == "--keep-lowercase-reference") { /* pileup only */ }
+        else if (k == "--stream-chunk-mb") a.stream_chunk_mb = std::stol(val());
         else if (k.rfind("-", 0) == 0) throw std::runtime_error("unknown flag " + k);
         else pos.push_back(k);
     }
@@ -165,6 +168,167 @@ struct Lap {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// ols_iter_with_kinship on an input that is read in PIECES (config 5 of BASELINE.json: a file far larger than
+// host memory): while the GPU takes piece c (H2D from pinned memory, loader, partial kinship), the worker
+// threads already parse piece c + 1 into the other pinned buffer.  The frequency matrix stays resident in HBM
+// piece by piece (288 GB hold 180 M columns of 200 pools); the host only keeps labels and results.
+// The input must be sorted by (chromosome, position) -- what the whole-file path obtains by sorting
+// (sync.rs:1092-1101) cannot be had across pieces -- and that is checked.
+// ---------------------------------------------------------------------------------------------------------
+static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap, size_t chunk_bytes, bool is_pileup,
+                                const PileupFilter &pf, const pg_filter &flt) {
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    };
+    const MappedFile mf(a.fname);
+    const std::vector<size_t> cuts = mf.cuts((mf.size() + chunk_bytes - 1) / chunk_bytes);
+    const int nchunks = (int)cuts.size() - 1;
+    const int n = ph.n, k = ph.k;
+    const std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
+    if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
+    const int n2 = (int)keep.size();
+    const int64_t ld = n2 + (n2 & 1);
+    std::vector<int32_t> pool_map(n, -1);
+    for (int i = 0; i < n2; ++i) pool_map[keep[i]] = i;
+    // two pinned buffers that grow on demand and are handed out in turn
+    struct Slot { void *p = nullptr; size_t cap = 0; } slot[2];
+    auto alloc_for = [&](int i) {
+        SyncAlloc al;
+        al.alloc = [&slot, i](size_t bytes) -> void * {
+            if (bytes > slot[i].cap) {
+                if (slot[i].p) (void)hipHostFree(slot[i].p);
+                slot[i].p = nullptr; slot[i].cap = 0;
+                const size_t want = bytes + bytes / 8;
+                if (hipHostMalloc(&slot[i].p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+                slot[i].cap = want;
+            }
+            return slot[i].p;
+        };
+        al.release = [](void *) {};
+        return al;
+    };
+    auto parse_piece = [&](int c) {
+        const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
+        return is_pileup ? parse_pileup_buffer(b, e, a.n_threads, pf, alloc_for(c & 1))
+                         : parse_sync_buffer(b, e, a.n_threads, n, alloc_for(c & 1));
+    };
+    std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, 0);
+    std::vector<double *> Gs;
+    std::vector<int64_t> ps;
+    std::vector<std::string> chrom_names;             // global dictionary
+    std::vector<int32_t> lab_chr;                     // per column
+    std::vector<uint64_t> lab_pos;
+    std::vector<char> lab_al;
+    std::vector<double> S_total((size_t)n2 * n2, 0.0), S_piece((size_t)n2 * n2);
+    double *S_dev = nullptr;
+    hip_ok(hipMalloc((void **)&S_dev, sizeof(double) * n2 * n2), "device memory");
+    uint32_t *counts_dev = nullptr;
+    size_t counts_cap = 0;
+    std::string last_chrom;
+    uint64_t last_pos = 0;
+    bool have_last = false;
+    for (int c = 0; c < nchunks; ++c) {
+        SyncBatch sb = next.get();
+        if (c + 1 < nchunks) next = std::async(std::launch::async, parse_piece, c + 1);
+        if (sb.L == 0) continue;
+        if (sb.n != n) throw std::runtime_error("the number of pools in the input and in the phenotype file differ");
+        for (int64_t l = 0; l < sb.L; ++l) { // sortedness, within and across pieces
+            const std::string &ch = sb.chrom(l);
+            if (have_last) {
+                const int cmp = last_chrom.compare(ch);
+                if (cmp > 0 || (cmp == 0 && last_pos > sb.pos[l]))
+                    throw std::runtime_error("streamed ols_iter_with_kinship needs the input sorted by chromosome and position (line of " +
+                                             ch + ":" + std::to_string(sb.pos[l]) + "); use --stream-chunk-mb 0 to load the whole file");
+                if (cmp != 0) last_chrom = ch;
+            } else { last_chrom = ch; have_last = true; }
+            last_pos = sb.pos[l];
+        }
+        if (sb.counts_bytes() > counts_cap) {
+            if (counts_dev) hip_ok(hipFree(counts_dev), "free");
+            counts_cap = sb.counts_bytes() + sb.counts_bytes() / 8;
+            hip_ok(hipMalloc((void **)&counts_dev, counts_cap), "device memory for the counts");
+        }
+        hip_ok(hipMemcpyAsync(counts_dev, sb.counts, sb.counts_bytes(), hipMemcpyHostToDevice, nullptr), "H2D counts");
+        int64_t pc = 0;
+        gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, sb.L, n, ph.pool_sizes.data(), &flt, a.keep_p_minus_1 ? 1 : 0, nullptr, &pc), "load");
+        if (pc == 0) continue;
+        double *G = nullptr;
+        int64_t *col_locus_dev = nullptr;
+        int32_t *col_allele_dev = nullptr;
+        hip_ok(hipMalloc((void **)&G, sizeof(double) * (size_t)pc * ld), "device memory for the genotype matrix");
+        hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * pc), "device memory");
+        hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * pc), "device memory");
+        gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G, ld, col_locus_dev, col_allele_dev), "load");
+        std::vector<int64_t> col_locus(pc);
+        std::vector<int32_t> col_allele(pc);
+        hip_ok(hipMemcpy(col_locus.data(), col_locus_dev, sizeof(int64_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
+        hip_ok(hipMemcpy(col_allele.data(), col_allele_dev, sizeof(int32_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
+        (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
+        std::vector<int32_t> remap(sb.chrom_names.size());
+        for (size_t i = 0; i < sb.chrom_names.size(); ++i) {
+            int g = -1;
+            for (size_t j = 0; j < chrom_names.size(); ++j) if (chrom_names[j] == sb.chrom_names[i]) { g = (int)j; break; }
+            if (g < 0) { chrom_names.push_back(sb.chrom_names[i]); g = (int)chrom_names.size() - 1; }
+            remap[i] = g;
+        }
+        for (int64_t q = 0; q < pc; ++q) {
+            lab_chr.push_back(remap[sb.chrom_id[col_locus[q]]]);
+            lab_pos.push_back(sb.pos[col_locus[q]]);
+            lab_al.push_back(ALLELES[col_allele[q]]);
+        }
+        gpu.ok(pg_kinship_partial_dev(gpu.c, G, pc, n2, ld, S_dev), "kinship");
+        hip_ok(hipMemcpy(S_piece.data(), S_dev, sizeof(double) * n2 * n2, hipMemcpyDeviceToHost), "D2H kinship");
+        for (size_t i = 0; i < S_total.size(); ++i) S_total[i] += S_piece[i];
+        Gs.push_back(G);
+        ps.push_back(pc);
+    }
+    if (counts_dev) (void)hipFree(counts_dev);
+    for (auto &sl : slot) if (sl.p) (void)hipHostFree(sl.p);
+    lap("pieces: parse | H2D + loader + partial kinship");
+    int64_t p = 0;
+    for (int64_t x : ps) p += x;
+    if (p <= 0) throw std::runtime_error("no loci passed the filters");
+    std::vector<double> Y;
+    for (int i : keep) for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]);
+    if (!a.output.empty()) { FILE *t = create_new(a.output); fclose(t); ::unlink(a.output.c_str()); } // ols.rs:285
+    hip_ok(hipMemcpy(S_dev, S_total.data(), sizeof(double) * n2 * n2, hipMemcpyHostToDevice), "H2D kinship");
+    int m = 0;
+    gpu.ok(pg_kinship_set(gpu.c, S_dev, p, n2, Y.data(), k, a.xxt, -1, &m, nullptr, nullptr), "ols_iter_with_kinship");
+    std::vector<double> beta((size_t)p * k), pval((size_t)p * k);
+    int64_t off = 0;
+    for (size_t c = 0; c < Gs.size(); ++c) {
+        double *out_dev = nullptr;
+        const size_t cnt = (size_t)ps[c] * k;
+        hip_ok(hipMalloc((void **)&out_dev, sizeof(double) * 3 * cnt), "device memory for the results");
+        gpu.ok(pg_ols_sweep_dev(gpu.c, Gs[c], ps[c], n2, ld, out_dev, out_dev + cnt, out_dev + 2 * cnt), "ols_iter_with_kinship");
+        gpu.ok(pg_synchronize(gpu.c), "ols_iter_with_kinship");
+        hip_ok(hipMemcpy(beta.data() + (size_t)off * k, out_dev, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H results");
+        hip_ok(hipMemcpy(pval.data() + (size_t)off * k, out_dev + 2 * cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H results");
+        (void)hipFree(out_dev);
+        (void)hipFree(Gs[c]);
+        off += ps[c];
+    }
+    (void)hipFree(S_dev);
+    lap("eigen rule + fits + D2H");
+    std::string out = a.output;
+    if (out.empty()) // ols.rs:393-398
+        out = basename_no_ext(a.fname) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";
+    FILE *fo = create_new(out);
+    fputs("#chr,pos,alleles,phenotype,statistic,pvalue\n", fo); // ols.rs:409
+    write_rows_parallel(fo, (int64_t)k * p, a.n_threads, [&](int64_t r, std::string &text) {
+        const int64_t j = r / p, i = r - j * p; // rows are trait-major (ols.rs:411-433)
+        // coefficient i carries label i of the (1+p)-long vectors whose entry 0 is "intercept" (ols.rs:421-425)
+        if (i == 0) text += "intercept,0,intercept";
+        else { text += chrom_names[lab_chr[i - 1]]; text += ","; text += std::to_string(lab_pos[i - 1]); text += ","; text.push_back(lab_al[i - 1]); }
+        text += ",Pheno_" + std::to_string(j) + "," + rust_display(beta[(size_t)i * k + j]) + "," + rust_display(pval[(size_t)i * k + j]) + "\n";
+    });
+    fclose(fo);
+    lap("format + write CSV");
+    std::cout << out << "\n";
+    return 0;
+}
+
 static int run(int argc, char **argv) {
     const Args a = parse_args(argc, argv);
     Lap lap;
@@ -207,15 +371,31 @@ static int run(int argc, char **argv) {
         const size_t m = std::strlen(suf);
         return x.size() >= m && x.compare(x.size() - m, m, suf) == 0;
     };
+    const bool is_pileup = ends_with(a.fname, ".pileup") || ends_with(a.fname, ".mpileup");
+    PileupFilter pf;
+    pf.remove_ns = !a.keep_ns;
+    pf.max_base_error_rate = a.max_base_error_rate;
+    pf.min_coverage_depth = a.min_coverage_depth;
+    pf.min_coverage_breadth = a.min_coverage_breadth;
+    pf.min_allele_frequency = a.min_allele_frequency;
+    pf.pool_sizes = ph.pool_sizes;
+    pg_filter flt{};
+    flt.remove_ns = a.keep_ns ? 0 : 1;
+    flt.min_coverage_depth = a.min_coverage_depth;
+    flt.min_allele_frequency = a.min_allele_frequency;
+    flt.max_missingness_rate = a.max_missingness_rate;
+    if (a.analysis == "ols_iter_with_kinship") {
+        // large inputs are taken in pieces (default: 2 GiB of text each once the file exceeds 8 GiB)
+        struct stat st;
+        const size_t fsize = ::stat(a.fname.c_str(), &st) == 0 ? (size_t)st.st_size : 0;
+        long mb = a.stream_chunk_mb;
+        if (mb < 0) mb = fsize > ((size_t)8 << 30) ? 2048 : 0;
+        size_t piece = (size_t)(mb > 0 ? mb : 0) << 20;
+        if (const char *e = std::getenv("PGH_STREAM_CHUNK_BYTES")) piece = (size_t)std::strtoull(e, nullptr, 10); // tests: small pieces
+        if (piece > 0 && fsize > piece) return run_kinship_streamed(a, ph, gpu, lap, piece, is_pileup, pf, flt);
+    }
     SyncBatch sb;
-    if (ends_with(a.fname, ".pileup") || ends_with(a.fname, ".mpileup")) {
-        PileupFilter pf;
-        pf.remove_ns = !a.keep_ns;
-        pf.max_base_error_rate = a.max_base_error_rate;
-        pf.min_coverage_depth = a.min_coverage_depth;
-        pf.min_coverage_breadth = a.min_coverage_breadth;
-        pf.min_allele_frequency = a.min_allele_frequency;
-        pf.pool_sizes = ph.pool_sizes;
+    if (is_pileup) {
         sb = parse_pileup_file(a.fname, a.n_threads, pf, pinned);
         lap("pileup -> counts");
     } else {
@@ -224,11 +404,6 @@ static int run(int argc, char **argv) {
     }
     if (sb.size() == 0) throw std::runtime_error("no loci in " + a.fname);
     if (sb.n != ph.n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
-    pg_filter flt{};
-    flt.remove_ns = a.keep_ns ? 0 : 1;
-    flt.min_coverage_depth = a.min_coverage_depth;
-    flt.min_allele_frequency = a.min_allele_frequency;
-    flt.max_missingness_rate = a.max_missingness_rate;
     const int n = sb.n, k = ph.k;
     const int64_t L = sb.size();
     const int mode = known.at(a.analysis);

@@ -241,19 +241,14 @@ int64_t pileup_to_sync_file(const std::string &fname, const std::vector<std::str
 }
 
 SyncBatch parse_pileup_file(const std::string &fname, int n_threads, const PileupFilter &f, const SyncAlloc &alloc) {
-    const int fd = ::open(fname.c_str(), O_RDONLY);
-    if (fd < 0) throw std::runtime_error("The input file: " + fname + " does not exist. Please make sure you are entering the correct filename and/or the correct path.");
-    struct stat st;
-    if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat " + fname); }
-    const size_t sz = (size_t)st.st_size;
-    const char *buf = nullptr;
-    if (sz) {
-        void *m = ::mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot map " + fname); }
-        buf = (const char *)m;
-    }
-    ::close(fd);
-    struct Unmap { const char *p; size_t n; ~Unmap() { if (p && n) ::munmap(const_cast<char *>(p), n); } } unmap{buf, sz};
+    const MappedFile mf(fname);
+    return parse_pileup_buffer(mf.data(), mf.data() + mf.size(), n_threads, f, alloc);
+}
+
+SyncBatch parse_pileup_buffer(const char *bb, const char *be, int n_threads, const PileupFilter &f, const SyncAlloc &alloc) {
+    const char *buf = bb;
+    const size_t sz = (size_t)(be - bb);
+    const std::string fname = "the pileup input";
     if (n_threads < 1) n_threads = 1;
     std::vector<size_t> cuts{0};
     for (int t = 1; t < n_threads; ++t) {
@@ -293,7 +288,7 @@ SyncBatch parse_pileup_file(const std::string &fname, int n_threads, const Pileu
     const int64_t Lcand = base[parts];
     const size_t bytes = sizeof(uint32_t) * (size_t)Lcand * sb.n * 6;
     sb.counts = static_cast<uint32_t *>(alloc.alloc ? alloc.alloc(bytes ? bytes : 1) : std::malloc(bytes ? bytes : 1));
-    sb.release = alloc.alloc ? alloc.release : nullptr;
+    if (alloc.alloc) sb.release = alloc.release ? alloc.release : [](void *) {};
     if (!sb.counts) throw std::runtime_error("out of memory for the allele counts of " + fname);
     sb.chrom_id.resize(Lcand);
     sb.pos.resize(Lcand);

@@ -55,5 +55,6 @@ int64_t pileup_to_sync_file(const std::string &fname, const std::vector<std::str
 // deletion count and position 5 the N count, exactly what the sync reader finds there (and labels N and D,
 // base/sync.rs:134 vs pileup.rs:184).
 SyncBatch parse_pileup_file(const std::string &fname, int n_threads, const PileupFilter &f, const SyncAlloc &alloc);
+SyncBatch parse_pileup_buffer(const char *b, const char *e, int n_threads, const PileupFilter &f, const SyncAlloc &alloc);
 
 } // namespace pgh

@@ -172,3 +172,31 @@ def test_pileup_input_equals_pileup2sync_then_analysis(tmp_path):
                                capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
         assert a.read_text() == b.read_text() and a.read_text().count("\n") > 100, analysis
+
+
+def _read_kinship_csv(path):
+    rows = [l.rstrip("\n").split(",") for l in Path(path).read_text().splitlines()[1:]]
+    return [r[:4] for r in rows], np.array([[float(r[4]), float(r[5])] for r in rows])
+
+
+def test_streamed_kinship_equals_whole_file(tmp_path):
+    """ols_iter_with_kinship on an input taken in pieces (double-buffered pinned parse, per-piece loader and partial
+    kinship): same labels and, up to the summation order of the kinship partials, the same numbers as the whole-file
+    path; an unsorted input is refused (the (chromosome, position) sort cannot be done across pieces)."""
+    import os, subprocess
+    exe = ROOT / "poolgen_amd" / "csrc" / "poolgen"
+    lines = [l for l in (GOLD / "test.sync").read_text().splitlines() if not l.startswith("#")]
+    lines.sort(key=lambda l: (l.split("\t")[0].encode(), int(l.split("\t")[1])))
+    srt = tmp_path / "sorted.sync"; srt.write_text("\n".join(lines) + "\n")
+    base = [str(exe), "ols_iter_with_kinship", "-p", str(GOLD / "test.csv"), "--phen-value-col", "2,3", "--n-threads", "3", "-x", "0.5"]
+    whole, piece = tmp_path / "whole.csv", tmp_path / "pieces.csv"
+    subprocess.run(base + ["-f", str(srt), "-o", str(whole), "--stream-chunk-mb", "0"], check=True, capture_output=True)
+    env = dict(os.environ, PGH_STREAM_CHUNK_BYTES="40000")           # ~12 pieces
+    r = subprocess.run(base + ["-f", str(srt), "-o", str(piece)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    la, va = _read_kinship_csv(whole)
+    lb, vb = _read_kinship_csv(piece)
+    assert la == lb and len(la) > 10000
+    assert np.allclose(va, vb, rtol=1e-9, atol=1e-12, equal_nan=True)
+    r = subprocess.run(base + ["-f", str(GOLD / "test.sync"), "-o", str(tmp_path / "x.csv")], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "sorted by chromosome and position" in r.stderr
