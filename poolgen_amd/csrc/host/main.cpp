@@ -176,6 +176,8 @@ struct Lap {
 // The input must be sorted by (chromosome, position) -- what the whole-file path obtains by sorting
 // (sync.rs:1092-1101) cannot be had across pieces -- and that is checked.
 // ---------------------------------------------------------------------------------------------------------
+struct UnsortedInput : std::runtime_error { using std::runtime_error::runtime_error; };
+
 static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap, size_t chunk_bytes, bool is_pileup,
                                 const PileupFilter &pf, const pg_filter &flt) {
     auto hip_ok = [](hipError_t e, const char *what) {
@@ -238,8 +240,8 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
             if (have_last) {
                 const int cmp = last_chrom.compare(ch);
                 if (cmp > 0 || (cmp == 0 && last_pos > sb.pos[l]))
-                    throw std::runtime_error("streamed ols_iter_with_kinship needs the input sorted by chromosome and position (line of " +
-                                             ch + ":" + std::to_string(sb.pos[l]) + "); use --stream-chunk-mb 0 to load the whole file");
+                    throw UnsortedInput("streamed ols_iter_with_kinship needs the input sorted by chromosome and position (line of " +
+                                        ch + ":" + std::to_string(sb.pos[l]) + "); use --stream-chunk-mb 0 to load the whole file");
                 if (cmp != 0) last_chrom = ch;
             } else { last_chrom = ch; have_last = true; }
             last_pos = sb.pos[l];
@@ -385,14 +387,24 @@ static int run(int argc, char **argv) {
     flt.min_allele_frequency = a.min_allele_frequency;
     flt.max_missingness_rate = a.max_missingness_rate;
     if (a.analysis == "ols_iter_with_kinship") {
-        // large inputs are taken in pieces (default: 2 GiB of text each once the file exceeds 8 GiB)
+        // inputs above 1 GiB are taken in pieces of 256 MiB of text (parse of piece c + 1 overlaps the GPU work on
+        // piece c, and the pinned buffers stay small); an unsorted input falls back to the whole-file path unless
+        // the pieces were asked for explicitly
         struct stat st;
         const size_t fsize = ::stat(a.fname.c_str(), &st) == 0 ? (size_t)st.st_size : 0;
+        const bool automatic = a.stream_chunk_mb < 0 && !std::getenv("PGH_STREAM_CHUNK_BYTES");
         long mb = a.stream_chunk_mb;
-        if (mb < 0) mb = fsize > ((size_t)8 << 30) ? 2048 : 0;
+        if (mb < 0) mb = fsize > ((size_t)1 << 30) ? 256 : 0;
         size_t piece = (size_t)(mb > 0 ? mb : 0) << 20;
         if (const char *e = std::getenv("PGH_STREAM_CHUNK_BYTES")) piece = (size_t)std::strtoull(e, nullptr, 10); // tests: small pieces
-        if (piece > 0 && fsize > piece) return run_kinship_streamed(a, ph, gpu, lap, piece, is_pileup, pf, flt);
+        if (piece > 0 && fsize > piece) {
+            try {
+                return run_kinship_streamed(a, ph, gpu, lap, piece, is_pileup, pf, flt);
+            } catch (const UnsortedInput &e) {
+                if (!automatic) throw;
+                std::cerr << "note: input is not sorted by (chromosome, position); loading the whole file instead\n";
+            }
+        }
     }
     SyncBatch sb;
     if (is_pileup) {
