@@ -203,6 +203,10 @@ int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
 /* Symmetric eigen-decomposition standing in for `kinship.eig()` (gwas/ols.rs:296): eigenvalues
  * DESCENDING, eigenvectors in the columns of V (n x n row-major; V may be NULL). */
 int pg_host_sym_eig(const double *A, int n, double *evals, double *V);
+/* All eigenvalues (descending) and the m leading eigenvectors only (V: n x m row-major) -- what pg_kinship_set
+ * needs for the covariates of gwas/ols.rs:312-315: values-only QL + inverse iteration + back-transformation,
+ * verified against A, full decomposition as the fallback. */
+int pg_host_sym_eig_top(const double *A, int n, int m, double *evals, double *V);
 /* n_eigenvecs from the cumulative-variance rule, literal (gwas/ols.rs:297-311). */
 int pg_host_n_eigenvecs(const double *evals, int n, double var_explained);
 /* Moore-Penrose pseudo-inverse of a symmetric matrix with the reference tolerance

@@ -83,6 +83,7 @@ void pg_prof_end(pg_ctx *ctx);
 // host math (pg_hostmath.cpp)
 // symmetric eigen-decomposition: eigenvalues descending, eigenvectors in columns of V (row-major)
 int pg_sym_eig(const double *A, int n, double *evals, double *V, bool want_vectors);
+int pg_sym_eig_top(const double *A, int n, int m, double *evals, double *V); // all values, the m leading vectors (n x m)
 // thin Householder QR of Z (n x c row-major) -> Q (n x c row-major), returns numerical rank
 int pg_thin_qr(const double *Z, int n, int c, double *Q);
 // t-distribution finite-series coefficients (Abramowitz & Stegun 26.7.3/26.7.4)

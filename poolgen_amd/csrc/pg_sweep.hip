@@ -409,10 +409,16 @@ extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total,
         }
     }
     scale_K();
-    const bool need_vec_first = force_m > 0;
-    if (need_vec_first) V.resize((size_t)n * n);
-    if (pg_sym_eig(K.data(), n, ev.data(), need_vec_first ? V.data() : nullptr, need_vec_first) != 0)
-        return pg_fail(ctx, PG_ERR_INVALID, "kinship_set: eigen-decomposition did not converge");
+    // eigenvalues always; eigenvectors only the m leading ones (pg_sym_eig_top)
+    if (force_m > 0) {
+        PG_CHECK(ctx, force_m <= n, "kinship_set: force_m=%d exceeds n=%d", force_m, n);
+        V.resize((size_t)n * force_m);
+        if (pg_sym_eig_top(K.data(), n, force_m, ev.data(), V.data()) != 0)
+            return pg_fail(ctx, PG_ERR_INVALID, "kinship_set: eigen-decomposition did not converge");
+    } else {
+        if (pg_sym_eig(K.data(), n, ev.data(), nullptr, false) != 0)
+            return pg_fail(ctx, PG_ERR_INVALID, "kinship_set: eigen-decomposition did not converge");
+    }
     if (force_m < 0) {
         // n_eigenvecs rule, literal (gwas/ols.rs:297-311), eigenvalues descending
         double sum = 0.0;
@@ -424,9 +430,9 @@ extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total,
             cum[i] = cum[i - 1] + cum[i];
             if ((cum[i - 1] >= var_explained) & (i - 1 < m)) m = i - 1;
         }
-        if (m > 0) {
-            V.resize((size_t)n * n);
-            if (pg_sym_eig(K.data(), n, ev.data(), V.data(), true) != 0)
+        if (m > 0 && m + 2 < n) {
+            V.resize((size_t)n * m);
+            if (pg_sym_eig_top(K.data(), n, m, ev.data(), V.data()) != 0)
                 return pg_fail(ctx, PG_ERR_INVALID, "kinship_set: eigen-decomposition did not converge");
         }
     }
@@ -441,7 +447,7 @@ extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total,
                        "--xxt-eigen-variance-explained", m, n);
     std::vector<double> C((size_t)n * (m > 0 ? m : 1));
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < m; ++j) C[(size_t)i * m + j] = V[(size_t)i * n + j]; // ols.rs:312-315
+        for (int j = 0; j < m; ++j) C[(size_t)i * m + j] = V[(size_t)i * m + j]; // ols.rs:312-315
     return pg_covariates_set(ctx, n, C.data(), m, Y, k);
 }
 

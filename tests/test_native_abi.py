@@ -92,3 +92,25 @@ def test_host_pinv_matches_numpy(native):
     out = np.empty_like(A)
     assert native.pg_host_pinv_sym(A.ctypes.data, 6, out.ctypes.data) == 0
     assert np.allclose(out, np.linalg.pinv(A), atol=1e-9)
+
+
+def test_host_top_eigenvectors_match_lapack(native):
+    """pg_host_sym_eig_top: all eigenvalues, the m leading vectors by inverse iteration (incl. clustered and repeated
+    eigenvalues, where it must either orthogonalise or fall back to the full solve)."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    cases = []
+    G = rng.random((120, 3000)); cases.append((G @ G.T / 3000, 6))                       # kinship-like: one dominant value
+    Q, _ = np.linalg.qr(rng.normal(size=(60, 60)))
+    lam = np.array([5.0, 5.0, 5.0 - 1e-9, 3.0, 3.0 + 1e-13] + list(np.linspace(2, 0.1, 55)))
+    cases.append(((Q * lam) @ Q.T, 5))                                                   # repeated / nearly repeated values
+    cases.append((np.diag(np.arange(1.0, 41.0)), 4))                                     # already diagonal
+    for A, m in cases:
+        A = np.ascontiguousarray((A + A.T) / 2)
+        n = A.shape[0]
+        ev = np.empty(n); V = np.empty((n, m))
+        assert native.pg_host_sym_eig_top(A.ctypes.data, n, m, ev.ctypes.data, V.ctypes.data) == 0
+        w = np.linalg.eigvalsh(A)[::-1]
+        assert np.allclose(ev, w, rtol=0, atol=1e-12 * abs(w[0]))
+        assert np.allclose(V.T @ V, np.eye(m), atol=1e-9)
+        assert np.max(np.abs(A @ V - V * ev[:m])) <= 1e-10 * abs(w[0])
