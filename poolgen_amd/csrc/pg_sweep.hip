@@ -360,9 +360,14 @@ extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total,
     PG_CHECK(ctx, S_dev && p_total > 0 && n >= 2, "kinship_set: bad arguments");
     PG_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<double> K((size_t)n * n), ev(n), V;
-    PG_HIP(ctx, hipMemcpyAsync(K.data(), S_dev, sizeof(double) * n * n, hipMemcpyDeviceToHost,
-                               ctx->stream));
-    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        // through the context's pinned buffer: a D2H into pageable memory is staged by the runtime
+        int prc = pg_pin_reserve(ctx, sizeof(double) * (size_t)n * n);
+        if (prc) return prc;
+        PG_HIP(ctx, hipMemcpyAsync(ctx->pin, S_dev, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(K.data(), ctx->pin, sizeof(double) * (size_t)n * n);
+    }
     const double pd = (double)p_total;
     auto scale_K = [&]() { for (auto &x : K) x = x / pd; }; // kinship = G G^T / p  (gwas/ols.rs:295)
     int m = force_m;
