@@ -297,7 +297,16 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
                 constexpr int ao = 4 * s * 208 + 16 * kin_tri_ti(t, 13);
                 constexpr int bo = 4 * s * 208 + 16 * kin_tri_tj(t, 13);
                 fa[q % R] = bufbase[ao];
+#ifdef KIN_EXP_HALF
+                fb[q % R] = fa[q % R]; // experiment: half the LDS reads (wrong numbers, timing only)
+                (void)bo;
+#elif defined(KIN_EXP_QUARTER)
+                if constexpr (q % 2 == 0) fa[q % R] = bufbase[ao]; else fa[q % R] = fa[(q + R - 1) % R];
+                fb[q % R] = fa[q % R];
+                (void)bo;
+#else
                 fb[q % R] = bufbase[bo];
+#endif
             } else {
                 const double *row = bufbase + 4 * s * ldsld;
                 fa[q % R] = row[acol[u]];
