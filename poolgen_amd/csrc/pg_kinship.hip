@@ -63,6 +63,47 @@ constexpr int kin_tri_tj(int t, int T) { int ti = 0; while (ti < T && t >= T - t
 // tile of slot u of wave w (slots past the end of the list recompute tile 0 and are never stored)
 constexpr int kin_slot_tile(int w, int u, int T) { return (w + KIN_WAVES_DEF * u) < T * (T + 1) / 2 ? (w + KIN_WAVES_DEF * u) : 0; }
 
+// ---- 13-tile shape: which tiles a wave owns, chosen so that they SHARE fragments ------------------------------
+// A fragment "4 loci x 16 pools of tile column c" serves as the A operand of every tile in tile row c and as the B
+// operand of every tile in tile column c.  Waves 0..3 own the 3 x 3 triangles on the diagonal (6 tiles from 3
+// fragments), waves 4..9 the 2 x 3 blocks (6 tiles from 5 fragments), the rest what is left, grouped for shared
+// columns: 69 fragment reads per k-step for the 91 tiles instead of 182, and 23/23/23/22 tiles on the four SIMDs.
+constexpr int KIN13_T[16][6][2] = {
+    {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}},
+    {{3, 3}, {3, 4}, {3, 5}, {4, 4}, {4, 5}, {5, 5}},
+    {{6, 6}, {6, 7}, {6, 8}, {7, 7}, {7, 8}, {8, 8}},
+    {{9, 9}, {9, 10}, {9, 11}, {10, 10}, {10, 11}, {11, 11}},
+    {{0, 3}, {0, 4}, {0, 5}, {1, 3}, {1, 4}, {1, 5}},
+    {{0, 6}, {0, 7}, {0, 8}, {1, 6}, {1, 7}, {1, 8}},
+    {{0, 9}, {0, 10}, {0, 11}, {1, 9}, {1, 10}, {1, 11}},
+    {{3, 6}, {3, 7}, {3, 8}, {4, 6}, {4, 7}, {4, 8}},
+    {{3, 9}, {3, 10}, {3, 11}, {4, 9}, {4, 10}, {4, 11}},
+    {{6, 9}, {6, 10}, {6, 11}, {7, 9}, {7, 10}, {7, 11}},
+    {{2, 4}, {2, 11}, {2, 12}, {4, 12}, {11, 12}, {12, 12}},
+    {{2, 5}, {2, 6}, {2, 7}, {5, 6}, {5, 7}, {-1, -1}},
+    {{1, 12}, {5, 8}, {5, 11}, {8, 11}, {8, 12}, {-1, -1}},
+    {{0, 12}, {2, 3}, {3, 12}, {6, 12}, {7, 12}, {-1, -1}},
+    {{2, 8}, {2, 9}, {2, 10}, {8, 9}, {8, 10}, {-1, -1}},
+    {{5, 9}, {5, 10}, {5, 12}, {9, 12}, {10, 12}, {-1, -1}},
+};
+constexpr int kin13_ntiles(int w) { int c = 0; for (int u = 0; u < 6; ++u) c += KIN13_T[w][u][0] >= 0; return c; }
+// distinct tile columns of wave w, in order of first use; kin13_col(w, i) = -1 past the end
+constexpr int kin13_col(int w, int idx) {
+    int seen[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, ns = 0;
+    for (int u = 0; u < 6; ++u)
+        for (int h = 0; h < 2; ++h) {
+            const int c = KIN13_T[w][u][h];
+            if (c < 0) continue;
+            bool dup = false;
+            for (int i = 0; i < ns; ++i) dup = dup || seen[i] == c;
+            if (!dup) seen[ns++] = c;
+        }
+    return idx < ns ? seen[idx] : -1;
+}
+constexpr int kin13_ncols(int w) { int c = 0; while (c < 12 && kin13_col(w, c) >= 0) ++c; return c; }
+constexpr int kin13_slot(int w, int col) { int i = 0; while (kin13_col(w, i) != col) ++i; return i; } // fragment register of a column
+constexpr int KIN13_MAXC = 6;
+
 struct KinParams {
     const double *G;
     int64_t p;
@@ -286,6 +327,63 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         double4_t acc[TPW];
 #pragma unroll
         for (int u = 0; u < TPW; ++u) acc[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#ifndef KIN_SHARED_FRAGS
+#define KIN_SHARED_FRAGS 1
+#endif
+        if constexpr (W >= 0 && KIN_SHARED_FRAGS) {
+            // ---- 13-tile shape with shared fragments: per k-step the wave reads its <= 6 distinct fragments once
+            // (two register sets: the set of step s + 1 is requested before the MFMAs of step s are issued) and
+            // feeds its <= 6 tiles from them.  The stage barrier sits in front of the LAST k-step's MFMAs: their
+            // operands are already in registers, and the first reads of the next stage hide behind them.
+            constexpr int NC = kin13_ncols(W), NT = kin13_ntiles(W);
+            static_assert(NC <= KIN13_MAXC && KS % 2 == 0, "fragment sets alternate with the k-step parity");
+            double fr[2][KIN13_MAXC];
+            const double *lb = lds + kq * ldsld + fi;
+            auto load_set = [&](const double *bufbase, auto sc, auto pc) __attribute__((always_inline)) {
+                constexpr int s2 = decltype(sc)::value, par = decltype(pc)::value;
+                static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int ci = decltype(cc)::value;
+                    fr[par][ci] = bufbase[4 * s2 * 208 + 16 * kin13_col(W, ci)];
+                });
+            };
+            auto mfma_set = [&](auto pc) __attribute__((always_inline)) {
+                constexpr int par = decltype(pc)::value;
+                static_for<NT>([&](auto uc) __attribute__((always_inline)) {
+                    constexpr int u = decltype(uc)::value;
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[par][kin13_slot(W, KIN13_T[W][u][0])],
+                                                                   fr[par][kin13_slot(W, KIN13_T[W][u][1])], acc[u], 0, 0, 0);
+                });
+            };
+            if (nstages > 0) load_set(lb, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            constexpr int spec_step = (W / 4) % KS; // FUSE: the four waves of a SIMD do their per-locus sums in different k-steps
+            for (int c = 0; c < nstages; ++c) {
+                const bool more = (c + 1) < nstages;
+                if (more) stage_load(c + 1);
+                const double *buf = lds + (c & 1) * bufsz;
+                const double *b0 = lb + (c & 1) * bufsz;
+                const double *b1 = lb + ((c + 1) & 1) * bufsz;
+                static_for<KS>([&](auto sc) __attribute__((always_inline)) {
+                    constexpr int s2 = decltype(sc)::value;
+                    if constexpr (FUSE && s2 == spec_step) spec_pass(buf, l_begin + (int64_t)c * KIN_KC);
+                    if constexpr (s2 + 1 < KS) {
+                        load_set(b0, std::integral_constant<int, s2 + 1>{}, std::integral_constant<int, (s2 + 1) & 1>{});
+                    } else {
+                        if (more) stage_store((c + 1) & 1);
+                        __syncthreads();
+                        if (more) load_set(b1, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                    }
+                    mfma_set(std::integral_constant<int, s2 & 1>{});
+                });
+            }
+            double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
+            static_for<NT>([&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int r0 = 16 * KIN13_T[W][u][0], c0 = 16 * KIN13_T[W][u][1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(size_t)(r0 + kq + 4 * r) * P.npad + c0 + fi] = acc[u][r];
+            });
+            return;
+        }
         double fa[R], fb[R];
         const double *lanebase = lds + kq * ldsld + fi; // + buffer + 4 s ldsld + tile column
         auto frag_load = [&](const double *bufbase, auto qc) {
