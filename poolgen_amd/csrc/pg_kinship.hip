@@ -273,24 +273,31 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
             const int loc = wave + KIN_WAVES * jl;
             const double *row = buf + loc * ldsld;
             const double shift = row[0]; // same address in every lane: an LDS broadcast
-            double s1 = 0.0, s2 = 0.0, sy[KIN_FUSE_MAXK];
+            double s1 = 0.0, s2 = 0.0, sy[KIN_FUSE_MAXK], d[4];
 #pragma unroll
             for (int t = 0; t < KIN_FUSE_MAXK; ++t) sy[t] = 0.0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int pool = lane + 64 * j;
-                const double gv = row[pool < ldsld ? pool : ldsld - 1];
-                const double d = (pool < P.n) ? gv - shift : 0.0;
-                s1 += d;
-                s2 = fma(d, d, s2);
+                // 13-tile shape: 193..208 pools, pitch 208 -- the first three 64-pool groups are always whole
+                if (SPEC13 && j < 3) d[j] = row[pool] - shift;
+                else {
+                    const double gv = row[pool < ldsld ? pool : ldsld - 1];
+                    d[j] = (pool < P.n) ? gv - shift : 0.0;
+                }
+                s1 += d[j];
+                s2 = fma(d[j], d[j], s2);
+                sy[0] = fma(d[j], yreg[0][j], sy[0]);
+            }
+            const bool two = P.k > 1; // wave-uniform
+            if (two) {
 #pragma unroll
-                for (int t = 0; t < KIN_FUSE_MAXK; ++t)
-                    sy[t] = fma(d, yreg[t][j], sy[t]); // traits beyond P.k carry zeros
+                for (int j = 0; j < 4; ++j) sy[1] = fma(d[j], yreg[1][j], sy[1]);
             }
             scratch[lane] = s1;
             scratch[64 + lane] = s2;
-#pragma unroll
-            for (int t = 0; t < KIN_FUSE_MAXK; ++t) scratch[(2 + t) * 64 + lane] = sy[t];
+            scratch[2 * 64 + lane] = sy[0];
+            if (two) scratch[3 * 64 + lane] = sy[1];
             __builtin_amdgcn_wave_barrier();
             const int v = lane >> 4, r = lane & 15;
             const double *sc = scratch + v * 64 + r;
