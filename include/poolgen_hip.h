@@ -187,7 +187,8 @@ int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld
 /* gp::penalise_ridge_like (gp/penalise.rs:133-159) = the lambda path with k-fold cross-validation
  * (:461-669) at alpha = 0, generalised to 0 <= alpha <= 1 (alpha = 1 is penalise_lasso_like, :101-130).
  * The reference draws its folds from an unseeded RNG (:452-453); here they are explicit:
- * fold_of[rep * n_rows + i] in 0..n_folds-1 is the fold of pool row_idx[i] in repetition rep.
+ * fold_of[rep * n_rows + i] in 0..n_folds-1 is the fold of pool row_idx[i] in repetition rep; the value
+ * n_folds marks the left-over group k_split makes (:444-448), which trains in every fold and is never validated.
  * lambda path = {0, step, 2 step, ..., 1} (step 0.1 in the reference).  Outputs: beta_dev (1+p) x k
  * (penalised coefficients of the all-rows fit, row 0 = intercept), lambdas_out[k] (host), optional
  * perf_out (host, n_reps x n_folds x L x k error indices, :359-426). */
@@ -195,6 +196,10 @@ int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
                     int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
                     int n_folds, double alpha, double lambda_step, double *beta_dev,
                     double *lambdas_out, double *perf_out);
+/* yhat (n x k, host) = X beta for EVERY pool, X = [1 | G^T], beta (1+p) x k on the device: the prediction step of
+ * the cross-validation harness (multiply_views_xx in gp/cv.rs:160-168); the caller reads the validation rows. */
+int pg_gp_predict_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *beta_dev,
+                      int k, double *yhat);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side pieces of the path (O(n^3), n = pools): exported so that they can be validated

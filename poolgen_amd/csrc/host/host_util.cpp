@@ -361,4 +361,25 @@ SyncBatch parse_sync_buffer(const char *bb, const char *be, int n_threads, int e
     return sb;
 }
 
+std::vector<int32_t> k_split(int64_t n, int k, const std::vector<int64_t> &order, int &k_out) {
+    if ((k >= n) | (n <= 2))
+        throw std::runtime_error("The number of splits, i.e. k, needs to be less than the number of pools, n, and n > 2. We are aiming for fold sizes of 10 or greater.");
+    int64_t s = n / k;
+    while (s < 10) {
+        if (n < 20) { k = 2; s = n / k; break; }
+        k -= 1;
+        s = n / k;
+    }
+    std::vector<int32_t> g;
+    for (int x = 0; x < k; ++x) g.insert(g.end(), (size_t)s, x);
+    for (int64_t i = 0; i < n - s; ++i) g.push_back(k); // as written: more entries than ever used
+    std::vector<int32_t> out(n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (order[i] < 0 || (size_t)order[i] >= g.size()) throw std::runtime_error("k_split: index out of bounds"); // a panic there
+        out[i] = g[order[i]];
+    }
+    k_out = k;
+    return out;
+}
+
 } // namespace pgh

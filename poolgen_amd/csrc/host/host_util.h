@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace pgh {
@@ -75,5 +76,29 @@ SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc all
 SyncBatch parse_sync_buffer(const char *b, const char *e, int n_threads, int expect_n, SyncAlloc alloc = SyncAlloc());
 
 extern const char ALLELES[7];
+
+// The reference draws its folds from rand::thread_rng (cv.rs:39-43, penalise.rs:452-453), i.e. unrepeatably; here a
+// seeded generator takes that place so that a run can be reproduced and tested.
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    std::vector<int64_t> permutation(int64_t n) { // Fisher-Yates
+        std::vector<int64_t> v(n);
+        for (int64_t i = 0; i < n; ++i) v[i] = i;
+        for (int64_t i = n - 1; i > 0; --i) { const int64_t j = (int64_t)(next() % (uint64_t)(i + 1)); std::swap(v[i], v[j]); }
+        return v;
+    }
+};
+
+// k_split (cv.rs:15-49 / penalise.rs:428-459): group sizes s = floor(n / k) with k lowered until s >= 10 (k = 2 when
+// n < 20); groups 0..k-1 of s members and what is left in group k, which no fold ever validates; `order[i]` picks the
+// group of position i out of that list.  Returns the group of every position, and k.
+std::vector<int32_t> k_split(int64_t n, int k_requested, const std::vector<int64_t> &order, int &k_out);
 
 } // namespace pgh

@@ -77,6 +77,14 @@ int main(int argc, char **argv) {
             const auto t0 = std::chrono::steady_clock::now();
             const int64_t kept = pileup_to_sync_file(argv[2], splitc(argv[5]), f, argv[3], std::atoi(argv[4]));
             std::cout << kept << " loci in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s\n";
+        } else if (mode == "ksplit") { // hostcheck ksplit <n> <k> <seed>: the seeded outer folds of the CV harness
+            const int64_t n = std::atoll(argv[2]);
+            SplitMix64 rng(std::strtoull(argv[4], nullptr, 10));
+            int k = 0;
+            const std::vector<int32_t> g = k_split(n, std::atoi(argv[3]), rng.permutation(n), k);
+            std::printf("%d", k);
+            for (int32_t x : g) std::printf(" %d", x);
+            std::printf("\n");
         } else if (mode == "parsetime") { // throughput of parse_sync_file: hostcheck parsetime <sync> <threads>
             const auto t0 = std::chrono::steady_clock::now();
             const SyncBatch sb = parse_sync_file(argv[2], std::atoi(argv[3]));

@@ -17,6 +17,7 @@
 #include <future>
 #include <iostream>
 #include <map>
+#include "gp_cv.h"
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
@@ -36,6 +37,8 @@ struct Args {
     int phen_name_col = 0, phen_pool_size_col = 1, n_threads = 1;
     long stream_chunk_mb = -1; // ols_iter_with_kinship: pieces of this size are parsed / copied / loaded in turn (-1 = automatic)
     std::vector<int> phen_value_col{2};
+    int k_folds = 10, n_reps = 3; // genomic_prediction_cross_validation (main.rs:104-109)
+    uint64_t seed = 42;           // ... and the seed of its folds (an extension: the reference's folds are unrepeatable)
 };
 
 static double parse_valid_freq(const std::string &v, const std::string &flag) { // helpers.rs:93-100
@@ -83,6 +86,9 @@ static Args parse_args(int argc, char **argv) {
         else if (k == "--output-sig-snps-only") a.sig_only = true;
         else if (k == "--keep-lowercase-reference") { /* pileup only */ }
         else if (k == "--stream-chunk-mb") a.stream_chunk_mb = std::stol(val());
+        else if (k == "--k-folds") a.k_folds = std::stoi(val());
+        else if (k == "--n-reps") a.n_reps = std::stoi(val());
+        else if (k == "--seed") a.seed = std::stoull(val());
         else if (k.rfind("-", 0) == 0) throw std::runtime_error("unknown flag " + k);
         else pos.push_back(k);
     }
@@ -335,10 +341,12 @@ static int run(int argc, char **argv) {
     const Args a = parse_args(argc, argv);
     Lap lap;
     const std::map<std::string, int> known{{"chisq_test", 0}, {"pearson_corr", 1}, {"ols_iter", 2},
-                                           {"ols_iter_with_kinship", 3}, {"pileup2sync", 4}};
+                                           {"ols_iter_with_kinship", 3}, {"pileup2sync", 4},
+                                           {"genomic_prediction_cross_validation", 5}};
     if (!known.count(a.analysis))
         throw std::runtime_error("Invalid analysis utility for this build: `" + a.analysis +
-                                 "` (available: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship)");
+                                 "` (available: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship, "
+                                 "genomic_prediction_cross_validation)");
     if (a.generate_plots || a.sig_only)
         throw std::runtime_error("--generate-plots / --output-sig-snps-only call the reference's python scripts and are out of scope here");
     Phen ph = parse_phen(a.phen_fname, a.phen_delim, a.phen_name_col, a.phen_pool_size_col, a.phen_value_col);
@@ -547,6 +555,20 @@ static int run(int argc, char **argv) {
     }
     std::vector<double> Y;
     for (int i : keep) for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]);
+    if (mode == 5) { // genomic_prediction_cross_validation (main.rs:397-426)
+        CvLabels labels{lab_chr, lab_al, lab_pos};
+        CvArgs ca;
+        ca.k_folds = a.k_folds; ca.n_reps = a.n_reps; ca.seed = a.seed; ca.n_threads = a.n_threads;
+        ca.fname_input = a.fname; ca.fname_output = a.output;
+        std::vector<std::string> names;
+        for (int i : keep) names.push_back(ph.pool_names[i]);
+        (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
+        const std::string out = gp_cross_validate(gpu.c, G_dev, p, n2, ld, Y, k, names, labels, ca);
+        (void)hipFree(G_dev);
+        lap("cross-validation");
+        std::cout << out << "\n";
+        return 0;
+    }
     if (!a.output.empty()) { FILE *t = create_new(a.output); fclose(t); ::unlink(a.output.c_str()); } // ols.rs:285
     std::vector<double> beta((size_t)p * k), var((size_t)p * k), pval((size_t)p * k);
     int m = 0;

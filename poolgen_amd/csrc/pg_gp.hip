@@ -221,6 +221,39 @@ __global__ void k_gp_predict_reduce(const double *__restrict__ part, int nblocks
     out[idx] = s;
 }
 
+// yhat partials for a plain coefficient matrix: thread = pool, block = slab of loci, up to 8 traits
+__global__ __launch_bounds__(256) void k_gp_predict_beta(const double *__restrict__ G, const double *__restrict__ beta,
+                                                         int k, int64_t p, int n, int64_t ld, int64_t loci_per_block,
+                                                         double *__restrict__ part) {
+    const int pool = blockIdx.y * 256 + threadIdx.x;
+    const int64_t l0 = (int64_t)blockIdx.x * loci_per_block;
+    const int64_t l1 = min(p, l0 + loci_per_block);
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    const bool on = pool < n;
+    const double *gp = G + (on ? pool : 0);
+    for (int64_t l = l0; l < l1; ++l) {
+        const double g = gp[l * ld];
+        const double *bl = beta + (l + 1) * k; // row 0 of beta is the intercept
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < k) acc[j] = fma(g, bl[j], acc[j]);
+    }
+    if (on) {
+        double *o = part + ((size_t)blockIdx.x * n + pool) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = acc[j];
+    }
+}
+__global__ void k_gp_predict_beta_reduce(const double *__restrict__ part, int nblocks, int n, double *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // pool * 8 + j
+    if (idx >= n * 8) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * n * 8 + idx];
+    out[idx] = s;
+}
+
 // pearsons_correlation (gwas/correlation_test.rs:7-71) on two complete vectors, as error_index calls it
 double host_pearson_r(const std::vector<double> &x, const std::vector<double> &y) {
     const int n = (int)x.size();
@@ -328,7 +361,7 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
     std::vector<double> perf((size_t)n_reps * n_folds * L * k, NAN), b0(k), yh((size_t)n * GP_LMAX);
     std::vector<int64_t> itr, iva;
     for (int i = 0; i < n_reps * n_rows; ++i)
-        if (fold_of[i] < 0 || fold_of[i] >= n_folds) { ctx->err = "gp_ridge: fold id out of range"; return fail(PG_ERR_INVALID); }
+        if (fold_of[i] < 0 || fold_of[i] > n_folds /* == n_folds: the left-over group of k_split (:444-448), never validated */) { ctx->err = "gp_ridge: fold id out of range"; return fail(PG_ERR_INVALID); }
     // error_index (:359-426) of trait j on the validation pools `iva`, for every lambda, from yhat (n x GP_LMAX)
     auto score = [&](int rep, int fold, int j, double b0j, const std::vector<int64_t> &iva_) {
         const int nv = (int)iva_.size();
@@ -485,5 +518,32 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
     if (perf_out) std::memcpy(perf_out, perf.data(), sizeof(double) * perf.size());
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(raw);
+    return PG_OK;
+}
+
+// yhat = X beta for every pool (the multiply_views_xx of gp/cv.rs:160-168, all rows at once)
+extern "C" int pg_gp_predict_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *beta_dev,
+                                 int k, double *yhat) {
+    if (!ctx) return PG_ERR_INVALID;
+    PG_CHECK(ctx, G_dev && beta_dev && yhat && p > 0 && n >= 1 && k >= 1 && k <= 8, "gp_predict: bad arguments");
+    PG_CHECK(ctx, ld >= n, "gp_predict: ld must be >= n");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    const int nblk = std::max(1, std::min<int>(ctx->cus * 4, (int)((p + 255) / 256)));
+    const int64_t lpb = (p + nblk - 1) / nblk;
+    const int nblk2 = (int)((p + lpb - 1) / lpb);
+    const size_t need = sizeof(double) * ((size_t)nblk2 * n * 8 + (size_t)n * 8);
+    int rc = pg_ws_reserve(ctx, need);
+    if (rc) return rc;
+    double *part = static_cast<double *>(ctx->ws);
+    double *out = part + (size_t)nblk2 * n * 8;
+    hipLaunchKernelGGL(k_gp_predict_beta, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, beta_dev, k, p, n, ld, lpb, part);
+    hipLaunchKernelGGL(k_gp_predict_beta_reduce, dim3((n * 8 + 255) / 256), dim3(256), 0, ctx->stream, part, nblk2, n, out);
+    PG_HIP(ctx, hipGetLastError());
+    std::vector<double> h((size_t)n * 8), b0(k);
+    PG_HIP(ctx, hipMemcpyAsync(h.data(), out, sizeof(double) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(b0.data(), beta_dev, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) yhat[(size_t)i * k + j] = b0[j] + h[(size_t)i * 8 + j];
     return PG_OK;
 }

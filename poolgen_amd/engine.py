@@ -260,6 +260,15 @@ class Engine:
                                             beta.data_ptr()), "pg_gp_ols_dev")
         return beta
 
+    def gp_predict(self, G: torch.Tensor, beta: torch.Tensor, n: int | None = None) -> np.ndarray:
+        """yhat = [1 | G^T] beta for every pool (n x k on the host)."""
+        p, ld, n = self._g_dims(G, n)
+        k = beta.shape[1]
+        yhat = np.empty((n, k))
+        self._check(self._lib.pg_gp_predict_dev(self._ctx, self._dev(G, torch.float64), p, n, ld,
+                                                self._dev(beta, torch.float64), k, yhat.ctypes.data), "pg_gp_predict_dev")
+        return yhat
+
     def gp_ridge(self, G: torch.Tensor, Y, row_idx, fold_of, n_folds: int, alpha: float = 0.0,
                  lambda_step: float = 0.1, n: int | None = None):
         """penalise_ridge_like (gp/penalise.rs:133-159) with explicit folds: fold_of is (n_reps, len(row_idx)).

@@ -1,0 +1,182 @@
+"""genomic_prediction_cross_validation (gp/cv.rs:105-414, main.rs:397-426) through the `poolgen` CLI against the same
+analysis composed from the oracle's fits.  The reference's folds come from an unseeded RNG (cv.rs:39-43,
+penalise.rs:452-453); the CLI's --seed generator (SplitMix64 + Fisher-Yates) is restated here so that both sides see the
+same folds."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+CLI = ROOT / "poolgen_amd" / "csrc" / "poolgen"
+M64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & M64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+    def permutation(self, n):
+        v = list(range(n))
+        for i in range(n - 1, 0, -1):
+            j = self.next() % (i + 1)
+            v[i], v[j] = v[j], v[i]
+        return v
+
+
+def k_split(n, k, order):
+    """cv.rs:15-49 / penalise.rs:428-459 with the shuffle handed in"""
+    assert k < n and n > 2
+    s = n // k
+    while s < 10:
+        if n < 20:
+            k = 2; s = n // k
+            break
+        k -= 1
+        s = n // k
+    g = [x for x in range(k) for _ in range(s)] + [k] * (n - s)
+    return [g[order[i]] for i in range(n)], k
+
+
+def pearson_sensible(x, y):
+    """correlation_test.rs:7-71, "sensible_corr" """
+    n = len(x)
+    dx, dy = x - x.mean(), y - y.mean()
+    with np.errstate(all="ignore"):
+        r = (dx * dy).sum() / (np.sqrt((dx * dx).sum()) * np.sqrt((dy * dy).sum()))
+    if np.isnan(r):
+        return np.nan
+    if (1.0 - r * r) / (n - 2.0) <= 0.0:
+        return r
+    return round(r * 1e7) / 1e7
+
+
+def make_inputs(tmp_path, n=36, loci=260, seed=5):
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(0.1, 0.9, size=loci)
+    lines, eff = [], rng.normal(size=loci) * (rng.uniform(size=loci) < 0.1)
+    F = np.empty((loci, n))
+    for l in range(loci):
+        f = np.clip(q[l] + rng.normal(scale=0.15, size=n), 0.02, 0.98)
+        F[l] = f
+        a = rng.binomial(60, f)
+        cols = [f"{a[i]}:{60 - a[i]}:0:0:0:0" for i in range(n)]
+        lines.append("\t".join([f"chr{1 + l // 130}", str(100 + 7 * (l % 130)), "N"] + cols))
+    y0 = F.T @ eff + rng.normal(scale=0.3, size=n)
+    y1 = rng.normal(size=n)
+    (tmp_path / "x.sync").write_text("\n".join(lines) + "\n")
+    (tmp_path / "x.csv").write_text("#pool,size,y0,y1\n" + "".join(f"P{i},20,{float(y0[i])!r},{float(y1[i])!r}\n" for i in range(n)))
+    return lines, np.column_stack([y0, y1])
+
+
+def test_cli_cross_validation(oracle, tmp_path):
+    n, kf, reps, seed = 36, 3, 2, 11
+    lines, Y = make_inputs(tmp_path, n=n)
+    out = tmp_path / "cv.csv"
+    r = subprocess.run([str(CLI), "genomic_prediction_cross_validation", "-f", str(tmp_path / "x.sync"), "-p", str(tmp_path / "x.csv"),
+                        "--phen-value-col", "2,3", "--n-threads", "2", "--k-folds", str(kf), "--n-reps", str(reps), "--seed", str(seed),
+                        "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().endswith(str(out))
+    # ---- the same analysis from the oracle ----------------------------------------------------------------------
+    f = oracle.filt()
+    rows = [oracle.parse_sync_line(x)[1:] for x in lines]
+    lab, cols = [("intercept", 0, "intercept")], []
+    for chrom, pos, cnt in sorted(rows, key=lambda t: (t[0], t[1])):
+        res = oracle.filter_locus(cnt, [20.0] * n, f)
+        if res is None:
+            continue
+        ids, fc = res
+        fr = oracle.to_frequencies(fc)
+        for j, a in enumerate(ids):
+            lab.append((chrom, pos, "ATCGND"[a])); cols.append(fr[:, j])
+    Xt = np.vstack([np.ones(n), np.array(cols)])  # (1 + p) x n
+    P, m = Xt.shape[0], 2
+    rng = SplitMix64(seed)
+    models = [("ols", None), ("penalise_lasso_like", 1.0), ("penalise_ridge_like", 0.0)]
+
+    def fit(mi, rows_):
+        base, alpha = models[mi]
+        if alpha is None:
+            rc, b = oracle.gp_ols(Xt, Y, rows_)
+            assert rc == 0
+            return b, base
+        nr, folds, nf = len(rows_), [], 0
+        for _ in range(10):
+            perm = rng.permutation(nr)
+            g, nf = k_split(nr, 10, [rows_[i] for i in perm])
+            folds.append(g)
+        b, lam, _ = oracle.penalised_lambda_path(Xt, Y, rows_, np.array(folds), nf, alpha=alpha)
+        name = base + "-alphas_" + "_".join(oracle.fmt(alpha) for _ in range(m)) + "-lambdas_" + "_".join(oracle.fmt(x) for x in lam)
+        return b, name
+
+    perf = {}
+    yvp = np.full((reps, 3, n, 2 * m), np.nan)
+    names = [None] * 3
+    for rep in range(reps):
+        grp, kk = k_split(n, kf, rng.permutation(n))
+        for fold in range(kk):
+            val = [i for i in range(n) if grp[i] == fold]
+            tr = [i for i in range(n) if grp[i] != fold]
+            for mi in range(3):
+                b, name = fit(mi, tr)
+                if rep == 0 and fold == 0:
+                    names[mi] = name
+                yh = Xt.T @ b
+                yvp[rep, mi, val, :m] = yh[val]
+                yvp[rep, mi, val, m:] = Y[val]
+                for j in range(m):
+                    d = Y[val, j] - yh[val, j]
+                    perf[(rep, fold, mi, j)] = (pearson_sensible(Y[val, j], yh[val, j]), d.mean(), np.abs(d).sum(), (d * d).sum(),
+                                                np.sqrt((d * d).sum()))
+    # ---- performance table ---------------------------------------------------------------------------------------
+    got = out.read_text().splitlines()
+    assert got[0] == "#rep,fold,model,phenotype,pearsons_correlation,mean_bias_error,mean_absolute_error,mean_square_error,root_mean_square_error"
+    assert len(got) == 1 + reps * kf * 3 * m
+    it = iter(got[1:])
+    for rep in range(reps):
+        for fold in range(kf):
+            for mi in range(3):
+                for j in range(m):
+                    fa = next(it).split(",")
+                    assert fa[:4] == [str(rep), str(fold), names[mi], str(j)]
+                    want = perf.get((rep, fold, mi, j), (np.nan,) * 5)
+                    for a, b in zip(map(float, fa[4:]), want):
+                        assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-7 * max(1.0, abs(b)), (fa, want)
+    # ---- expected and predicted phenotypes -----------------------------------------------------------------------
+    got = (tmp_path / "cv-expected_and_predicted_phenotypes.csv").read_text().splitlines()
+    assert got[0] == "#rep,model,pool,predicted_trait_0,predicted_trait_1,expected_trait_0,expected_trait_1"
+    assert len(got) == 1 + reps * 3 * n
+    it = iter(got[1:])
+    for rep in range(reps):
+        for mi in range(3):
+            for pool in range(n):
+                fa = next(it).split(",")
+                assert fa[:3] == [str(rep), names[mi], f"P{pool}"]
+                for a, b in zip(map(float, fa[3:]), yvp[rep, mi, pool]):
+                    assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-7 * max(1.0, abs(b))
+                assert fa[5:] == [oracle.fmt(x) for x in yvp[rep, mi, pool, m:]]       # the expected traits print exactly
+    # ---- all-data predictors -------------------------------------------------------------------------------------
+    allrows = list(range(n))
+    for mi in range(3):
+        b, name = fit(mi, allrows)
+        got = (tmp_path / f"cv-genomic_predictors-{name}.csv").read_text().splitlines()
+        assert got[0] == "#chromosome,position,allele,phenotype,predictor" and len(got) == 1 + P * m
+        for i in range(P):
+            for j in range(m):
+                fa = got[1 + i * m + j].split(",")
+                assert (fa[0], int(fa[1]), fa[2], fa[3]) == (lab[i][0], lab[i][1], lab[i][2], str(j))
+                assert abs(float(fa[4]) - b[i, j]) <= 1e-7 * max(1.0, abs(b[i, j]))
+    # the outputs are created with create_new: a second run must refuse
+    r = subprocess.run([str(CLI), "genomic_prediction_cross_validation", "-f", str(tmp_path / "x.sync"), "-p", str(tmp_path / "x.csv"),
+                        "--phen-value-col", "2,3", "--k-folds", str(kf), "--n-reps", "1", "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unable to create file" in r.stderr

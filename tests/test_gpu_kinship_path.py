@@ -185,6 +185,35 @@ def test_gp_ols_matches_oracle(engine, oracle, n, p, k, rows):
     assert np.array_equal(beta, beta2)
 
 
+@pytest.mark.parametrize("n,p,k", [(100, 70001, 2), (37, 513, 1), (200, 20000, 4)])
+def test_gp_predict_is_x_times_beta(engine, n, p, k):
+    """The prediction step of the CV harness (multiply_views_xx, gp/cv.rs:160-168): yhat = [1 | G^T] beta."""
+    G, _ = make(p, n, 61)
+    rng = np.random.default_rng(3)
+    beta = rng.normal(size=(1 + p, k))
+    got = engine.gp_predict(G, torch.from_numpy(beta).cuda(), n=n)
+    want = beta[0] + G.cpu().numpy()[:, :n].T @ beta[1:]
+    assert np.allclose(got, want, rtol=1e-11, atol=1e-11 * np.abs(want).max())
+
+
+def test_gp_ridge_leftover_group_only_trains(engine, oracle):
+    """k_split's left-over group (penalise.rs:444-448, fold id == n_folds) is in every training set and in no
+    validation set."""
+    n, p = 48, 1500
+    G, Y = make(p, n, 49)
+    Y = Y[:, :1]
+    rng = np.random.default_rng(9)
+    rows = np.arange(n)
+    n_folds, n_reps = 4, 2
+    folds = np.stack([rng.permutation(np.concatenate([np.arange(40) % n_folds, np.full(8, n_folds)])) for _ in range(n_reps)])
+    beta, lam, perf = engine.gp_ridge(G, Y, rows, folds, n_folds, alpha=0.0, n=n)
+    Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])
+    rb, rl, rp = oracle.penalised_lambda_path(Xt, Y, rows, folds, n_folds, alpha=0.0, n=n)
+    assert np.array_equal(lam, rl)
+    assert np.allclose(perf, rp, rtol=1e-6, atol=1e-9)
+    assert np.allclose(beta.cpu().numpy(), rb, rtol=1e-6, atol=1e-8 * np.abs(rb).max())
+
+
 def test_gp_ols_with_duplicated_pools_uses_the_pseudo_inverse(engine, oracle):
     """Two identical pools make X X^T singular: the reference's pinv (helpers.rs:463-482) drops the null
     direction.  The product's fast path (Cholesky) must hand such a matrix to the eigen-based pseudo-inverse."""

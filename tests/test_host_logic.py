@@ -90,3 +90,14 @@ def test_sync_parser_edge_cases(tmp_path):
         assert rc != 0 and "hostcheck:" in err, bad
     rc, out, _ = _parse_text(tmp_path, "# only comments\n#\n")
     assert rc == 0 and out == ["0 0"]
+
+
+def test_seeded_k_split_matches_restatement():
+    """The CV harness's folds (gp/cv.rs:15-49 with a seeded shuffle): C++ against the restatement the GPU test uses."""
+    from test_gpu_cv import SplitMix64, k_split
+    for n, k, seed in ((36, 3, 11), (45, 10, 3), (200, 10, 42), (19, 5, 1), (25, 10, 7)):
+        out = run("ksplit", n, k, seed).split()
+        g, kk = k_split(n, k, SplitMix64(seed).permutation(n))
+        assert [int(x) for x in out] == [kk] + g
+    r = subprocess.run([str(HC), "ksplit", "10", "10", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "number of splits" in r.stderr
