@@ -196,6 +196,25 @@ int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
                     int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
                     int n_folds, double alpha, double lambda_step, double *beta_dev,
                     double *lambdas_out, double *perf_out);
+/* The whole family behind penalised_lambda_path_with_k_fold_cross_validation (gp/penalise.rs:461-669):
+ *   alpha in [0, 1], iterative_proxy = 0 : pg_gp_ridge_dev (penalise_lasso_like alpha = 1, penalise_ridge_like alpha = 0);
+ *   alpha < 0                            : penalise_glmnet (:168-195): the grid alpha x lambda over the same path values
+ *                                          (:479-498), alpha and lambda chosen by separate mode counts (:605-627);
+ *   iterative_proxy != 0                 : the *_with_iterative_proxy_norms models (:197-246): the penalised set is
+ *                                          picked by the norms of pg_gp_proxy_dev's coefficients (fitted once on
+ *                                          row_idx, :543, :656), the amounts by the fit's own norms (:262-283).
+ * alphas_out[k] (host, optional), lambdas_out[k]; perf_out (optional) n_reps x n_folds x A x L x k, A = 1 or L.
+ * With iterative_proxy the covariate state of ctx (pg_covariates_set / pg_kinship_set) is overwritten. */
+int pg_gp_penalised_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
+                        int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
+                        int n_folds, double alpha, int iterative_proxy, double lambda_step, double *beta_dev,
+                        double *alphas_out, double *lambdas_out, double *perf_out);
+/* gp::ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199): proxy_dev (1+p) x k on the device, row 0 = the
+ * trait means over the training pools, row 1+l = the locus coefficient of y ~ [1 | PC1 | g_l] on the training pools
+ * (PC1: leading eigenvector of the reference's centred X X^T of those pools, :115-141, with its two indexing quirks:
+ * columns = intercept and all loci but the last; means over the first n_rows pools).  Overwrites ctx's covariates. */
+int pg_gp_proxy_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y, int k,
+                    const int64_t *row_idx, int n_rows, const double *XXt_host_or_null, double *proxy_dev);
 /* yhat (n x k, host) = X beta for EVERY pool, X = [1 | G^T], beta (1+p) x k on the device: the prediction step of
  * the cross-validation harness (multiply_views_xx in gp/cv.rs:160-168); the caller reads the validation rows. */
 int pg_gp_predict_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *beta_dev,

@@ -1175,21 +1175,115 @@ void orc_error_index(const double *Xt, int64_t P, int n, int64_t ld, const doubl
     free(yt);
 }
 
-/* penalised_lambda_path_with_k_fold_cross_validation with alpha >= 0, iterative = false
- * (:461-669).  The reference draws the folds with an unseeded rand::thread_rng (:452-453); here the
- * fold of row_idx[i] in repetition rep is given: fold_of[rep * n_rows + i] in 0..nfolds-1.
- * perf (may be NULL): r x nfolds x L x k.  Returns L (number of lambdas), lambdas_out k, beta P x k. */
-int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
-                              const int64_t *row_idx, int n_rows, const int32_t *fold_of, int r,
-                              int nfolds, double alpha, double lambda_step, double *beta,
-                              double *lambdas_out, double *perf, int n_threads) {
+/* gp::ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199), as written: the "kinship" is X_c X_c^T over the
+ * training rows, X_c = columns 0..P-2 of x (the intercept is column 0; the LAST locus is left out, :115) centred by
+ * the column means over the FIRST n_rows rows of x (not over row_idx, :124-129); PC1 = eigenvector 0 (:177; LAPACK
+ * dgeev order read as "leading", as for gwas/ols.rs:296); b[0] = trait means (:170-172), b[j] = solution[2] of the
+ * least-squares fit y ~ [1 | PC1 | x_j] (:193, gelsd: minimum-norm when rank deficient).  b: P x k. */
+int orc_gp_proxy(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k, const int64_t *row_idx,
+                 int nr, double *b, int n_threads) {
+    (void)n;
+    int nt = n_threads > 0 ? n_threads : 1;
+    const int64_t pc = P - 1;
+    double *xc = (double *)malloc(sizeof(double) * (size_t)nr * (pc > 0 ? pc : 1));
+    for (int64_t j = 0; j < pc; j++) {
+        double mean = 0.0;
+        for (int i_ = 0; i_ < nr; i_++) mean += Xt[j * ld + i_];
+        mean = mean / (double)nr;
+        for (int a = 0; a < nr; a++) xc[(size_t)a * pc + j] = Xt[j * ld + row_idx[a]] - mean;
+    }
+    double *xxt = (double *)malloc(sizeof(double) * nr * nr);
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int a = 0; a < nr; a++)
+        for (int c = 0; c < nr; c++) {
+            double x = 0.0;
+            for (int64_t j = 0; j < pc; j++) x += xc[(size_t)a * pc + j] * xc[(size_t)c * pc + j];
+            xxt[a * nr + c] = x;
+        }
+    double *evals = (double *)malloc(sizeof(double) * nr);
+    double *V = (double *)malloc(sizeof(double) * nr * nr);
+    orc_sym_eig(xxt, nr, evals, V);
+    double *ev = (double *)malloc(sizeof(double) * nr);
+    for (int a = 0; a < nr; a++) ev[a] = V[a * nr + 0];
+    for (int j_ = 0; j_ < k; j_++) {
+        double m = 0.0;
+        for (int a = 0; a < nr; a++) m += Y[row_idx[a] * k + j_];
+        b[j_] = m / (double)nr;
+    }
+    /* orthonormal basis of [1 | PC1] */
+    double *q1 = (double *)malloc(sizeof(double) * nr * 2);
+    double *q2 = q1 + nr;
+    {
+        double s = 1.0 / sqrt((double)nr), d = 0.0, nn = 0.0;
+        for (int a = 0; a < nr; a++) q1[a] = s;
+        for (int a = 0; a < nr; a++) d += q1[a] * ev[a];
+        for (int a = 0; a < nr; a++) { q2[a] = ev[a] - d * q1[a]; nn += q2[a] * q2[a]; }
+        nn = sqrt(nn);
+        for (int a = 0; a < nr; a++) q2[a] = nn > 0.0 ? q2[a] / nn : 0.0;
+    }
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int64_t j = 1; j < P; j++) {
+        double *r = (double *)malloc(sizeof(double) * nr);
+        double xx = 0.0, rr = 0.0;
+        for (int a = 0; a < nr; a++) { r[a] = Xt[j * ld + row_idx[a]]; xx += r[a] * r[a]; }
+        for (int pass = 0; pass < 2; pass++) {
+            double d1 = 0.0, d2 = 0.0;
+            for (int a = 0; a < nr; a++) { d1 += q1[a] * r[a]; }
+            for (int a = 0; a < nr; a++) r[a] -= d1 * q1[a];
+            for (int a = 0; a < nr; a++) { d2 += q2[a] * r[a]; }
+            for (int a = 0; a < nr; a++) r[a] -= d2 * q2[a];
+        }
+        for (int a = 0; a < nr; a++) rr += r[a] * r[a];
+        if (rr > 1e-28 * xx) { /* full rank: the locus coefficient is <r, y> / <r, r> */
+            for (int j_ = 0; j_ < k; j_++) {
+                double ry = 0.0;
+                for (int a = 0; a < nr; a++) ry += r[a] * Y[row_idx[a] * k + j_];
+                b[j * k + j_] = ry / rr;
+            }
+        } else { /* rank deficient: minimum-norm least squares = pinv(X^T X) X^T y */
+            double xtx[9], pinv[9], xs[3];
+            for (int u = 0; u < 9; u++) xtx[u] = 0.0;
+            for (int a = 0; a < nr; a++) {
+                xs[0] = 1.0; xs[1] = ev[a]; xs[2] = Xt[j * ld + row_idx[a]];
+                for (int u = 0; u < 3; u++)
+                    for (int v = 0; v < 3; v++) xtx[u * 3 + v] += xs[u] * xs[v];
+            }
+            orc_pinv_sym(xtx, 3, pinv);
+            for (int j_ = 0; j_ < k; j_++) {
+                double xty[3] = {0.0, 0.0, 0.0};
+                for (int a = 0; a < nr; a++) {
+                    double y = Y[row_idx[a] * k + j_];
+                    xty[0] += y; xty[1] += ev[a] * y; xty[2] += Xt[j * ld + row_idx[a]] * y;
+                }
+                b[j * k + j_] = pinv[6] * xty[0] + pinv[7] * xty[1] + pinv[8] * xty[2];
+            }
+        }
+        free(r);
+    }
+    free(xc); free(xxt); free(evals); free(V); free(ev); free(q1);
+    return 0;
+}
+
+/* penalised_lambda_path_with_k_fold_cross_validation (:461-669), every mode: alpha >= 0 one lambda path (a = 1),
+ * alpha < 0 the grid of path values for alpha too (a = l, :479-498); iterative: the proxy coefficients above, fitted
+ * on row_idx (:543, :656), pick the penalised set.  The reference draws the folds with an unseeded rand::thread_rng
+ * (:452-453); here the fold of row_idx[i] in repetition rep is given: fold_of[rep * n_rows + i] in 0..nfolds-1
+ * (nfolds itself: the left-over group, never validated).
+ * perf (may be NULL): r x nfolds x A x L x k.  Returns L; alphas_out (may be NULL) / lambdas_out k, beta P x k. */
+int orc_penalised_path_general(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
+                               const int64_t *row_idx, int n_rows, const int32_t *fold_of, int r, int nfolds,
+                               double alpha, int iterative, double lambda_step, double *beta, double *alphas_out,
+                               double *lambdas_out, double *perf, int n_threads) {
     const int max_usize = (int)round(1.0 / lambda_step);
     const int L = max_usize + 1;
+    const int A = alpha >= 0.0 ? 1 : L;
     double *path = (double *)malloc(sizeof(double) * L);
     for (int i = 0; i < L; i++) path[i] = (double)i / (double)max_usize;
-    double *perf_l = perf ? perf : (double *)malloc(sizeof(double) * r * nfolds * L * k);
-    double *b_hat = (double *)malloc(sizeof(double) * P * k * 2);
+    double *perf_l = perf ? perf : (double *)malloc(sizeof(double) * r * nfolds * A * L * k);
+    double *b_hat = (double *)malloc(sizeof(double) * P * k * 3);
     double *b_new = b_hat + P * k;
+    double *b_proxy = b_new + P * k;
+    if (iterative) orc_gp_proxy(Xt, P, n, ld, Y, k, row_idx, n_rows, b_proxy, n_threads);
     int64_t *itr = (int64_t *)malloc(sizeof(int64_t) * n_rows * 2);
     int64_t *iva = itr + n_rows;
     for (int rep = 0; rep < r; rep++)
@@ -1200,45 +1294,57 @@ int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, co
                 else itr[nt++] = row_idx[i];
             }
             orc_gp_ols(Xt, P, n, ld, Y, k, itr, nt, b_hat, n_threads); /* :526 */
-            for (int li = 0; li < L; li++) {
-                orc_expand_and_contract(b_hat, b_hat, P, k, alpha, path[li], b_new);
-                orc_error_index(Xt, P, n, ld, b_new, k, Y, iva, nv, &perf_l[((rep * nfolds + fold) * L + li) * k]);
-            }
+            for (int a = 0; a < A; a++)
+                for (int li = 0; li < L; li++) {
+                    orc_expand_and_contract(b_hat, iterative ? b_proxy : b_hat, P, k, alpha >= 0.0 ? alpha : path[a], path[li], b_new);
+                    orc_error_index(Xt, P, n, ld, b_new, k, Y, iva, nv, &perf_l[(((rep * nfolds + fold) * A + a) * L + li) * k]);
+                }
         }
     orc_gp_ols(Xt, P, n, ld, Y, k, row_idx, n_rows, b_hat, n_threads); /* :573 */
     memcpy(beta, b_hat, sizeof(double) * P * k);
-    int *counts = (int *)malloc(sizeof(int) * L);
+    int *acount = (int *)malloc(sizeof(int) * L * 2);
+    int *lcount = acount + L;
     for (int j = 0; j < k; j++) {
-        for (int a = 0; a < L; a++) counts[a] = 0;
-        for (int rep = 0; rep < r; rep++) { /* per repetition: arg-min of the mean error across folds */
+        for (int c = 0; c < L; c++) { acount[c] = 0; lcount[c] = 0; }
+        for (int rep = 0; rep < r; rep++) { /* per repetition: arg-min of the mean error across folds (:584-612) */
             double minv = 0.0;
             int arg = -1;
-            for (int li = 0; li < L; li++) {
-                double s = 0.0;
-                for (int fold = 0; fold < nfolds; fold++) s += perf_l[((rep * nfolds + fold) * L + li) * k + j];
-                double m = s / (double)nfolds;
-                if (li == 0) { minv = m; }
-                else if (m < minv) minv = m;
+            for (int pass = 0; pass < 2 && arg < 0; pass++)
+                for (int q = 0; q < A * L && arg < 0; q++) {
+                    double s = 0.0;
+                    for (int fold = 0; fold < nfolds; fold++) s += perf_l[(((rep * nfolds + fold) * A + q / L) * L + q % L) * k + j];
+                    double m = s / (double)nfolds;
+                    if (pass == 0) { if (q == 0 || m < minv) minv = m; }
+                    else if (m == minv) arg = q;
+                }
+            if (arg >= 0) {
+                double aval = alpha >= 0.0 ? alpha : path[arg / L], lval = path[arg % L];
+                for (int c = 0; c < L; c++) { acount[c] += (aval == path[c]); lcount[c] += (lval == path[c]); }
             }
-            for (int li = 0; li < L && arg < 0; li++) {
-                double s = 0.0;
-                for (int fold = 0; fold < nfolds; fold++) s += perf_l[((rep * nfolds + fold) * L + li) * k + j];
-                if (s / (double)nfolds == minv) arg = li;
-            }
-            if (arg >= 0) counts[arg] += 1;
         }
-        int best = 0, mx = 0; /* mode, first maximum (:609-627) */
-        for (int a = 0; a < L; a++)
-            if (counts[a] > mx) mx = counts[a];
-        for (int a = 0; a < L; a++)
-            if (counts[a] == mx) { best = a; break; }
-        lambdas_out[j] = path[best];
-        orc_expand_and_contract(b_hat, b_hat, P, k, alpha, path[best], b_new);
+        int abest = 0, lbest = 0, amx = 0, lmx = 0; /* mode, first maximum (:614-627) */
+        for (int c = 0; c < L; c++) { if (acount[c] > amx) amx = acount[c]; if (lcount[c] > lmx) lmx = lcount[c]; }
+        for (int c = 0; c < L; c++) if (acount[c] == amx) { abest = c; break; }
+        for (int c = 0; c < L; c++) if (lcount[c] == lmx) { lbest = c; break; }
+        /* an alpha >= 0 that is on the path grid is its own mode (0 and 1, the only values the reference passes) */
+        double afinal = alpha >= 0.0 ? alpha : path[abest];
+        if (alphas_out) alphas_out[j] = afinal;
+        lambdas_out[j] = path[lbest];
+        orc_expand_and_contract(b_hat, iterative ? b_proxy : b_hat, P, k, afinal, path[lbest], b_new);
         for (int64_t i = 0; i < P; i++) beta[i * k + j] = b_new[i * k + j];
     }
-    free(counts); free(itr); free(b_hat); free(path);
+    free(acount); free(itr); free(b_hat); free(path);
     if (!perf) free(perf_l);
     return L;
+}
+
+/* alpha >= 0, iterative = false (penalise_lasso_like / penalise_ridge_like); perf r x nfolds x L x k */
+int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
+                              const int64_t *row_idx, int n_rows, const int32_t *fold_of, int r,
+                              int nfolds, double alpha, double lambda_step, double *beta,
+                              double *lambdas_out, double *perf, int n_threads) {
+    return orc_penalised_path_general(Xt, P, n, ld, Y, k, row_idx, n_rows, fold_of, r, nfolds, alpha, 0, lambda_step, beta,
+                                      NULL, lambdas_out, perf, n_threads);
 }
 
 /* ============================================================================================

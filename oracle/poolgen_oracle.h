@@ -151,6 +151,12 @@ void orc_expand_and_contract(const double *b_hat, const double *b_proxy, int64_t
 /* error_index (gp/penalise.rs:359-426) and the ridge-like lambda path with explicit folds (:461-669) */
 void orc_error_index(const double *Xt, int64_t P, int n, int64_t ld, const double *b, int k,
                      const double *Y, const int64_t *idx_val, int n_val, double *err_out);
+int orc_gp_proxy(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k, const int64_t *row_idx,
+                 int nr, double *b, int n_threads);
+int orc_penalised_path_general(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
+                               const int64_t *row_idx, int n_rows, const int32_t *fold_of, int r, int nfolds,
+                               double alpha, int iterative, double lambda_step, double *beta, double *alphas_out,
+                               double *lambdas_out, double *perf, int n_threads);
 int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,
                               const int64_t *row_idx, int n_rows, const int32_t *fold_of, int r,
                               int nfolds, double alpha, double lambda_step, double *beta,

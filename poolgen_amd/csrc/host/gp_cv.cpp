@@ -46,15 +46,24 @@ double pearson_sensible(const std::vector<double> &x, const std::vector<double> 
 
 struct Model {
     const char *base;  // function_name!() of the reference
-    double alpha;      // < 0: plain ols
+    bool penalised;
+    double alpha;      // < 0: the alpha x lambda grid of penalise_glmnet
+    int proxy;         // the *_with_iterative_proxy_norms variants
 };
 
 } // namespace
 
 std::string gp_cross_validate(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const std::vector<double> &Y,
                               int m, const std::vector<std::string> &pool_names, const CvLabels &labels, const CvArgs &a) {
-    const Model models[] = {{"ols", -1.0}, {"penalise_lasso_like", 1.0}, {"penalise_ridge_like", 0.0}};
-    const int nmod = 3;
+    // main.rs:402-411, in that order; the "ridge-like" proxy model passes alpha = 1 as the lasso-like one does
+    // (penalise.rs:225-227)
+    const Model models[] = {{"ols", false, 0.0, 0},
+                            {"penalise_glmnet", true, -0.1, 0},
+                            {"penalise_lasso_like", true, 1.0, 0},
+                            {"penalise_ridge_like", true, 0.0, 0},
+                            {"penalise_lasso_like_with_iterative_proxy_norms", true, 1.0, 1},
+                            {"penalise_ridge_like_with_iterative_proxy_norms", true, 1.0, 1}};
+    const int nmod = 6;
     const int k = a.k_folds, r = a.n_reps;
     SplitMix64 rng(a.seed);
     double *beta_dev = nullptr;
@@ -69,7 +78,7 @@ std::string gp_cross_validate(pg_ctx *ctx, const double *G_dev, int64_t p, int n
     }
     // one fit of model `mi` on `rows` -> beta_dev, and the name the reference gives it
     auto fit = [&](int mi, const std::vector<int64_t> &rows, std::string &name) {
-        if (models[mi].alpha < 0.0) {
+        if (!models[mi].penalised) {
             ok(ctx, pg_gp_ols_dev(ctx, G_dev, p, n, ld, Y.data(), m, rows.data(), (int)rows.size(), xxt.data(), beta_dev), "ols");
             name = models[mi].base;
             return;
@@ -84,11 +93,11 @@ std::string gp_cross_validate(pg_ctx *ctx, const double *G_dev, int64_t p, int n
             const std::vector<int32_t> g = k_split(nr, 10, order, nf);
             for (int i = 0; i < nr; ++i) folds[(size_t)rep * nr + i] = g[i]; // group nf: the left-over, never validated
         }
-        std::vector<double> lam(m);
-        ok(ctx, pg_gp_ridge_dev(ctx, G_dev, p, n, ld, Y.data(), m, rows.data(), nr, folds.data(), inner_reps, nf, models[mi].alpha, 0.1,
-                                beta_dev, lam.data(), nullptr), models[mi].base);
+        std::vector<double> lam(m), al(m);
+        ok(ctx, pg_gp_penalised_dev(ctx, G_dev, p, n, ld, Y.data(), m, rows.data(), nr, folds.data(), inner_reps, nf, models[mi].alpha,
+                                    models[mi].proxy, 0.1, beta_dev, al.data(), lam.data(), nullptr), models[mi].base);
         name = std::string(models[mi].base) + "-alphas_";
-        for (int j = 0; j < m; ++j) name += (j ? "_" : "") + rust_display(models[mi].alpha);
+        for (int j = 0; j < m; ++j) name += (j ? "_" : "") + rust_display(al[j]);
         name += "-lambdas_";
         for (int j = 0; j < m; ++j) name += (j ? "_" : "") + rust_display(lam[j]);
     };

@@ -37,6 +37,13 @@ struct PathParams {
     int L;
 };
 
+// The coefficients whose norms pick the penalised set (:262-283): the fit itself, or, for the *_with_iterative_proxy_norms
+// models, the per-locus GWAS-like estimates of pg_gp_proxy_dev ((1+p) x k, row 0 unused).  b == nullptr: the fit itself.
+struct Proxy {
+    const double *b;
+    int k, j;
+};
+
 __device__ __forceinline__ double gp_norm(double b, double alpha) { // :259-261
     return ((1.00 - alpha) * (b * b) / 1.00) + (alpha * fabs(b));
 }
@@ -60,14 +67,15 @@ __global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k,
 // For every lambda_i: subtracted/added masses of the penalised set and the norm masses of the
 // de-penalised set, split by the sign of b (:296-326).  part: [block][4][GP_LMAX].
 __global__ void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, int row0, PathParams P,
-                               double *__restrict__ part) {
+                               Proxy X, double *__restrict__ part) {
     double sp[GP_LMAX], ap[GP_LMAX], sd[GP_LMAX], ad[GP_LMAX];
 #pragma unroll
     for (int i = 0; i < GP_LMAX; ++i) { sp[i] = 0.0; ap[i] = 0.0; sd[i] = 0.0; ad[i] = 0.0; }
     for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < p; l += (int64_t)gridDim.x * blockDim.x) {
         const double b = beta[(l + row0) * k + j];
         const double nrm = gp_norm(b, P.alpha);
-        const double sc = nrm / P.nmax; // normed_proxy / normed_proxy_max (:282), a true division: max/max == 1
+        const double nrx = X.b ? gp_norm(X.b[(l + 1) * X.k + X.j], P.alpha) : nrm;
+        const double sc = nrx / P.nmax; // normed_proxy / normed_proxy_max (:282), a true division: max/max == 1
         const bool pos = b >= 0.0;
         const double pen_pos = pos ? (((b - nrm) < 0.0) ? b : nrm) : 0.0;       // :298-305
         const double pen_neg = pos ? 0.0 : (((b + nrm) > 0.0) ? fabs(b) : nrm); // :306-313
@@ -101,9 +109,9 @@ __global__ void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k
 }
 
 // expand_and_contract of one coefficient for lambda_i (:296-352), given the global masses
-__device__ __forceinline__ double gp_contract(double b, const PathParams &P, int i) {
+__device__ __forceinline__ double gp_contract(double b, double bx, const PathParams &P, int i) {
     const double nrm = gp_norm(b, P.alpha);
-    const double sc = nrm / P.nmax;
+    const double sc = gp_norm(bx, P.alpha) / P.nmax;
     if (sc < P.lambda[i]) { // penalised: contract by its own norm, not across zero
         if (b >= 0.0) return ((b - nrm) < 0.0) ? 0.0 : b - nrm;
         return ((b + nrm) > 0.0) ? 0.0 : b + nrm;
@@ -114,20 +122,22 @@ __device__ __forceinline__ double gp_contract(double b, const PathParams &P, int
 }
 
 // B[l][i] for all lambdas (row stride GP_LMAX)
-__global__ void k_gp_blambda(const double *__restrict__ beta, int64_t p, int k, int j, PathParams P,
+__global__ void k_gp_blambda(const double *__restrict__ beta, int64_t p, int k, int j, PathParams P, Proxy X,
                              double *__restrict__ B) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= p) return;
     const double b = beta[(l + 1) * k + j];
+    const double bx = X.b ? X.b[(l + 1) * X.k + X.j] : b;
 #pragma unroll
-    for (int i = 0; i < GP_LMAX; ++i) B[l * GP_LMAX + i] = (i < P.L) ? gp_contract(b, P, i) : 0.0;
+    for (int i = 0; i < GP_LMAX; ++i) B[l * GP_LMAX + i] = (i < P.L) ? gp_contract(b, bx, P, i) : 0.0;
 }
 
 // single-lambda variant writing the penalised column back (final model, :653-662)
-__global__ void k_gp_apply(double *__restrict__ beta, int64_t p, int k, int j, PathParams P, int i) {
+__global__ void k_gp_apply(double *__restrict__ beta, int64_t p, int k, int j, PathParams P, Proxy X, int i) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= p) return;
-    beta[(l + 1) * k + j] = gp_contract(beta[(l + 1) * k + j], P, i);
+    const double b = beta[(l + 1) * k + j];
+    beta[(l + 1) * k + j] = gp_contract(b, X.b ? X.b[(l + 1) * X.k + X.j] : b, P, i);
 }
 
 // yhat partials: thread = pool, block = slab of loci; B rows are wave-uniform (scalar loads)
@@ -174,8 +184,8 @@ __global__ __launch_bounds__(256) void k_gp_predict(const double *__restrict__ G
 struct FoldMasses { double nmax, sub_scale[GP_LMAX], add_scale[GP_LMAX]; };
 __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
                                                           int C, const int32_t *__restrict__ colof,
-                                                          const FoldMasses *__restrict__ FM, PathParams P0, int64_t p,
-                                                          int n, int64_t ld, int64_t loci_per_block,
+                                                          const FoldMasses *__restrict__ FM, PathParams P0, Proxy X,
+                                                          int64_t p, int n, int64_t ld, int64_t loci_per_block,
                                                           double *__restrict__ part) {
     const int pool = blockIdx.y * 256 + threadIdx.x;
     const int64_t l0 = (int64_t)blockIdx.x * loci_per_block;
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restri
             const double g = gp[l * ld];
             const double b = bp[l * C];
             const double nrm = gp_norm(b, P0.alpha);
-            const double sc = nrm / fm.nmax;
+            const double sc = (X.b ? gp_norm(X.b[(l + 1) * X.k + X.j], P0.alpha) : nrm) / fm.nmax;
             const bool pos = b >= 0.0;
             const double pen = pos ? (((b - nrm) < 0.0) ? 0.0 : b - nrm) : (((b + nrm) > 0.0) ? 0.0 : b + nrm);
 #pragma unroll
@@ -277,10 +287,11 @@ struct RidgeWork {
 
 // steps 2-4 for trait j of `beta_dev`; returns the path parameters with the masses filled in
 int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int j, double alpha,
-                      const std::vector<double> &path, RidgeWork &W, PathParams &P, int row0 = 1) {
+                      const std::vector<double> &path, RidgeWork &W, PathParams &P, int row0 = 1, Proxy X = Proxy{nullptr, 0, 0}) {
     const int nb = 1024;
     std::vector<double> h((size_t)nb * 4 * GP_LMAX);
-    hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, alpha, W.part);
+    if (X.b) hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, X.b, p, X.k, X.j, 1, alpha, W.part);
+    else hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, alpha, W.part);
     PG_HIP(ctx, hipGetLastError());
     PG_HIP(ctx, hipMemcpyAsync(h.data(), W.part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -291,7 +302,7 @@ int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int
     P.nmax = mx;
     P.L = (int)path.size();
     for (int i = 0; i < P.L; ++i) P.lambda[i] = path[i];
-    hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, P, W.part);
+    hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, P, X, W.part);
     PG_HIP(ctx, hipGetLastError());
     PG_HIP(ctx, hipMemcpyAsync(h.data(), W.part, sizeof(double) * nb * 4 * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -312,22 +323,21 @@ int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int
     return PG_OK;
 }
 
-} // namespace
 
-extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
-                               int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
-                               int n_folds, double alpha, double lambda_step, double *beta_dev,
-                               double *lambdas_out, double *perf_out) {
-    if (!ctx) return PG_ERR_INVALID;
-    PG_CHECK(ctx, G_dev && Y && row_idx && fold_of && beta_dev && lambdas_out, "gp_ridge: null pointer");
-    PG_CHECK(ctx, p > 0 && n >= 3 && k >= 1 && k <= 8 && n_rows >= 3 && n_rows <= n && n_reps >= 1 && n_folds >= 2,
-             "gp_ridge: bad shape");
-    PG_CHECK(ctx, alpha >= 0.0 && alpha <= 1.0 && lambda_step > 0.0 && lambda_step <= 1.0, "gp_ridge: bad alpha / lambda step");
+// The lambda path with k-fold cross-validation (:461-669) behind penalise_lasso_like / _ridge_like (alpha = 1 / 0, one
+// path), penalise_glmnet (alpha < 0: the 2-D grid alpha x lambda over the same path values, :479-498) and the
+// *_with_iterative_proxy_norms models (proxy != nullptr, :540-553, :655-657).
+int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y, int k,
+                   const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps, int n_folds, double alpha,
+                   const double *proxy_dev, double lambda_step, double *beta_dev, double *alphas_out, double *lambdas_out,
+                   double *perf_out) {
     const int maxu = (int)std::llround(1.0 / lambda_step);
     const int L = maxu + 1;
     PG_CHECK(ctx, L <= GP_LMAX, "gp_ridge: at most %d lambdas on the path", GP_LMAX);
     std::vector<double> path(L);
     for (int i = 0; i < L; ++i) path[i] = (double)i / (double)maxu; // :470-476
+    const int A = alpha >= 0.0 ? 1 : L;                              // :479-498
+    auto alpha_at = [&](int a) { return alpha >= 0.0 ? alpha : path[a]; };
     PG_HIP(ctx, hipSetDevice(ctx->device));
 
     // the full-data X X^T once; every training subset uses a principal sub-block
@@ -358,12 +368,15 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
     W.yhat = W.B + (size_t)p * GP_LMAX;
     auto fail = [&](int rc) { (void)hipFree(raw); return rc; };
 
-    std::vector<double> perf((size_t)n_reps * n_folds * L * k, NAN), b0(k), yh((size_t)n * GP_LMAX);
+    // error indices (rep, fold, alpha, lambda, trait) as the reference's `performances` (:509)
+    std::vector<double> perf((size_t)n_reps * n_folds * A * L * k, NAN), b0(k), yh((size_t)n * GP_LMAX);
     std::vector<int64_t> itr, iva;
     for (int i = 0; i < n_reps * n_rows; ++i)
-        if (fold_of[i] < 0 || fold_of[i] > n_folds /* == n_folds: the left-over group of k_split (:444-448), never validated */) { ctx->err = "gp_ridge: fold id out of range"; return fail(PG_ERR_INVALID); }
+        if (fold_of[i] < 0 || fold_of[i] > n_folds /* == n_folds: the left-over group of k_split (:444-448), never validated */) {
+            ctx->err = "gp_ridge: fold id out of range"; return fail(PG_ERR_INVALID);
+        }
     // error_index (:359-426) of trait j on the validation pools `iva`, for every lambda, from yhat (n x GP_LMAX)
-    auto score = [&](int rep, int fold, int j, double b0j, const std::vector<int64_t> &iva_) {
+    auto score = [&](int rep, int fold, int a, int j, double b0j, const std::vector<int64_t> &iva_) {
         const int nv = (int)iva_.size();
         std::vector<double> yt(nv), yp(nv);
         double mn = 0, mx = 0;
@@ -380,12 +393,12 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
             mae /= (mx - mn);
             mse /= ((mx - mn) * (mx - mn));
             const double rmse = std::sqrt(mse) / (mx - mn);
-            perf[(((size_t)rep * n_folds + fold) * L + li) * k + j] = ((1.0 - std::fabs(cor)) + mae + mse + rmse) / 4.0;
+            perf[((((size_t)rep * n_folds + fold) * A + a) * L + li) * k + j] = ((1.0 - std::fabs(cor)) + mae + mse + rmse) / 4.0;
         }
     };
     // Every pool is validated by exactly ONE fold of a repetition, so all folds share two passes over G: one that
-    // forms the slopes of every fold's training fit (n_folds * k coefficient columns), one that predicts every
-    // pool with the coefficients of the fold that holds it out.  (Fallback below: one pair of passes per fold.)
+    // forms the slopes of every fold's training fit (n_folds * k coefficient columns), one (per alpha) that predicts
+    // every pool with the coefficients of the fold that holds it out.  (Fallback below: one pair of passes per fold.)
     const int C = n_folds * k;
     const bool fused = C <= PG_MAX_SWEEP_COLS && !std::getenv("POOLGEN_RIDGE_PER_FOLD");
     double *bf = nullptr;       // p x C slopes of the folds' fits
@@ -430,37 +443,39 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
             if (bad[f]) return fail2(pg_fail(ctx, PG_ERR_INVALID, "gp_ridge: pinv failed"));
         int rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Z.data(), C, bf); // :526 for every fold at once
         if (rc) return fail2(rc);
-        // the redistribution masses of every (fold, trait) column
-        std::vector<FoldMasses> fm(C);
-        PathParams P0;
-        std::memset(&P0, 0, sizeof P0);
-        for (int f = 0; f < n_folds; ++f)
-            for (int j = 0; j < k; ++j) {
-                if (va[f].empty() || tr[f].empty()) { std::memset(&fm[f * k + j], 0, sizeof(FoldMasses)); fm[f * k + j].nmax = 1.0; continue; }
-                PathParams P;
-                rc = ridge_path_params(ctx, bf, p, C, f * k + j, alpha, path, W, P, 0);
-                if (rc) return fail2(rc);
-                fm[f * k + j].nmax = P.nmax;
-                for (int i = 0; i < GP_LMAX; ++i) { fm[f * k + j].sub_scale[i] = P.sub_scale[i]; fm[f * k + j].add_scale[i] = P.add_scale[i]; }
-                P0 = P; // alpha, lambda[], L are the same for every column
-            }
-        if (hipMemcpyAsync(fm_dev, fm.data(), sizeof(FoldMasses) * C, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-            return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
-        for (int j = 0; j < k; ++j) {
-            std::vector<int32_t> colof(n, -1);
+        for (int a = 0; a < A; ++a) {
+            // the redistribution masses of every (fold, trait) column
+            std::vector<FoldMasses> fm(C);
+            PathParams P0;
+            std::memset(&P0, 0, sizeof P0);
             for (int f = 0; f < n_folds; ++f)
-                if (!va[f].empty() && !tr[f].empty())
-                    for (int64_t pool : va[f]) colof[pool] = f * k + j;
-            if (hipMemcpyAsync(colof_dev, colof.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                for (int j = 0; j < k; ++j) {
+                    if (va[f].empty() || tr[f].empty()) { std::memset(&fm[f * k + j], 0, sizeof(FoldMasses)); fm[f * k + j].nmax = 1.0; continue; }
+                    PathParams P;
+                    rc = ridge_path_params(ctx, bf, p, C, f * k + j, alpha_at(a), path, W, P, 0, Proxy{proxy_dev, k, j});
+                    if (rc) return fail2(rc);
+                    fm[f * k + j].nmax = P.nmax;
+                    for (int i = 0; i < GP_LMAX; ++i) { fm[f * k + j].sub_scale[i] = P.sub_scale[i]; fm[f * k + j].add_scale[i] = P.add_scale[i]; }
+                    P0 = P; // alpha, lambda[], L are the same for every column
+                }
+            if (hipMemcpyAsync(fm_dev, fm.data(), sizeof(FoldMasses) * C, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                 return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
-            hipLaunchKernelGGL(k_gp_predict_folds, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, bf, C, colof_dev,
-                               fm_dev, P0, p, n, ld, lpb, W.part);
-            hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
-            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess)
-                return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
-            for (int f = 0; f < n_folds; ++f)
-                if (!va[f].empty() && !tr[f].empty()) score(rep, f, j, b0c[f * k + j], va[f]);
+            for (int j = 0; j < k; ++j) {
+                std::vector<int32_t> colof(n, -1);
+                for (int f = 0; f < n_folds; ++f)
+                    if (!va[f].empty() && !tr[f].empty())
+                        for (int64_t pool : va[f]) colof[pool] = f * k + j;
+                if (hipMemcpyAsync(colof_dev, colof.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
+                hipLaunchKernelGGL(k_gp_predict_folds, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, bf, C, colof_dev,
+                                   fm_dev, P0, Proxy{proxy_dev, k, j}, p, n, ld, lpb, W.part);
+                hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
+                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess)
+                    return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
+                for (int f = 0; f < n_folds; ++f)
+                    if (!va[f].empty() && !tr[f].empty()) score(rep, f, a, j, b0c[f * k + j], va[f]);
+            }
         }
     }
     (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev);
@@ -476,43 +491,58 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
             if (rc) return fail(rc);
             if (hipMemcpyAsync(b0.data(), beta_dev, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
                 return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: D2H failed"));
-            for (int j = 0; j < k; ++j) {
-                PathParams P;
-                rc = ridge_path_params(ctx, beta_dev, p, k, j, alpha, path, W, P);
-                if (rc) return fail(rc);
-                hipLaunchKernelGGL(k_gp_blambda, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, W.B);
-                hipLaunchKernelGGL(k_gp_predict, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, W.B, p, n, ld, lpb, W.part);
-                hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
-                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess)
-                    return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
-                score(rep, fold, j, b0[j], iva);
-            }
+            for (int a = 0; a < A; ++a)
+                for (int j = 0; j < k; ++j) {
+                    PathParams P;
+                    const Proxy X{proxy_dev, k, j};
+                    rc = ridge_path_params(ctx, beta_dev, p, k, j, alpha_at(a), path, W, P, 1, X);
+                    if (rc) return fail(rc);
+                    hipLaunchKernelGGL(k_gp_blambda, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, X, W.B);
+                    hipLaunchKernelGGL(k_gp_predict, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, W.B, p, n, ld, lpb, W.part);
+                    hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
+                    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess)
+                        return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
+                    score(rep, fold, a, j, b0[j], iva);
+                }
         }
-    // all-rows fit, per trait the mode over repetitions of the per-repetition arg-min (:573-627)
+    // all-rows fit; per trait the mode over repetitions of the per-repetition arg-min over the (alpha, lambda) grid
+    // (:573-627): alpha and lambda are counted separately, each against the path values
     int rc = pg_gp_ols_dev(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, xxt.data(), beta_dev);
     if (rc) return fail(rc);
     for (int j = 0; j < k; ++j) {
-        std::vector<int> counts(L, 0);
+        std::vector<int> acount(L, 0), lcount(L, 0);
         for (int rep = 0; rep < n_reps; ++rep) {
-            std::vector<double> mean(L);
-            for (int li = 0; li < L; ++li) {
-                double s = 0.0;
-                for (int fold = 0; fold < n_folds; ++fold) s += perf[(((size_t)rep * n_folds + fold) * L + li) * k + j];
-                mean[li] = s / (double)n_folds;
-            }
+            std::vector<double> mean((size_t)A * L);
+            for (int a = 0; a < A; ++a)
+                for (int li = 0; li < L; ++li) {
+                    double sum = 0.0;
+                    for (int fold = 0; fold < n_folds; ++fold) sum += perf[((((size_t)rep * n_folds + fold) * A + a) * L + li) * k + j];
+                    mean[(size_t)a * L + li] = sum / (double)n_folds;
+                }
             double mnv = mean[0];
-            for (int li = 0; li < L; ++li) if (mean[li] < mnv) mnv = mean[li];
-            for (int li = 0; li < L; ++li) if (mean[li] == mnv) { counts[li] += 1; break; }
+            for (double x : mean) if (x < mnv) mnv = x;
+            for (size_t q = 0; q < mean.size(); ++q)
+                if (mean[q] == mnv) {
+                    const double aval = alpha_at((int)(q / L)), lval = path[q % L];
+                    for (int c = 0; c < L; ++c) { acount[c] += (aval == path[c]); lcount[c] += (lval == path[c]); }
+                    break;
+                }
         }
-        int mxc = 0, best = 0;
-        for (int a = 0; a < L; ++a) mxc = std::max(mxc, counts[a]);
-        for (int a = 0; a < L; ++a) if (counts[a] == mxc) { best = a; break; }
-        lambdas_out[j] = path[best];
+        int amax = 0, lmax = 0, abest = 0, lbest = 0;
+        for (int c = 0; c < L; ++c) { amax = std::max(amax, acount[c]); lmax = std::max(lmax, lcount[c]); }
+        for (int c = 0; c < L; ++c) if (acount[c] == amax) { abest = c; break; }
+        for (int c = 0; c < L; ++c) if (lcount[c] == lmax) { lbest = c; break; }
+        // a single alpha off the path grid counts nowhere in the reference (:605-608), which then reports and applies
+        // path[0]; such an alpha never reaches it from its own callers (0, 1, grid), here it is kept as given
+        const double afinal = alpha >= 0.0 ? alpha : path[abest];
+        if (alphas_out) alphas_out[j] = afinal;
+        lambdas_out[j] = path[lbest];
         PathParams P;
-        rc = ridge_path_params(ctx, beta_dev, p, k, j, alpha, path, W, P);
+        const Proxy X{proxy_dev, k, j};
+        rc = ridge_path_params(ctx, beta_dev, p, k, j, afinal, path, W, P, 1, X);
         if (rc) return fail(rc);
-        hipLaunchKernelGGL(k_gp_apply, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, best);
+        hipLaunchKernelGGL(k_gp_apply, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, X, lbest);
         if (hipGetLastError() != hipSuccess) return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: apply failed"));
     }
     if (perf_out) std::memcpy(perf_out, perf.data(), sizeof(double) * perf.size());
@@ -520,6 +550,46 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
     (void)hipFree(raw);
     return PG_OK;
 }
+
+} // namespace
+
+extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
+                               int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
+                               int n_folds, double alpha, double lambda_step, double *beta_dev,
+                               double *lambdas_out, double *perf_out) {
+    if (!ctx) return PG_ERR_INVALID;
+    PG_CHECK(ctx, G_dev && Y && row_idx && fold_of && beta_dev && lambdas_out, "gp_ridge: null pointer");
+    PG_CHECK(ctx, p > 0 && n >= 3 && k >= 1 && k <= 8 && n_rows >= 3 && n_rows <= n && n_reps >= 1 && n_folds >= 2,
+             "gp_ridge: bad shape");
+    PG_CHECK(ctx, alpha >= 0.0 && alpha <= 1.0 && lambda_step > 0.0 && lambda_step <= 1.0, "gp_ridge: bad alpha / lambda step");
+    return penalised_path(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, fold_of, n_reps, n_folds, alpha, nullptr, lambda_step,
+                          beta_dev, nullptr, lambdas_out, perf_out);
+}
+
+extern "C" int pg_gp_penalised_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
+                                   int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
+                                   int n_folds, double alpha, int iterative_proxy, double lambda_step, double *beta_dev,
+                                   double *alphas_out, double *lambdas_out, double *perf_out) {
+    if (!ctx) return PG_ERR_INVALID;
+    PG_CHECK(ctx, G_dev && Y && row_idx && fold_of && beta_dev && lambdas_out, "gp_penalised: null pointer");
+    PG_CHECK(ctx, p > 0 && n >= 3 && k >= 1 && k <= 8 && n_rows >= 3 && n_rows <= n && n_reps >= 1 && n_folds >= 2,
+             "gp_penalised: bad shape");
+    PG_CHECK(ctx, alpha <= 1.0 && lambda_step > 0.0 && lambda_step <= 1.0, "gp_penalised: bad alpha / lambda step");
+    double *proxy = nullptr;
+    if (iterative_proxy) { // the same proxy serves every fold and the final fit (:543, :656: always on `row_idx`)
+        PG_HIP(ctx, hipSetDevice(ctx->device));
+        PG_HIP(ctx, hipMalloc((void **)&proxy, sizeof(double) * (size_t)(p + 1) * k));
+        const int rc = pg_gp_proxy_dev(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, nullptr, proxy);
+        if (rc) { (void)hipFree(proxy); return rc; }
+    }
+    const int rc = penalised_path(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, fold_of, n_reps, n_folds, alpha, proxy, lambda_step,
+                                  beta_dev, alphas_out, lambdas_out, perf_out);
+    if (proxy) (void)hipFree(proxy);
+    return rc;
+}
+
+namespace {
+} // namespace
 
 // yhat = X beta for every pool (the multiply_views_xx of gp/cv.rs:160-168, all rows at once)
 extern "C" int pg_gp_predict_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *beta_dev,

@@ -673,3 +673,130 @@ extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
     if (rc) return rc;
     return PG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// gp::ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199): the proxy coefficients of the
+// *_with_iterative_proxy_norms models.  Per locus the last coefficient of y ~ [1 | PC1 | g] on the training
+// pools, PC1 = leading eigenvector of the "kinship" of the training pools -- the very sweep of
+// ols_iter_with_kinship with one covariate, run on the training pools' columns of G.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void k_gather_pools(const double *__restrict__ G, int64_t p, int64_t ld, const int32_t *__restrict__ rows,
+                               int nr, int64_t ld2, double *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p * ld2) return;
+    const int64_t l = idx / ld2;
+    const int i = (int)(idx - l * ld2);
+    out[idx] = i < nr ? G[l * ld + rows[i]] : 0.0;
+}
+
+struct ProxyFix { double a0[8]; };
+// A locus whose frequencies are the same in every training pool is collinear with the intercept; the reference's
+// least_squares (LAPACK gelsd, :193) returns the minimum-norm solution there: with y ~ a0 + b0 PC1 the fit of the
+// other two columns, the set of solutions is a + c d = a0, and the shortest one has d = c a0 / (1 + c^2).
+__global__ void k_proxy_fix_constant(const double *__restrict__ Gs, int64_t p, int nr, int64_t ld2, ProxyFix F, int k,
+                                     double *__restrict__ beta) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= p) return;
+    if (!isnan(beta[l * k])) return;
+    const double c = Gs[l * ld2];
+    for (int i = 1; i < nr; ++i)
+        if (Gs[l * ld2 + i] != c) return; // singular for another reason: stays NaN
+    for (int j = 0; j < k; ++j) beta[l * k + j] = c * F.a0[j] / (1.0 + c * c);
+}
+
+} // namespace
+
+extern "C" int pg_gp_proxy_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y, int k,
+                               const int64_t *row_idx, int n_rows, const double *XXt_host_or_null, double *proxy_dev) {
+    if (!ctx) return PG_ERR_INVALID;
+    PG_CHECK(ctx, G_dev && Y && row_idx && proxy_dev && p >= 2 && n >= 4 && k >= 1 && k <= 8 && n_rows >= 4 && n_rows <= n,
+             "gp_proxy: bad arguments");
+    PG_CHECK(ctx, ld >= n, "gp_proxy: ld must be >= n");
+    for (int a = 0; a < n_rows; ++a) PG_CHECK(ctx, row_idx[a] >= 0 && row_idx[a] < n, "gp_proxy: row index out of range");
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    const int nr = n_rows;
+    std::vector<double> T((size_t)n * n), glast(n);
+    if (XXt_host_or_null) std::memcpy(T.data(), XXt_host_or_null, sizeof(double) * n * n);
+    else {
+        double *S = nullptr;
+        PG_HIP(ctx, hipMalloc((void **)&S, sizeof(double) * n * n));
+        int rc = pg_gp_xxt_dev(ctx, G_dev, p, n, ld, S);
+        if (rc == PG_OK && (hipMemcpyAsync(T.data(), S, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                            hipStreamSynchronize(ctx->stream) != hipSuccess))
+            rc = pg_fail(ctx, PG_ERR_HIP, "gp_proxy: D2H failed");
+        (void)hipFree(S);
+        if (rc) return rc;
+    }
+    PG_HIP(ctx, hipMemcpyAsync(glast.data(), G_dev + (p - 1) * ld, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // The reference centres columns 0..P-2 of x = [1 | G^T] (the intercept IS among them, the last locus is NOT, :115),
+    // each by its mean over the FIRST n_rows rows of x (not over row_idx, :124-129), then takes X_c X_c^T over the
+    // training rows (:132-140).  With T = x x^T over those columns (the full X X^T minus the last locus' outer
+    // product): K[a][b] = T[ra][rb] - u[ra] - u[rb] + c,  u[r] = mean_{i<nr} T[i][r],  c = mean_{i,i'<nr} T[i][i'].
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) T[(size_t)i * n + j] -= glast[i] * glast[j];
+    std::vector<double> u(n, 0.0), K((size_t)nr * nr);
+    double c = 0.0;
+    for (int r = 0; r < n; ++r) {
+        double s = 0.0;
+        for (int i = 0; i < nr; ++i) s += T[(size_t)i * n + r];
+        u[r] = s / (double)nr;
+    }
+    for (int i = 0; i < nr; ++i) c += u[i];
+    c /= (double)nr;
+    for (int a = 0; a < nr; ++a)
+        for (int b = 0; b < nr; ++b)
+            K[(size_t)a * nr + b] = T[(size_t)row_idx[a] * n + row_idx[b]] - u[row_idx[a]] - u[row_idx[b]] + c;
+    // eigen_vectors column 0 (:141, :177): the leading one, under the same reading of the LAPACK order as
+    // ols_with_covariate (gwas/ols.rs:296)
+    std::vector<double> evals(nr), ev(nr);
+    if (pg_sym_eig_top(K.data(), nr, 1, evals.data(), ev.data()) != 0)
+        return pg_fail(ctx, PG_ERR_INVALID, "gp_proxy: eigen-decomposition failed");
+    std::vector<double> Ys((size_t)nr * k), ymean(k, 0.0);
+    for (int a = 0; a < nr; ++a)
+        for (int j = 0; j < k; ++j) { Ys[(size_t)a * k + j] = Y[(size_t)row_idx[a] * k + j]; ymean[j] += Ys[(size_t)a * k + j]; }
+    for (int j = 0; j < k; ++j) ymean[j] /= (double)nr; // row 0 (:170-172)
+    // the training pools' columns, compacted (the sweep reads whole rows of pools)
+    const int64_t ld2 = nr + (nr & 1);
+    double *Gs = nullptr, *scratch = nullptr;
+    int32_t *rows_dev = nullptr;
+    std::vector<int32_t> rows32(nr);
+    for (int a = 0; a < nr; ++a) rows32[a] = (int32_t)row_idx[a];
+    auto cleanup = [&] { (void)hipFree(Gs); (void)hipFree(scratch); (void)hipFree(rows_dev); };
+    if (hipMalloc((void **)&Gs, sizeof(double) * (size_t)p * ld2) != hipSuccess ||
+        hipMalloc((void **)&scratch, sizeof(double) * (size_t)p * k) != hipSuccess ||
+        hipMalloc((void **)&rows_dev, sizeof(int32_t) * nr) != hipSuccess) {
+        cleanup();
+        return pg_fail(ctx, PG_ERR_HIP, "gp_proxy: out of device memory");
+    }
+    if (hipMemcpyAsync(rows_dev, rows32.data(), sizeof(int32_t) * nr, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        cleanup();
+        return pg_fail(ctx, PG_ERR_HIP, "gp_proxy: H2D failed");
+    }
+    hipLaunchKernelGGL(k_gather_pools, dim3((unsigned)(((size_t)p * ld2 + 255) / 256)), dim3(256), 0, ctx->stream, G_dev, p, ld,
+                       rows_dev, nr, ld2, Gs);
+    int rc = pg_covariates_set(ctx, nr, ev.data(), 1, Ys.data(), k);
+    if (rc == PG_OK) rc = pg_ols_sweep_dev(ctx, Gs, p, nr, ld2, proxy_dev + k, scratch, scratch);
+    if (rc == PG_OK) {
+        // y ~ a0 + b0 PC1 for the constant loci
+        ProxyFix F{};
+        double s1 = 0.0, s2 = 0.0;
+        for (int a = 0; a < nr; ++a) { s1 += ev[a]; s2 += ev[a] * ev[a]; }
+        const double det = (double)nr * s2 - s1 * s1;
+        for (int j = 0; j < k; ++j) {
+            double sy = 0.0, sey = 0.0;
+            for (int a = 0; a < nr; ++a) { sy += Ys[(size_t)a * k + j]; sey += ev[a] * Ys[(size_t)a * k + j]; }
+            F.a0[j] = (s2 * sy - s1 * sey) / det;
+        }
+        hipLaunchKernelGGL(k_proxy_fix_constant, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, Gs, p, nr, ld2, F, k,
+                           proxy_dev + k);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(proxy_dev, ymean.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = pg_fail(ctx, PG_ERR_HIP, "gp_proxy: closing step failed");
+    }
+    cleanup();
+    return rc;
+}

@@ -269,6 +269,40 @@ class Engine:
                                                 self._dev(beta, torch.float64), k, yhat.ctypes.data), "pg_gp_predict_dev")
         return yhat
 
+    def gp_penalised(self, G: torch.Tensor, Y, row_idx, fold_of, n_folds: int, alpha: float, iterative_proxy: bool = False,
+                     lambda_step: float = 0.1, n: int | None = None):
+        """Every model behind penalised_lambda_path_with_k_fold_cross_validation (gp/penalise.rs:461-669): alpha in
+        [0, 1] one lambda path, alpha < 0 the alpha x lambda grid of penalise_glmnet, iterative_proxy the
+        *_with_iterative_proxy_norms variants.  Returns (beta (1+p) x k on the device, alphas[k], lambdas[k],
+        perf[n_reps, n_folds, A, L, k])."""
+        p, ld, n = self._g_dims(G, n)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        ri = np.ascontiguousarray(np.asarray(row_idx, dtype=np.int64))
+        fo = np.ascontiguousarray(np.asarray(fold_of, dtype=np.int32)).reshape(-1, len(ri))
+        L = int(round(1.0 / lambda_step)) + 1
+        A = 1 if alpha >= 0 else L
+        beta = torch.empty((p + 1, k), dtype=torch.float64, device=G.device)
+        al, lam = np.empty(k), np.empty(k)
+        perf = np.empty((fo.shape[0], n_folds, A, L, k))
+        self._check(self._lib.pg_gp_penalised_dev(self._ctx, self._dev(G, torch.float64), p, n, ld, Yh.ctypes.data, k,
+                                                  ri.ctypes.data, len(ri), fo.ctypes.data, fo.shape[0], int(n_folds),
+                                                  float(alpha), int(bool(iterative_proxy)), float(lambda_step),
+                                                  beta.data_ptr(), al.ctypes.data, lam.ctypes.data, perf.ctypes.data),
+                    "pg_gp_penalised_dev")
+        return beta, al, lam, perf
+
+    def gp_proxy(self, G: torch.Tensor, Y, row_idx, n: int | None = None) -> torch.Tensor:
+        """ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199): (1+p) x k on the device."""
+        p, ld, n = self._g_dims(G, n)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        ri = np.ascontiguousarray(np.asarray(row_idx, dtype=np.int64))
+        out = torch.empty((p + 1, k), dtype=torch.float64, device=G.device)
+        self._check(self._lib.pg_gp_proxy_dev(self._ctx, self._dev(G, torch.float64), p, n, ld, Yh.ctypes.data, k,
+                                              ri.ctypes.data, len(ri), None, out.data_ptr()), "pg_gp_proxy_dev")
+        return out
+
     def gp_ridge(self, G: torch.Tensor, Y, row_idx, fold_of, n_folds: int, alpha: float = 0.0,
                  lambda_step: float = 0.1, n: int | None = None):
         """penalise_ridge_like (gp/penalise.rs:133-159) with explicit folds: fold_of is (n_reps, len(row_idx)).

@@ -69,6 +69,8 @@ class Oracle:
         lib.orc_expand_and_contract.argtypes = [vp, vp, i64, i, d, d, vp]
         lib.orc_error_index.argtypes = [vp, i64, i, i64, vp, i, vp, vp, i, vp]
         lib.orc_penalised_lambda_path.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i, i, d, d, vp, vp, vp, i]
+        lib.orc_penalised_path_general.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i, i, d, i, d, vp, vp, vp, vp, i]
+        lib.orc_gp_proxy.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i]
 
     # ---- small conveniences -------------------------------------------------------------
     @staticmethod
@@ -256,6 +258,36 @@ class Oracle:
                                            fo.ctypes.data, fo.shape[0], n_folds, float(alpha), float(lambda_step),
                                            beta.ctypes.data, lam.ctypes.data, perf.ctypes.data, threads)
         return beta, lam, perf
+
+    def penalised_path_general(self, Xt, Y, row_idx, fold_of, n_folds, alpha, iterative, lambda_step=0.1, n=None, threads=0):
+        """every mode of the path (alpha < 0: the alpha x lambda grid; iterative: proxy norms).
+        Returns beta, alphas, lambdas, perf[reps, folds, A, L, k]."""
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        P, ld = Xt.shape
+        n = ld if n is None else n
+        Y = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        k = Y.shape[1]
+        ri = np.ascontiguousarray(row_idx, dtype=np.int64)
+        fo = np.ascontiguousarray(fold_of, dtype=np.int32).reshape(-1, len(ri))
+        L = int(round(1.0 / lambda_step)) + 1
+        A = 1 if alpha >= 0 else L
+        beta = np.empty((P, k)); al = np.empty(k); lam = np.empty(k); perf = np.empty((fo.shape[0], n_folds, A, L, k))
+        self.lib.orc_penalised_path_general(Xt.ctypes.data, P, n, ld, Y.ctypes.data, k, ri.ctypes.data, len(ri),
+                                            fo.ctypes.data, fo.shape[0], n_folds, float(alpha), int(bool(iterative)),
+                                            float(lambda_step), beta.ctypes.data, al.ctypes.data, lam.ctypes.data,
+                                            perf.ctypes.data, threads)
+        return beta, al, lam, perf
+
+    def gp_proxy(self, Xt, Y, row_idx, n=None, threads=0):
+        """ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199): P x k"""
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        P, ld = Xt.shape
+        n = ld if n is None else n
+        Y = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        ri = np.ascontiguousarray(row_idx, dtype=np.int64)
+        b = np.empty((P, Y.shape[1]))
+        self.lib.orc_gp_proxy(Xt.ctypes.data, P, n, ld, Y.ctypes.data, Y.shape[1], ri.ctypes.data, len(ri), b.ctypes.data, threads)
+        return b
 
     def expand_and_contract(self, b, bp, alpha, lam):
         b = np.ascontiguousarray(b, dtype=np.float64); bp = np.ascontiguousarray(bp, dtype=np.float64)

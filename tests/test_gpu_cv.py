@@ -102,10 +102,12 @@ def test_cli_cross_validation(oracle, tmp_path):
     Xt = np.vstack([np.ones(n), np.array(cols)])  # (1 + p) x n
     P, m = Xt.shape[0], 2
     rng = SplitMix64(seed)
-    models = [("ols", None), ("penalise_lasso_like", 1.0), ("penalise_ridge_like", 0.0)]
+    models = [("ols", None, 0), ("penalise_glmnet", -0.1, 0), ("penalise_lasso_like", 1.0, 0), ("penalise_ridge_like", 0.0, 0),
+              ("penalise_lasso_like_with_iterative_proxy_norms", 1.0, 1), ("penalise_ridge_like_with_iterative_proxy_norms", 1.0, 1)]
+    nmod = len(models)
 
     def fit(mi, rows_):
-        base, alpha = models[mi]
+        base, alpha, proxy = models[mi]
         if alpha is None:
             rc, b = oracle.gp_ols(Xt, Y, rows_)
             assert rc == 0
@@ -115,19 +117,19 @@ def test_cli_cross_validation(oracle, tmp_path):
             perm = rng.permutation(nr)
             g, nf = k_split(nr, 10, [rows_[i] for i in perm])
             folds.append(g)
-        b, lam, _ = oracle.penalised_lambda_path(Xt, Y, rows_, np.array(folds), nf, alpha=alpha)
-        name = base + "-alphas_" + "_".join(oracle.fmt(alpha) for _ in range(m)) + "-lambdas_" + "_".join(oracle.fmt(x) for x in lam)
+        b, al, lam, _ = oracle.penalised_path_general(Xt, Y, rows_, np.array(folds), nf, alpha, proxy)
+        name = base + "-alphas_" + "_".join(oracle.fmt(x) for x in al) + "-lambdas_" + "_".join(oracle.fmt(x) for x in lam)
         return b, name
 
     perf = {}
-    yvp = np.full((reps, 3, n, 2 * m), np.nan)
-    names = [None] * 3
+    yvp = np.full((reps, nmod, n, 2 * m), np.nan)
+    names = [None] * nmod
     for rep in range(reps):
         grp, kk = k_split(n, kf, rng.permutation(n))
         for fold in range(kk):
             val = [i for i in range(n) if grp[i] == fold]
             tr = [i for i in range(n) if grp[i] != fold]
-            for mi in range(3):
+            for mi in range(nmod):
                 b, name = fit(mi, tr)
                 if rep == 0 and fold == 0:
                     names[mi] = name
@@ -141,11 +143,11 @@ def test_cli_cross_validation(oracle, tmp_path):
     # ---- performance table ---------------------------------------------------------------------------------------
     got = out.read_text().splitlines()
     assert got[0] == "#rep,fold,model,phenotype,pearsons_correlation,mean_bias_error,mean_absolute_error,mean_square_error,root_mean_square_error"
-    assert len(got) == 1 + reps * kf * 3 * m
+    assert len(got) == 1 + reps * kf * nmod * m
     it = iter(got[1:])
     for rep in range(reps):
         for fold in range(kf):
-            for mi in range(3):
+            for mi in range(nmod):
                 for j in range(m):
                     fa = next(it).split(",")
                     assert fa[:4] == [str(rep), str(fold), names[mi], str(j)]
@@ -155,10 +157,10 @@ def test_cli_cross_validation(oracle, tmp_path):
     # ---- expected and predicted phenotypes -----------------------------------------------------------------------
     got = (tmp_path / "cv-expected_and_predicted_phenotypes.csv").read_text().splitlines()
     assert got[0] == "#rep,model,pool,predicted_trait_0,predicted_trait_1,expected_trait_0,expected_trait_1"
-    assert len(got) == 1 + reps * 3 * n
+    assert len(got) == 1 + reps * nmod * n
     it = iter(got[1:])
     for rep in range(reps):
-        for mi in range(3):
+        for mi in range(nmod):
             for pool in range(n):
                 fa = next(it).split(",")
                 assert fa[:3] == [str(rep), names[mi], f"P{pool}"]
@@ -167,7 +169,7 @@ def test_cli_cross_validation(oracle, tmp_path):
                 assert fa[5:] == [oracle.fmt(x) for x in yvp[rep, mi, pool, m:]]       # the expected traits print exactly
     # ---- all-data predictors -------------------------------------------------------------------------------------
     allrows = list(range(n))
-    for mi in range(3):
+    for mi in range(nmod):
         b, name = fit(mi, allrows)
         got = (tmp_path / f"cv-genomic_predictors-{name}.csv").read_text().splitlines()
         assert got[0] == "#chromosome,position,allele,phenotype,predictor" and len(got) == 1 + P * m

@@ -1,6 +1,8 @@
 """GPU parity tests of the headline path (ols_iter_with_kinship) through the C ABI, checked
 against the CPU oracle on identical inputs.  Tolerances (north_star): 1e-10 for coefficients
 (relative) and p-values (absolute); kinship sums 1e-11 relative (summation order only)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -212,6 +214,58 @@ def test_gp_ridge_leftover_group_only_trains(engine, oracle):
     assert np.array_equal(lam, rl)
     assert np.allclose(perf, rp, rtol=1e-6, atol=1e-9)
     assert np.allclose(beta.cpu().numpy(), rb, rtol=1e-6, atol=1e-8 * np.abs(rb).max())
+
+
+@pytest.mark.parametrize("n,p,k,rows", [(40, 3000, 2, None), (50, 2001, 1, "odd"), (64, 1500, 2, "drop")])
+def test_gp_proxy_matches_oracle(engine, oracle, n, p, k, rows):
+    """ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199): per-locus coefficient of y ~ [1 | PC1 | g] on the
+    training pools, with the reference's kinship (last locus left out, means over the first n_rows pools)."""
+    G, Y = make(p, n, 71)
+    Y = np.hstack([Y, Y[:, :1] * 0.5 + 1.0])[:, :k]
+    idx = np.arange(n) if rows is None else (np.arange(1, n, 2) if rows == "odd" else np.array([i for i in range(n) if i % 10 != 3]))
+    G[17, :] = 0.25                          # a locus constant over the pools: the minimum-norm branch of least_squares
+    got = engine.gp_proxy(G, Y, idx, n=n).cpu().numpy()
+    Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])
+    ref = oracle.gp_proxy(Xt, Y, idx, n=n)
+    assert not np.isnan(ref).any()
+    assert np.allclose(got, ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    # and against numpy's own least squares for a few loci (the restated kinship included)
+    nr = len(idx)
+    xc = Xt[:-1, :].T[idx] - Xt[:-1, :nr].mean(axis=1)
+    w, V = np.linalg.eigh(xc @ xc.T)
+    ev = V[:, -1]
+    for l in (1, 18, p // 2, p):
+        sol = np.linalg.lstsq(np.column_stack([np.ones(nr), ev, Xt[l, idx]]), Y[idx], rcond=None)[0][2]
+        assert np.allclose(got[l], sol, rtol=1e-6, atol=1e-8 * np.abs(ref).max()), l
+
+
+@pytest.mark.parametrize("n,p,k,alpha,proxy", [(48, 2000, 1, -0.1, False), (40, 1500, 2, -0.1, False),
+                                                (48, 2000, 1, 1.0, True), (44, 1200, 2, 0.0, True)])
+def test_gp_penalised_family_matches_oracle(engine, oracle, n, p, k, alpha, proxy):
+    """penalise_glmnet (alpha < 0: the alpha x lambda grid, gp/penalise.rs:168-195, :479-498) and the
+    *_with_iterative_proxy_norms models (:197-246) with explicit folds."""
+    G, Y = make(p, n, 83)
+    Y = Y[:, :k]
+    rng = np.random.default_rng(12)
+    rows = np.array([i for i in range(n) if i % 11 != 5])
+    n_folds, n_reps = 3, 3
+    folds = np.stack([rng.permutation(np.arange(len(rows)) % n_folds) for _ in range(n_reps)])
+    beta, al, lam, perf = engine.gp_penalised(G, Y, rows, folds, n_folds, alpha, proxy, n=n)
+    Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])
+    rb, ra, rl, rp = oracle.penalised_path_general(Xt, Y, rows, folds, n_folds, alpha, proxy, n=n)
+    assert perf.shape == rp.shape == (n_reps, n_folds, 11 if alpha < 0 else 1, 11, k)
+    assert np.allclose(perf, rp, rtol=1e-6, atol=1e-9)
+    assert np.array_equal(al, ra) and np.array_equal(lam, rl)
+    assert np.allclose(beta.cpu().numpy(), rb, rtol=1e-6, atol=1e-8 * np.abs(rb).max())
+    if alpha >= 0 and not proxy:
+        return
+    # the per-fold route (one pair of passes over G per fold) must agree with the fused one
+    os.environ["POOLGEN_RIDGE_PER_FOLD"] = "1"
+    try:
+        beta2, al2, lam2, perf2 = engine.gp_penalised(G, Y, rows, folds, n_folds, alpha, proxy, n=n)
+    finally:
+        del os.environ["POOLGEN_RIDGE_PER_FOLD"]
+    assert np.allclose(perf2, perf, rtol=1e-9, atol=1e-12) and np.array_equal(lam2, lam) and np.array_equal(al2, al)
 
 
 def test_gp_ols_with_duplicated_pools_uses_the_pseudo_inverse(engine, oracle):
