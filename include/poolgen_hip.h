@@ -159,6 +159,10 @@ int pg_load_plan_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, 
                      const pg_filter *filter, int keep_p_minus_1, const int64_t *order_dev, int64_t *p_out);
 int pg_load_emit_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,
                      int64_t *col_locus_dev, int32_t *col_allele_dev);
+/* pg_load_emit_dev that also writes the coverages GenotypesAndPhenotypes carries (sync.rs:1129-1152): cov_dev is
+ * p x ld like G; every column row of a locus holds, per pool, the depth summed over the locus' surviving alleles. */
+int pg_load_emit_cov_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,
+                         int64_t *col_locus_dev, int32_t *col_allele_dev, double *cov_dev);
 /* Host-buffer forms of the three batch operators (H2D/D2H inside). */
 int pg_ols_iter_batch(pg_ctx *ctx, const uint32_t *counts, int64_t L, int n,
                       const double *pool_sizes, const pg_filter *filter, const double *Y, int k,
@@ -219,6 +223,28 @@ int pg_gp_proxy_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
  * the cross-validation harness (multiply_views_xx in gp/cv.rs:160-168); the caller reads the validation rows. */
 int pg_gp_predict_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *beta_dev,
                       int k, double *yhat);
+
+/* ---------------------------------------------------------------------------------------
+ * popgen on the loader's matrix: fst (popgen/fst.rs:10-115, :158-200) and
+ * theta_pi / `heterozygosity` (popgen/pi.rs:10-113).  G and cov as written by pg_load_emit_cov_dev
+ * (all alleles kept); locus_col (host, L + 1 entries, 0 .. p): the first column of every locus =
+ * count_loci (sync.rs:73-97) minus the intercept; windows = inclusive locus index ranges from
+ * pg_host_sliding_windows = define_sliding_windows (base/helpers.rs:294-403; chromosomes as ids,
+ * only equality is used; head/tail need room for L entries; returns the number of windows).
+ *   pg_pi_dev : pi_win (host, n_windows x n) per-window means, pi_mean (host, n) their mean (:133).
+ *   pg_fst_dev: fst_mean (host, n x n) mean over all loci (:145), fst_win (host, n_windows x n*n);
+ *               fails with PG_ERR_INVALID where the reference's assert does (a locus whose
+ *               frequencies do not sum to one in every pool, :66).
+ * ------------------------------------------------------------------------------------- */
+int64_t pg_host_sliding_windows(const int32_t *chr_id, const uint64_t *pos, int64_t L, uint64_t window_size_bp,
+                                uint64_t window_slide_size_bp, uint64_t min_loci_per_window, int64_t *head,
+                                int64_t *tail);
+int pg_pi_dev(pg_ctx *ctx, const double *G_dev, const double *cov_dev, int64_t p, int n, int64_t ld,
+              const int64_t *locus_col, int64_t L, const int64_t *win_head, const int64_t *win_tail,
+              int64_t n_windows, double *pi_win, double *pi_mean);
+int pg_fst_dev(pg_ctx *ctx, const double *G_dev, const double *cov_dev, int64_t p, int n, int64_t ld,
+               const int64_t *locus_col, int64_t L, const int64_t *win_head, const int64_t *win_tail,
+               int64_t n_windows, double *fst_mean, double *fst_win);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side pieces of the path (O(n^3), n = pools): exported so that they can be validated

@@ -1348,6 +1348,133 @@ int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, co
 }
 
 /* ============================================================================================
+ * popgen: define_sliding_windows (base/helpers.rs:294-403), fst (popgen/fst.rs:10-115, :158-200),
+ * theta_pi (popgen/pi.rs:10-113).  Genotypes as for gp: Xt locus-major (P x ld), row 0 = intercept.
+ * loci_idx: the L + 1 column starts of count_loci (sync.rs:73-97; the first is 1, the last is P).
+ * cov: L x n (the reference stores the transpose, coverages[(pool, locus)], sync.rs:1129-1152).
+ * ============================================================================================ */
+/* chromosomes by id (only equality is used).  head/tail: room for l entries.  Returns the number of windows. */
+int64_t orc_define_sliding_windows(const int32_t *chr, const uint64_t *pos, int64_t l, uint64_t window_size_bp,
+                                   uint64_t window_slide_size_bp, uint64_t min_loci_per_window, int64_t *out_head,
+                                   int64_t *out_tail) {
+    if (l <= 0) return 0;
+    int64_t *idx_head = (int64_t *)malloc(sizeof(int64_t) * (l + 1) * 2);
+    int64_t *idx_tail = idx_head + (l + 1);
+    uint64_t *cov = (uint64_t *)malloc(sizeof(uint64_t) * (l + 1));
+    int64_t nw = 1;
+    idx_head[0] = 0; idx_tail[0] = 0; cov[0] = 1;
+    int marker_next_window_head = 0;
+    int64_t idx_next_head = 0, i = 1;
+    while (i < l) {
+        const int32_t chr_head = chr[idx_head[nw - 1]];
+        const uint64_t pos_head = pos[idx_head[nw - 1]];
+        if ((chr[i] != chr_head) | (pos[i] > (pos_head + window_size_bp))) {
+            i = marker_next_window_head ? idx_next_head : i; /* :331-335 */
+            if (cov[nw - 1] >= min_loci_per_window) {
+                idx_head[nw] = i; idx_tail[nw] = i; cov[nw] = 1; nw++;
+            } else { /* ditch the ending window: its slot becomes the next window's start; its tail stays (:350-357) */
+                idx_head[nw - 1] = i; cov[nw - 1] = 1;
+            }
+            marker_next_window_head = 0;
+        } else {
+            idx_tail[nw - 1] = i;
+            cov[nw - 1] += 1;
+            if ((marker_next_window_head == 0) & (pos[i] >= (pos_head + window_slide_size_bp))) {
+                marker_next_window_head = 1;
+                idx_next_head = i;
+            }
+        }
+        i += 1;
+    }
+    /* remove redundant tails (:380-391) */
+    int64_t no = 0;
+    out_head[no] = idx_head[0]; out_tail[no] = idx_tail[0]; no++;
+    for (int64_t w = 1; w < nw; w++)
+        if (idx_tail[w] != out_tail[no - 1]) { out_head[no] = idx_head[w]; out_tail[no] = idx_tail[w]; no++; }
+    free(idx_head); free(cov);
+    return no;
+}
+
+/* the per-locus guard of fst (:66): |sum over pools of (sum over alleles) - n| <= eps, in ndarray's summation orders */
+static int popgen_locus_sums_to_one(const double *Xt, int64_t ld, int n, int64_t c0, int64_t c1) {
+    double *rs = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) rs[i] = 0.0;
+    for (int i = 0; i < n; i++) { /* sum_axis(Axis(1)): row.sum() of a contiguous lane of < 8 alleles = left to right */
+        double *tmp = (double *)malloc(sizeof(double) * (c1 - c0));
+        for (int64_t c = c0; c < c1; c++) tmp[c - c0] = Xt[c * ld + i];
+        rs[i] = orc_ndarray_sum(tmp, c1 - c0);
+        free(tmp);
+    }
+    double tot = orc_ndarray_sum(rs, n);
+    free(rs);
+    return fabs(tot - (double)n) <= ORC_EPS;
+}
+
+/* fst_mean n x n; fst_win n_windows x (n*n) (may be NULL with n_windows 0).  Returns 0, or -1 when the reference's
+ * assert (:66) fails at some locus. */
+int orc_fst(const double *Xt, int64_t P, int n, int64_t ld, const int64_t *loci_idx, int64_t L, const double *cov,
+            const int64_t *win_head, const int64_t *win_tail, int64_t n_windows, double *fst_mean, double *fst_win) {
+    (void)P;
+    double *f = (double *)malloc(sizeof(double) * (size_t)L * n * n);
+    for (int64_t i = 0; i < L; i++) {
+        const int64_t c0 = loci_idx[i], c1 = loci_idx[i + 1];
+        if (!popgen_locus_sums_to_one(Xt, ld, n, c0, c1)) { free(f); return -1; }
+        for (int j = 0; j < n; j++)
+            for (int k = 0; k < n; k++) {
+                const double nj = cov[i * n + j], nk = cov[i * n + k];
+                double sj = 0.0, sk = 0.0, q2 = 0.0;
+                for (int64_t c = c0; c < c1; c++) sj = sj + Xt[c * ld + j] * Xt[c * ld + j];
+                for (int64_t c = c0; c < c1; c++) sk = sk + Xt[c * ld + k] * Xt[c * ld + k];
+                for (int64_t c = c0; c < c1; c++) q2 = q2 + (Xt[c * ld + j] * Xt[c * ld + k]);
+                const double q1_j = (sj * (nj / (nj - 1.00 + ORC_EPS))) + (1.00 - (nj / (nj - 1.00 + ORC_EPS)));
+                const double q1_k = (sk * (nk / (nk - 1.00 + ORC_EPS))) + (1.00 - (nk / (nk - 1.00 + ORC_EPS)));
+                const double fu = (0.5 * (q1_j + q1_k) - q2) / (1.00 - q2 + ORC_EPS);
+                f[((size_t)i * n + j) * n + k] = fu < 0.0 ? 0.0 : (fu > 1.0 ? 1.0 : fu); /* NaN passes through */
+            }
+    }
+    for (int j = 0; j < n * n; j++) { /* mean_axis(Axis(0)): left to right from zero */
+        double s = 0.0;
+        for (int64_t i = 0; i < L; i++) s = s + f[(size_t)i * n * n + j];
+        fst_mean[j] = s / (double)L;
+    }
+    for (int64_t w = 0; w < n_windows; w++)
+        for (int j = 0; j < n * n; j++) {
+            double s = 0.0;
+            for (int64_t i = win_head[w]; i <= win_tail[w]; i++) s = s + f[(size_t)i * n * n + j];
+            fst_win[(size_t)w * n * n + j] = s / (double)(win_tail[w] + 1 - win_head[w]);
+        }
+    free(f);
+    return 0;
+}
+
+/* pi_win n_windows x n, pi_mean n (mean across windows, pi.rs:133) */
+int orc_theta_pi(const double *Xt, int64_t P, int n, int64_t ld, const int64_t *loci_idx, int64_t L, const double *cov,
+                 const int64_t *win_head, const int64_t *win_tail, int64_t n_windows, double *pi_win, double *pi_mean) {
+    (void)P;
+    double *pi = (double *)malloc(sizeof(double) * (size_t)L * n);
+    for (int64_t i = 0; i < L; i++)
+        for (int j = 0; j < n; j++) {
+            const double nj = cov[i * n + j];
+            double sj = 0.0;
+            for (int64_t c = loci_idx[i]; c < loci_idx[i + 1]; c++) sj = sj + Xt[c * ld + j] * Xt[c * ld + j];
+            pi[(size_t)i * n + j] = fabs((sj * (nj / (nj - 1.00 + ORC_EPS))) - (nj / (nj - 1.00 + ORC_EPS)));
+        }
+    for (int64_t w = 0; w < n_windows; w++)
+        for (int j = 0; j < n; j++) {
+            double s = 0.0;
+            for (int64_t i = win_head[w]; i <= win_tail[w]; i++) s = s + pi[(size_t)i * n + j];
+            pi_win[(size_t)w * n + j] = s / (double)(win_tail[w] + 1 - win_head[w]);
+        }
+    for (int j = 0; j < n; j++) {
+        double s = 0.0;
+        for (int64_t w = 0; w < n_windows; w++) s = s + pi_win[(size_t)w * n + j];
+        pi_mean[j] = s / (double)n_windows;
+    }
+    free(pi);
+    return 0;
+}
+
+/* ============================================================================================
  * base/pileup.rs: String::lparse -> PileupLine (:11-155), PileupLine::filter (:239-337),
  * to_counts (:160-214), pileup_to_sync (:340-371).  Literal restatement, one line at a time.
  * Return: length of the sync line written to out (> 0), 0 = the reference returns None (locus

@@ -151,6 +151,13 @@ void orc_expand_and_contract(const double *b_hat, const double *b_proxy, int64_t
 /* error_index (gp/penalise.rs:359-426) and the ridge-like lambda path with explicit folds (:461-669) */
 void orc_error_index(const double *Xt, int64_t P, int n, int64_t ld, const double *b, int k,
                      const double *Y, const int64_t *idx_val, int n_val, double *err_out);
+int64_t orc_define_sliding_windows(const int32_t *chr, const uint64_t *pos, int64_t l, uint64_t window_size_bp,
+                                   uint64_t window_slide_size_bp, uint64_t min_loci_per_window, int64_t *out_head,
+                                   int64_t *out_tail);
+int orc_fst(const double *Xt, int64_t P, int n, int64_t ld, const int64_t *loci_idx, int64_t L, const double *cov,
+            const int64_t *win_head, const int64_t *win_tail, int64_t n_windows, double *fst_mean, double *fst_win);
+int orc_theta_pi(const double *Xt, int64_t P, int n, int64_t ld, const int64_t *loci_idx, int64_t L, const double *cov,
+                 const int64_t *win_head, const int64_t *win_tail, int64_t n_windows, double *pi_win, double *pi_mean);
 int orc_gp_proxy(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k, const int64_t *row_idx,
                  int nr, double *b, int n_threads);
 int orc_penalised_path_general(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k,

@@ -28,6 +28,7 @@ class PgFilter(C.Structure):
 
 
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_u64 = C.c_uint64
 _pi, _pd, _pi64 = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64)
 _pf = C.POINTER(PgFilter)
 _batch = [_vp, _vp, _i64, _i, _vp, _pf, _vp, _i, _vp, _vp, _vp, _vp, _vp]
@@ -61,6 +62,10 @@ SIGNATURES = {
     "pg_gp_ridge_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _i, _i, _d, _d, _vp, _vp, _vp]),
     "pg_gp_penalised_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _i, _i, _d, _i, _d, _vp, _vp, _vp, _vp]),
     "pg_gp_proxy_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _vp]),
+    "pg_load_emit_cov_dev": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "pg_host_sliding_windows": (_i64, [_vp, _vp, _i64, _u64, _u64, _u64, _vp, _vp]),
+    "pg_pi_dev": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "pg_fst_dev": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "pg_gp_predict_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp]),
     "pg_host_sym_eig": (_i, [_vp, _i, _vp, _vp]),
     "pg_host_sym_eig_top": (_i, [_vp, _i, _i, _vp, _vp]),

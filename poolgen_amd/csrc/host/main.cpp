@@ -39,6 +39,7 @@ struct Args {
     std::vector<int> phen_value_col{2};
     int k_folds = 10, n_reps = 3; // genomic_prediction_cross_validation (main.rs:104-109)
     uint64_t seed = 42;           // ... and the seed of its folds (an extension: the reference's folds are unrepeatable)
+    uint64_t window_size_bp = 100, window_slide_size_bp = 50, min_loci_per_window = 10; // fst / heterozygosity (main.rs:110-118)
 };
 
 static double parse_valid_freq(const std::string &v, const std::string &flag) { // helpers.rs:93-100
@@ -89,6 +90,9 @@ static Args parse_args(int argc, char **argv) {
         else if (k == "--k-folds") a.k_folds = std::stoi(val());
         else if (k == "--n-reps") a.n_reps = std::stoi(val());
         else if (k == "--seed") a.seed = std::stoull(val());
+        else if (k == "--window-size-bp") a.window_size_bp = std::stoull(val());
+        else if (k == "--window-slide-size-bp") a.window_slide_size_bp = std::stoull(val());
+        else if (k == "--min-loci-per-window") a.min_loci_per_window = std::stoull(val());
         else if (k.rfind("-", 0) == 0) throw std::runtime_error("unknown flag " + k);
         else pos.push_back(k);
     }
@@ -337,16 +341,103 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
     return 0;
 }
 
+// fst (popgen/fst.rs:10-261) and heterozygosity = pi (popgen/pi.rs:115-190) on the loaded matrix: loci and windows on
+// the host (count_loci, define_sliding_windows), the per-locus arithmetic and the means on the GPU, the files as written
+// by the reference.
+static int run_popgen(const Args &a, bool is_fst, Ctx &gpu, const double *G_dev, const double *cov_dev, int64_t p, int n,
+                      int64_t ld, const std::vector<std::string> &lab_chr, const std::vector<uint64_t> &lab_pos,
+                      const std::vector<std::string> &pool_names, Lap &lap) {
+    // count_loci (sync.rs:73-97) without the intercept entry: column starts, and each locus' coordinates
+    std::vector<int64_t> locus_col;
+    std::vector<int32_t> chr_id;
+    std::vector<uint64_t> loc_pos;
+    std::vector<std::string> loc_chr;
+    for (int64_t c = 0; c < p; ++c)
+        if (c == 0 || lab_chr[c] != lab_chr[c + 1] || lab_pos[c] != lab_pos[c + 1]) { // labels carry the intercept at [0]
+            locus_col.push_back(c);
+            if (!loc_chr.empty() && loc_chr.back() == lab_chr[c + 1]) chr_id.push_back(chr_id.back());
+            else chr_id.push_back(chr_id.empty() ? 0 : chr_id.back() + 1);
+            loc_chr.push_back(lab_chr[c + 1]);
+            loc_pos.push_back(lab_pos[c + 1]);
+        }
+    locus_col.push_back(p);
+    const int64_t L = (int64_t)loc_pos.size();
+    std::vector<int64_t> wh(L), wt(L);
+    const int64_t nw = pg_host_sliding_windows(chr_id.data(), loc_pos.data(), L, a.window_size_bp, a.window_slide_size_bp,
+                                               a.min_loci_per_window, wh.data(), wt.data());
+    wh.resize(nw); wt.resize(nw);
+    const std::string win = std::to_string(a.window_size_bp);
+    const std::string time = unix_time_string();
+    if (!is_fst) {
+        std::string out = a.output;
+        if (out.empty()) out = basename_no_ext(a.fname) + "-pi-" + win + "_bp_windows-" + time + ".csv"; // pi.rs:135-159
+        std::vector<double> pw((size_t)nw * n), pm(n);
+        gpu.ok(pg_pi_dev(gpu.c, G_dev, cov_dev, p, n, ld, locus_col.data(), L, wh.data(), wt.data(), nw, pw.data(), pm.data()),
+               "heterozygosity");
+        lap("pi on the GPU");
+        FILE *fo = create_new(out);
+        std::string line = "Pool,Mean_across_windows";
+        for (int64_t w = 0; w < nw; ++w)
+            line += ",Window-" + loc_chr[wh[w]] + "_" + std::to_string(loc_pos[wh[w]]) + "_" + std::to_string(loc_pos[wt[w]]);
+        fputs((line + "\n").c_str(), fo);
+        for (int i = 0; i < n; ++i) {
+            line = pool_names[i] + "," + rust_display(pm[i]);
+            for (int64_t w = 0; w < nw; ++w) line += "," + roundup_own(pw[(size_t)w * n + i], 8);
+            fputs((line + "\n").c_str(), fo);
+        }
+        fclose(fo);
+        lap("write CSV");
+        std::cout << out << "\n";
+        return 0;
+    }
+    std::string out = a.output, out_win;
+    if (out.empty()) { // fst.rs:93-131
+        out = basename_no_ext(a.fname) + "-fst-averaged_across_genome-" + time + ".csv";
+        out_win = basename_no_ext(a.fname) + "-fst-" + win + "_bp_windows-" + time + ".csv";
+    } else
+        out_win = basename_no_ext(out) + "-fst-" + win + "_bp_windows.csv";
+    const size_t nn = (size_t)n * n;
+    std::vector<double> mean(nn), fw((size_t)nw * nn);
+    gpu.ok(pg_fst_dev(gpu.c, G_dev, cov_dev, p, n, ld, locus_col.data(), L, wh.data(), wt.data(), nw, mean.data(), fw.data()), "fst");
+    lap("fst on the GPU");
+    FILE *fo = create_new(out);
+    std::string line;
+    for (int i = 0; i < n; ++i) line += "," + pool_names[i];
+    fputs((line + "\n").c_str(), fo);
+    for (int i = 0; i < n; ++i) {
+        line = pool_names[i];
+        for (int j = 0; j < n; ++j) line += "," + roundup_own(mean[(size_t)i * n + j], 8);
+        fputs((line + "\n").c_str(), fo);
+    }
+    fclose(fo);
+    if (nw <= 0) // fst.rs:180, after the genome-wide file has been written
+        throw std::runtime_error("There were no windows defined. Please check the sync file, the window size, slide size, and the minimum number of loci per window.");
+    fo = create_new(out_win);
+    line = "chr,pos_ini,pos_fin";
+    for (int j = 0; j < n; ++j)
+        for (int k2 = 0; k2 < n; ++k2) line += "," + pool_names[j] + "_vs_" + pool_names[k2];
+    fputs((line + "\n").c_str(), fo);
+    write_rows_parallel(fo, nw, a.n_threads, [&](int64_t w, std::string &text) {
+        text += loc_chr[wh[w]] + "," + std::to_string(loc_pos[wh[w]]) + "," + std::to_string(loc_pos[wt[w]]);
+        for (size_t q = 0; q < nn; ++q) text += "," + rust_display(fw[(size_t)w * nn + q]);
+        text += "\n";
+    });
+    fclose(fo);
+    lap("write CSV");
+    std::cout << out << " and " << out_win << "\n"; // main.rs:441
+    return 0;
+}
+
 static int run(int argc, char **argv) {
     const Args a = parse_args(argc, argv);
     Lap lap;
     const std::map<std::string, int> known{{"chisq_test", 0}, {"pearson_corr", 1}, {"ols_iter", 2},
                                            {"ols_iter_with_kinship", 3}, {"pileup2sync", 4},
-                                           {"genomic_prediction_cross_validation", 5}};
+                                           {"genomic_prediction_cross_validation", 5}, {"fst", 6}, {"heterozygosity", 7}};
     if (!known.count(a.analysis))
         throw std::runtime_error("Invalid analysis utility for this build: `" + a.analysis +
                                  "` (available: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship, "
-                                 "genomic_prediction_cross_validation)");
+                                 "genomic_prediction_cross_validation, fst, heterozygosity)");
     if (a.generate_plots || a.sig_only)
         throw std::runtime_error("--generate-plots / --output-sig-snps-only call the reference's python scripts and are out of scope here");
     Phen ph = parse_phen(a.phen_fname, a.phen_delim, a.phen_name_col, a.phen_pool_size_col, a.phen_value_col);
@@ -512,7 +603,8 @@ static int run(int argc, char **argv) {
         const int c = sb.chrom(x).compare(sb.chrom(y));
         return c != 0 ? c < 0 : sb.pos[x] < sb.pos[y];
     });
-    const std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
+    std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
+    if (mode >= 6) { keep.resize(n); std::iota(keep.begin(), keep.end(), 0); } // fst / heterozygosity use every pool (main.rs:427-455)
     if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
     const int n2 = (int)keep.size();
     const int64_t ld = n2 + (n2 & 1);
@@ -528,16 +620,20 @@ static int run(int argc, char **argv) {
     hip_ok(hipMemcpy(counts_dev, sb.counts, sb.counts_bytes(), hipMemcpyHostToDevice), "H2D counts");
     hip_ok(hipMemcpy(order_dev, order.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice), "H2D order");
     int64_t p = 0;
-    gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, L, n, ph.pool_sizes.data(), &flt, a.keep_p_minus_1 ? 1 : 0, order_dev, &p),
-           "load");
+    const bool kpm1 = mode == 7 ? false : a.keep_p_minus_1; // heterozygosity: "we need all alleles in each locus" (main.rs:445)
+    gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, L, n, ph.pool_sizes.data(), &flt, kpm1 ? 1 : 0, order_dev, &p), "load");
     if (p <= 0) throw std::runtime_error("no loci passed the filters");
-    double *G_dev = nullptr, *out_dev = nullptr;
+    double *G_dev = nullptr, *out_dev = nullptr, *cov_dev = nullptr;
     int64_t *col_locus_dev = nullptr;
     int32_t *col_allele_dev = nullptr;
     hip_ok(hipMalloc((void **)&G_dev, sizeof(double) * (size_t)p * ld), "device memory for the genotype matrix");
     hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * p), "device memory");
     hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * p), "device memory");
-    gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G_dev, ld, col_locus_dev, col_allele_dev), "load");
+    if (mode >= 6) {
+        hip_ok(hipMalloc((void **)&cov_dev, sizeof(double) * (size_t)p * ld), "device memory for the coverages");
+        gpu.ok(pg_load_emit_cov_dev(gpu.c, pool_map.data(), n2, G_dev, ld, col_locus_dev, col_allele_dev, cov_dev), "load");
+    } else
+        gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G_dev, ld, col_locus_dev, col_allele_dev), "load");
     lap("sort + H2D + GPU loader");
     hip_ok(hipFree(counts_dev), "free");
     hip_ok(hipFree(order_dev), "free");
@@ -555,6 +651,12 @@ static int run(int argc, char **argv) {
     }
     std::vector<double> Y;
     for (int i : keep) for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]);
+    if (mode >= 6) {
+        (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
+        const int rc = run_popgen(a, mode == 6, gpu, G_dev, cov_dev, p, n2, ld, lab_chr, lab_pos, ph.pool_names, lap);
+        (void)hipFree(G_dev); (void)hipFree(cov_dev);
+        return rc;
+    }
     if (mode == 5) { // genomic_prediction_cross_validation (main.rs:397-426)
         CvLabels labels{lab_chr, lab_al, lab_pos};
         CvArgs ca;

@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_load_emit(const uint32_t *__restrict__ 
                                                    const int64_t *__restrict__ blockoff, int64_t L, int n, int pshift,
                                                    int kpm1, const int32_t *__restrict__ pool_map, int n_out,
                                                    double *__restrict__ G, int64_t ld, int64_t *__restrict__ col_locus,
-                                                   int32_t *__restrict__ col_allele) {
+                                                   int32_t *__restrict__ col_allele, double *__restrict__ cov) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t oi = gid / n;
     if (oi >= L) return;
@@ -1310,10 +1310,13 @@ __global__ __launch_bounds__(256) void k_load_emit(const uint32_t *__restrict__ 
         const double f = (rs == 0.0) ? NAN : (double)cv / rs; // sync.rs:176-183
         double *row = G + (size_t)(off + r) * ld;
         if (po >= 0) row[po] = f;
+        if (cov && po >= 0) cov[(size_t)(off + r) * ld + po] = rs; // the pool's depth over the surviving alleles (sync.rs:1142-1152)
         if (pool == 0) {
             col_locus[off + r] = l;
             col_allele[off + r] = al;
             for (int64_t q = n_out; q < ld; ++q) row[q] = 0.0; // padding columns of the locus-major layout
+            if (cov)
+                for (int64_t q = n_out; q < ld; ++q) cov[(size_t)(off + r) * ld + q] = 0.0;
         }
     }
 }
@@ -1410,7 +1413,7 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
 }
 
 int load_emit(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld, int64_t *col_locus_dev,
-              int32_t *col_allele_dev) {
+              int32_t *col_allele_dev, double *cov_dev) {
     if (!ctx->load_valid) return pg_fail(ctx, PG_ERR_STATE, "load_emit: call pg_load_plan_dev first (and nothing else in between)");
     PG_CHECK(ctx, G_dev && col_locus_dev && col_allele_dev, "load_emit: null pointer");
     const int n = ctx->load_n;
@@ -1432,7 +1435,7 @@ int load_emit(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, in
                        reinterpret_cast<const int32_t *>(ws + ctx->load_off_flags), ctx->load_order,
                        reinterpret_cast<const int32_t *>(ws + ctx->load_off_local),
                        reinterpret_cast<const int64_t *>(ws + ctx->load_off_blockoff), ctx->load_L, n, ctx->load_pshift,
-                       ctx->load_kpm1, pmap_dev, n_out, G_dev, ld, col_locus_dev, col_allele_dev);
+                       ctx->load_kpm1, pmap_dev, n_out, G_dev, ld, col_locus_dev, col_allele_dev, cov_dev);
     PG_HIP(ctx, hipGetLastError());
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // pool_map is the caller's
     return PG_OK;
@@ -1503,5 +1506,11 @@ extern "C" int pg_load_plan_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t
 extern "C" int pg_load_emit_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,
                                 int64_t *col_locus_dev, int32_t *col_allele_dev) {
     if (!ctx) return PG_ERR_INVALID;
-    return load_emit(ctx, pool_map, n_out, G_dev, ld, col_locus_dev, col_allele_dev);
+    return load_emit(ctx, pool_map, n_out, G_dev, ld, col_locus_dev, col_allele_dev, nullptr);
+}
+
+extern "C" int pg_load_emit_cov_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,
+                                    int64_t *col_locus_dev, int32_t *col_allele_dev, double *cov_dev) {
+    if (!ctx) return PG_ERR_INVALID;
+    return load_emit(ctx, pool_map, n_out, G_dev, ld, col_locus_dev, col_allele_dev, cov_dev);
 }

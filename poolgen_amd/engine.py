@@ -207,10 +207,11 @@ class Engine:
         return n_out, ids, chi2, pv
 
     def load_frequencies(self, counts, pool_sizes, flt: Filter, keep_p_minus_1: bool = False, order=None,
-                         pool_keep=None, ld: int | None = None):
+                         pool_keep=None, ld: int | None = None, coverages: bool = False):
         """The reference loader (base/sync.rs:972-1180) on a counts batch in HBM: filter, frequencies over the
         surviving alleles, optionally drop the major allele; one column of G per surviving allele.  Returns
-        (G [p x ld], col_locus [p], col_allele [p]); `pool_keep` (bool per pool) selects the rows written."""
+        (G [p x ld], col_locus [p], col_allele [p]); `pool_keep` (bool per pool) selects the rows written.
+        coverages=True appends cov [p x ld]: per column row the pools' depths over the locus' surviving alleles."""
         L, n, _ = counts.shape
         ps = _host_f64(pool_sizes)
         dev = counts.device
@@ -232,10 +233,52 @@ class Engine:
         G = torch.empty((p.value, ld), dtype=torch.float64, device=dev)
         col_locus = torch.empty(p.value, dtype=torch.int64, device=dev)
         col_allele = torch.empty(p.value, dtype=torch.int32, device=dev)
+        if coverages:
+            cov = torch.empty((p.value, ld), dtype=torch.float64, device=dev)
+            self._check(self._lib.pg_load_emit_cov_dev(self._ctx, pmap.ctypes.data if pmap is not None else None, n_out,
+                                                       G.data_ptr(), ld, col_locus.data_ptr(), col_allele.data_ptr(),
+                                                       cov.data_ptr()), "pg_load_emit_cov_dev")
+            return G, col_locus, col_allele, cov
         self._check(self._lib.pg_load_emit_dev(self._ctx, pmap.ctypes.data if pmap is not None else None, n_out,
                                                G.data_ptr(), ld, col_locus.data_ptr(), col_allele.data_ptr()),
                     "pg_load_emit_dev")
         return G, col_locus, col_allele
+
+    # ---- popgen -------------------------------------------------------------------------------
+    def sliding_windows(self, chrom_ids, pos, window_size_bp: int, window_slide_size_bp: int, min_loci_per_window: int):
+        """define_sliding_windows (base/helpers.rs:294-403) -> (head, tail) inclusive locus index ranges."""
+        ch = np.ascontiguousarray(chrom_ids, dtype=np.int32)
+        po = np.ascontiguousarray(pos, dtype=np.uint64)
+        head = np.empty(max(len(ch), 1), dtype=np.int64); tail = np.empty(max(len(ch), 1), dtype=np.int64)
+        nw = self._lib.pg_host_sliding_windows(ch.ctypes.data, po.ctypes.data, len(ch), int(window_size_bp),
+                                               int(window_slide_size_bp), int(min_loci_per_window), head.ctypes.data,
+                                               tail.ctypes.data)
+        return head[:nw].copy(), tail[:nw].copy()
+
+    def _popgen_args(self, G, cov, locus_col, win_head, win_tail, n):
+        p, ld, n = self._g_dims(G, n)
+        assert cov.shape == G.shape
+        lc = np.ascontiguousarray(locus_col, dtype=np.int64)
+        wh = np.ascontiguousarray(win_head, dtype=np.int64); wt = np.ascontiguousarray(win_tail, dtype=np.int64)
+        return p, ld, n, lc, wh, wt
+
+    def theta_pi(self, G, cov, locus_col, win_head, win_tail, n: int | None = None):
+        """popgen::theta_pi (popgen/pi.rs:10-113): (pi per window [n_windows x n], mean across windows [n])."""
+        p, ld, n, lc, wh, wt = self._popgen_args(G, cov, locus_col, win_head, win_tail, n)
+        win = np.empty((len(wh), n)); mean = np.empty(n)
+        self._check(self._lib.pg_pi_dev(self._ctx, self._dev(G, torch.float64), self._dev(cov, torch.float64), p, n, ld,
+                                        lc.ctypes.data, len(lc) - 1, wh.ctypes.data, wt.ctypes.data, len(wh),
+                                        win.ctypes.data, mean.ctypes.data), "pg_pi_dev")
+        return win, mean
+
+    def fst(self, G, cov, locus_col, win_head, win_tail, n: int | None = None):
+        """popgen::fst (popgen/fst.rs:10-115, :158-200): (genome-wide mean [n x n], per window [n_windows x n*n])."""
+        p, ld, n, lc, wh, wt = self._popgen_args(G, cov, locus_col, win_head, win_tail, n)
+        mean = np.empty((n, n)); win = np.empty((len(wh), n * n))
+        self._check(self._lib.pg_fst_dev(self._ctx, self._dev(G, torch.float64), self._dev(cov, torch.float64), p, n, ld,
+                                         lc.ctypes.data, len(lc) - 1, wh.ctypes.data, wt.ctypes.data, len(wh),
+                                         mean.ctypes.data, win.ctypes.data), "pg_fst_dev")
+        return mean, win
 
     # ---- genomic prediction -------------------------------------------------------------------
     def gp_xxt(self, G: torch.Tensor, n: int | None = None) -> torch.Tensor:

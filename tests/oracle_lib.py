@@ -71,6 +71,10 @@ class Oracle:
         lib.orc_penalised_lambda_path.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i, i, d, d, vp, vp, vp, i]
         lib.orc_penalised_path_general.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i, i, d, i, d, vp, vp, vp, vp, i]
         lib.orc_gp_proxy.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i]
+        lib.orc_define_sliding_windows.restype = i64
+        lib.orc_define_sliding_windows.argtypes = [vp, vp, i64, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp]
+        lib.orc_fst.argtypes = [vp, i64, i, i64, vp, i64, vp, vp, vp, i64, vp, vp]
+        lib.orc_theta_pi.argtypes = [vp, i64, i, i64, vp, i64, vp, vp, vp, i64, vp, vp]
 
     # ---- small conveniences -------------------------------------------------------------
     @staticmethod
@@ -288,6 +292,52 @@ class Oracle:
         b = np.empty((P, Y.shape[1]))
         self.lib.orc_gp_proxy(Xt.ctypes.data, P, n, ld, Y.ctypes.data, Y.shape[1], ri.ctypes.data, len(ri), b.ctypes.data, threads)
         return b
+
+    # ---- popgen ----------------------------------------------------------------------------
+    def sliding_windows(self, chrom, pos, window_size_bp, window_slide_size_bp, min_loci_per_window):
+        """define_sliding_windows (helpers.rs:294-403); chrom: any hashables"""
+        ids = {}
+        ch = np.array([ids.setdefault(c, len(ids)) for c in chrom], dtype=np.int32)
+        po = np.ascontiguousarray(pos, dtype=np.uint64)
+        l = len(ch)
+        head = np.empty(max(l, 1), dtype=np.int64); tail = np.empty(max(l, 1), dtype=np.int64)
+        nw = self.lib.orc_define_sliding_windows(ch.ctypes.data, po.ctypes.data, l, window_size_bp, window_slide_size_bp,
+                                                 min_loci_per_window, head.ctypes.data, tail.ctypes.data)
+        return head[:nw].copy(), tail[:nw].copy()
+
+    @staticmethod
+    def count_loci(chrom, pos):
+        """count_loci (sync.rs:73-97) on the labels WITH the leading intercept entry"""
+        idx, lc, lp = [], [], []
+        for i in range(1, len(chrom)):
+            if chrom[i - 1] != chrom[i] or pos[i - 1] != pos[i]:
+                idx.append(i); lc.append(chrom[i]); lp.append(pos[i])
+        idx.append(len(chrom)); lc.append(chrom[-1]); lp.append(pos[-1])
+        return idx, lc, lp
+
+    def fst(self, Xt, loci_idx, cov, win_head, win_tail, n=None):
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        P, ld = Xt.shape
+        n = ld if n is None else n
+        li = np.ascontiguousarray(loci_idx, dtype=np.int64); L = len(li) - 1
+        cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(L, n)
+        wh = np.ascontiguousarray(win_head, dtype=np.int64); wt = np.ascontiguousarray(win_tail, dtype=np.int64)
+        mean = np.empty((n, n)); win = np.empty((len(wh), n * n))
+        rc = self.lib.orc_fst(Xt.ctypes.data, P, n, ld, li.ctypes.data, L, cov.ctypes.data, wh.ctypes.data, wt.ctypes.data,
+                              len(wh), mean.ctypes.data, win.ctypes.data)
+        return rc, mean, win
+
+    def theta_pi(self, Xt, loci_idx, cov, win_head, win_tail, n=None):
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        P, ld = Xt.shape
+        n = ld if n is None else n
+        li = np.ascontiguousarray(loci_idx, dtype=np.int64); L = len(li) - 1
+        cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(L, n)
+        wh = np.ascontiguousarray(win_head, dtype=np.int64); wt = np.ascontiguousarray(win_tail, dtype=np.int64)
+        win = np.empty((len(wh), n)); mean = np.empty(n)
+        self.lib.orc_theta_pi(Xt.ctypes.data, P, n, ld, li.ctypes.data, L, cov.ctypes.data, wh.ctypes.data, wt.ctypes.data,
+                              len(wh), win.ctypes.data, mean.ctypes.data)
+        return win, mean
 
     def expand_and_contract(self, b, bp, alpha, lam):
         b = np.ascontiguousarray(b, dtype=np.float64); bp = np.ascontiguousarray(bp, dtype=np.float64)

@@ -114,3 +114,29 @@ def test_host_top_eigenvectors_match_lapack(native):
         assert np.allclose(ev, w, rtol=0, atol=1e-12 * abs(w[0]))
         assert np.allclose(V.T @ V, np.eye(m), atol=1e-9)
         assert np.max(np.abs(A @ V - V * ev[:m])) <= 1e-10 * abs(w[0])
+
+
+def test_host_sliding_windows_match_reference_literals_and_oracle(native, oracle):
+    """define_sliding_windows (base/helpers.rs:294-403): the reference's two literal cases (:541-583), then random
+    chromosomes / positions / window parameters against the oracle's restatement."""
+    import json
+    lit = json.loads((ROOT / "tests" / "golden" / "reference_literals.json").read_text())["popgen"]["windows"]
+
+    def run(chrom, pos, w, s, m):
+        ids = {}
+        ch = np.array([ids.setdefault(c, len(ids)) for c in chrom], dtype=np.int32)
+        po = np.ascontiguousarray(pos, dtype=np.uint64)
+        head = np.empty(len(ch), dtype=np.int64); tail = np.empty(len(ch), dtype=np.int64)
+        nw = native.pg_host_sliding_windows(ch.ctypes.data, po.ctypes.data, len(ch), w, s, m, head.ctypes.data, tail.ctypes.data)
+        return head[:nw].tolist(), tail[:nw].tolist()
+
+    for c in lit:
+        assert run(c["chr"], c["pos"], c["window_size_bp"], c["window_slide_size_bp"], c["min_loci_per_window"]) == (c["head"], c["tail"])
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        l = int(rng.integers(1, 400))
+        chrom = np.sort(rng.integers(0, int(rng.integers(1, 6)), size=l)).tolist()
+        pos = np.concatenate([np.sort(rng.integers(1, int(rng.integers(50, 5000)), size=chrom.count(c))) for c in sorted(set(chrom))]).tolist()
+        w, s, m = int(rng.integers(1, 500)), int(rng.integers(1, 300)), int(rng.integers(1, 6))
+        h, t = oracle.sliding_windows(chrom, pos, w, s, m)
+        assert run(chrom, pos, w, s, m) == (h.tolist(), t.tolist())

@@ -220,3 +220,44 @@ def test_pileup_reference_literal(oracle):
     assert oracle.pileup_to_sync("c\tx\tA\t1\t.\tJ", [1.0])[0] == -1
     assert oracle.pileup_to_sync("c\t1\tA\t2\t.\tJ", [1.0])[0] == -4
     assert oracle.pileup_to_sync("c\t1\tA\t1\t.+xa\tJ", [1.0])[0] == -5
+
+
+def _popgen_case(oracle, key):
+    g = LIT["popgen"]
+    x = np.array(g[key]["x_pool_by_column"])
+    idx, lc, lp = oracle.count_loci(g["labels"]["chromosome"], g["labels"]["position"])
+    cov = np.array(g["coverages_pool_by_locus"]).T                   # oracle: locus x pool
+    wh, wt = oracle.sliding_windows(lc[:-1], lp[:-1], g[key]["window_size_bp"], g[key]["window_slide_size_bp"],
+                                    g[key]["min_loci_per_window"])
+    return x.T.copy(), idx, cov, wh, wt
+
+
+def test_sliding_windows_golden(oracle):
+    for c in LIT["popgen"]["windows"]:                               # helpers.rs:541-583
+        h, t = oracle.sliding_windows(c["chr"], c["pos"], c["window_size_bp"], c["window_slide_size_bp"], c["min_loci_per_window"])
+        assert h.tolist() == c["head"] and t.tolist() == c["tail"]
+
+
+def test_fst_golden(oracle):
+    Xt, idx, cov, wh, wt = _popgen_case(oracle, "fst")               # popgen/fst.rs:262-356
+    rc, mean, win = oracle.fst(Xt, idx, cov, wh, wt)
+    assert rc == 0
+    e = LIT["popgen"]["fst"]["expect"]
+    printed = np.array([[float(oracle.round_own(v, 8)) for v in row] for row in mean])   # as written to the file (:146-155)
+    assert np.all(np.diag(printed) == e["diag"])
+    assert printed[0, 1] == e["pop1_2"] and printed[1, 0] == e["pop2_1"]
+    assert printed[3, 4] == e["pop4_5"] and printed[4, 3] == e["pop5_4"]
+    assert abs(printed[0, 2] - e["pop1_3_about"]) < e["about_tol"] and abs(printed[2, 1] - e["pop3_2_about"]) < e["about_tol"]
+    assert win.shape == (2, 25) and np.array_equal(win.reshape(2, 5, 5), win.reshape(2, 5, 5).transpose(0, 2, 1))
+    # frequencies that do not sum to one trip the reference's assert (:66)
+    bad = Xt.copy(); bad[1, 0] = 0.9
+    assert oracle.fst(bad, idx, cov, wh, wt)[0] == -1
+
+
+def test_pi_golden(oracle):
+    Xt, idx, cov, wh, wt = _popgen_case(oracle, "pi")                # popgen/pi.rs:202-297
+    win, mean = oracle.theta_pi(Xt, idx, cov, wh, wt)
+    e = LIT["popgen"]["pi"]["expect_round4"]
+    assert oracle.round_own(win[0, 1], 4) == e["pop2_window1"] and oracle.round_own(win[1, 1], 4) == e["pop2_window2"]
+    assert oracle.round_own(win[0, 4], 4) == e["pop5_window1"] and oracle.round_own(win[1, 4], 4) == e["pop5_window2"]
+    assert np.allclose(mean, win.mean(axis=0), rtol=1e-15)
