@@ -10,7 +10,7 @@
 //                    ndarray's summation orders
 //   k_range_mean_1d  thread = (window, pool): mean of pi over the window's loci, summed left to right as
 //                    mean_axis does (pi.rs:84-95)
-//   k_fst_ranges     block = (range of loci, 16 x 16 tile of pool pairs, upper triangle), thread = pair: per locus
+//   k_fst_ranges     block = (range of loci, 32 x 32 tile of pool pairs, upper triangle), thread = 4 x 4 pairs: per locus
 //                    q2 = sum_a g_j g_k, the clamped ratio (fst.rs:76-91), summed left to right over the range;
 //                    ranges are the windows (divide: per-window means, :178-199) or equal chunks of the genome
 //                    (partial sums, then k_chunk_reduce -> the genome-wide mean, :145)
@@ -87,9 +87,13 @@ __global__ __launch_bounds__(256) void k_range_mean_1d(const double *__restrict_
     out[gid] = s / (double)(tail[w] + 1 - head[w]);
 }
 
-constexpr int FT = 16; // pair tile edge
+constexpr int FT = 8;       // threads per tile edge (one wave per block)
+constexpr int FR = 4;       // pools per thread along each edge: a block covers a (FT*FR)^2 = 32 x 32 tile of pairs
+constexpr int FTILE = FT * FR;
 
-// grid.x = range, grid.y = upper-triangular tile id; out[range][n][n] (both triangles written)
+// grid.x = range, grid.y = upper-triangular tile id; out[range][n][n] (both triangles written).  Every thread keeps a
+// 4 x 4 block of pairs: 8 frequencies and 8 q1 per allele row serve 16 ratios, and the 16 independent divisions
+// overlap each other's latency.  Per pair the operations and their order are those of the reference (fst.rs:69-91).
 __global__ __launch_bounds__(FT * FT) void k_fst_ranges(const double *__restrict__ G, const double *__restrict__ Q1,
                                                         const int64_t *__restrict__ locus_col,
                                                         const int64_t *__restrict__ head, const int64_t *__restrict__ tail,
@@ -98,25 +102,61 @@ __global__ __launch_bounds__(FT * FT) void k_fst_ranges(const double *__restrict
     int t = blockIdx.y, tj = 0;
     while (t >= ntile - tj) { t -= ntile - tj; ++tj; }
     const int tk = tj + t;
-    const int j = tj * FT + (threadIdx.x / FT), k = tk * FT + (threadIdx.x % FT);
-    const bool on = j < n && k < n && j <= k;
+    const int j0 = tj * FTILE + (threadIdx.x / FT) * FR, k0 = tk * FTILE + (threadIdx.x % FT) * FR;
+    int jj[FR], kk[FR];
+#pragma unroll
+    for (int u = 0; u < FR; ++u) { jj[u] = min(j0 + u, n - 1); kk[u] = min(k0 + u, n - 1); }
     const int64_t w = blockIdx.x;
     const int64_t l0 = head[w], l1 = tail[w];
-    const int jj = on ? j : 0, kk = on ? k : 0;
-    double s = 0.0;
+    double s[FR][FR];
+#pragma unroll
+    for (int u = 0; u < FR; ++u)
+#pragma unroll
+        for (int v = 0; v < FR; ++v) s[u][v] = 0.0;
+    int64_t c0 = locus_col[l0];
     for (int64_t l = l0; l <= l1; ++l) {
-        const int64_t c0 = locus_col[l], c1 = locus_col[l + 1];
-        double q2 = 0.0;
-        for (int64_t c = c0; c < c1; ++c) q2 = q2 + (G[c * ld + jj] * G[c * ld + kk]);
-        const double q1j = Q1[l * n + jj], q1k = Q1[l * n + kk];
-        const double fu = (0.5 * (q1j + q1k) - q2) / (1.00 - q2 + POP_EPS);
-        s = s + (fu < 0.0 ? 0.0 : (fu > 1.0 ? 1.0 : fu)); // NaN passes through, as in the reference
+        const int64_t c1 = locus_col[l + 1];
+        double q2[FR][FR];
+#pragma unroll
+        for (int u = 0; u < FR; ++u)
+#pragma unroll
+            for (int v = 0; v < FR; ++v) q2[u][v] = 0.0;
+        for (int64_t c = c0; c < c1; ++c) {
+            const double *row = G + c * ld;
+            double gj[FR], gk[FR];
+#pragma unroll
+            for (int u = 0; u < FR; ++u) { gj[u] = row[jj[u]]; gk[u] = row[kk[u]]; }
+#pragma unroll
+            for (int u = 0; u < FR; ++u)
+#pragma unroll
+                for (int v = 0; v < FR; ++v) q2[u][v] = q2[u][v] + (gj[u] * gk[v]);
+        }
+        const double *qrow = Q1 + l * n;
+        double q1j[FR], q1k[FR];
+#pragma unroll
+        for (int u = 0; u < FR; ++u) { q1j[u] = qrow[jj[u]]; q1k[u] = qrow[kk[u]]; }
+#pragma unroll
+        for (int u = 0; u < FR; ++u)
+#pragma unroll
+            for (int v = 0; v < FR; ++v) {
+                const double fu = (0.5 * (q1j[u] + q1k[v]) - q2[u][v]) / (1.00 - q2[u][v] + POP_EPS);
+                s[u][v] = s[u][v] + (fu < 0.0 ? 0.0 : (fu > 1.0 ? 1.0 : fu)); // NaN passes through, as in the reference
+            }
+        c0 = c1;
     }
-    if (!on) return;
-    if (divide) s = s / (double)(l1 + 1 - l0);
+    const double den = (double)(l1 + 1 - l0);
     double *o = out + (size_t)w * n * n;
-    o[(size_t)j * n + k] = s;
-    o[(size_t)k * n + j] = s; // every term is symmetric in (j, k): x*y, q1_j + q1_k
+#pragma unroll
+    for (int u = 0; u < FR; ++u)
+#pragma unroll
+        for (int v = 0; v < FR; ++v) {
+            const int j = j0 + u, k = k0 + v;
+            if (j < n && k < n && j <= k) {
+                const double r = divide ? s[u][v] / den : s[u][v];
+                o[(size_t)j * n + k] = r;
+                o[(size_t)k * n + j] = r; // every term is symmetric in (j, k): x*y, q1_j + q1_k
+            }
+        }
 }
 
 __global__ __launch_bounds__(256) void k_chunk_reduce(const double *__restrict__ part, int64_t nchunks, int64_t nn,
@@ -244,7 +284,7 @@ extern "C" int pg_fst_dev(pg_ctx *ctx, const double *G_dev, const double *cov_de
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (hbad) // the reference's assert!((g.sum_axis(Axis(1)).sum() - n as f64).abs() <= f64::EPSILON) (fst.rs:66)
         return pg_fail(ctx, PG_ERR_INVALID, "fst: the allele frequencies of a locus do not sum up to one in every pool");
-    const int ntile = (n + FT - 1) / FT;
+    const int ntile = (n + FTILE - 1) / FTILE;
     const int ntri = ntile * (ntile + 1) / 2;
     hipLaunchKernelGGL(k_fst_ranges, dim3((unsigned)nchunks, ntri), dim3(FT * FT), 0, ctx->stream, G_dev, q1.as<double>(),
                        lc.as<int64_t>(), chh.as<int64_t>(), cht.as<int64_t>(), n, ld, ntile, 0, part.as<double>());
