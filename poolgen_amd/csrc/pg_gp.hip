@@ -66,7 +66,7 @@ __global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k,
 
 // For every lambda_i: subtracted/added masses of the penalised set and the norm masses of the
 // de-penalised set, split by the sign of b (:296-326).  part: [block][4][GP_LMAX].
-__global__ void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, int row0, PathParams P,
+__global__ __launch_bounds__(256) void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, int row0, PathParams P,
                                Proxy X, double *__restrict__ part) {
     double sp[GP_LMAX], ap[GP_LMAX], sd[GP_LMAX], ad[GP_LMAX];
 #pragma unroll
@@ -80,14 +80,12 @@ __global__ void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k
         const double pen_pos = pos ? (((b - nrm) < 0.0) ? b : nrm) : 0.0;       // :298-305
         const double pen_neg = pos ? 0.0 : (((b + nrm) > 0.0) ? fabs(b) : nrm); // :306-313
 #pragma unroll
-        for (int i = 0; i < GP_LMAX; ++i) {
-            if (i < P.L) {
-                const bool pen = sc < P.lambda[i];
-                sp[i] += pen ? pen_pos : 0.0;
-                ap[i] += pen ? pen_neg : 0.0;
-                sd[i] += (!pen && pos) ? nrm : 0.0;
-                ad[i] += (!pen && !pos) ? nrm : 0.0;
-            }
+        for (int i = 0; i < GP_LMAX; ++i) { // entries beyond P.L (lambda = 0) are never read: no guard, no branches
+            const bool pen = sc < P.lambda[i];
+            sp[i] += pen ? pen_pos : 0.0;
+            ap[i] += pen ? pen_neg : 0.0;
+            sd[i] += (!pen && pos) ? nrm : 0.0;
+            ad[i] += (!pen && !pos) ? nrm : 0.0;
         }
     }
     __shared__ double sm[4][4 * GP_LMAX];
@@ -182,36 +180,80 @@ __global__ __launch_bounds__(256) void k_gp_predict(const double *__restrict__ G
 // pass over G serves all of them).  The contracted coefficient is formed on the fly from the fold's masses
 // (the very arithmetic of gp_contract); partials and their reduction are laid out as in k_gp_predict.
 struct FoldMasses { double nmax, sub_scale[GP_LMAX], add_scale[GP_LMAX]; };
+// The contracted coefficient depends on (locus, fold, lambda) only, not on the pool: a block first forms them for a
+// chunk of loci in LDS (chunk x folds x lambdas), then every thread (= pool) accumulates yhat from ITS fold's entries:
+// per (locus, pool) one load of G, L LDS operands and L FMAs instead of the whole expand_and_contract arithmetic.
+// LP = the path length rounded up to even, a compile-time constant: entries beyond L carry lambda = 0 and zero masses
+// (harmless finite numbers nobody reads), so neither loop needs a guard -- guarded, every FMA became a branch with its
+// own LDS round trip.
+template <int LP>
 __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
                                                           int C, const int32_t *__restrict__ colof,
                                                           const FoldMasses *__restrict__ FM, PathParams P0, Proxy X,
                                                           int64_t p, int n, int64_t ld, int64_t loci_per_block,
-                                                          double *__restrict__ part) {
+                                                          int chunk, double *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double Bs[]; // [chunk][F][LP]
+    const int k = X.k, j = X.j;
+    const int F = C / k;
     const int pool = blockIdx.y * 256 + threadIdx.x;
     const int64_t l0 = (int64_t)blockIdx.x * loci_per_block;
     const int64_t l1 = min(p, l0 + loci_per_block);
-    double acc[GP_LMAX];
+    double acc[LP];
 #pragma unroll
-    for (int i = 0; i < GP_LMAX; ++i) acc[i] = 0.0;
+    for (int i = 0; i < LP; ++i) acc[i] = 0.0;
     const bool inr = pool < n;
     const int c = inr ? colof[pool] : -1;
     const bool on = c >= 0;
-    const FoldMasses fm = FM[on ? c : 0];
+    const int f = on ? c / k : 0;
     const double *gp = G + (inr ? pool : 0);
-    const double *bp = bf + (on ? c : 0);
-    if (on) {
-        for (int64_t l = l0; l < l1; ++l) {
-            const double g = gp[l * ld];
-            const double b = bp[l * C];
+    for (int64_t lc = l0; lc < l1; lc += chunk) {
+        const int m = (int)min((int64_t)chunk, l1 - lc);
+        __syncthreads();
+        for (int item = threadIdx.x; item < m * F; item += 256) {
+            const int ll = item / F, ff = item - ll * F;
+            const int64_t l = lc + ll;
+            const int col = ff * k + j;
+            const FoldMasses fm = FM[col];
+            const double b = bf[l * C + col];
             const double nrm = gp_norm(b, P0.alpha);
             const double sc = (X.b ? gp_norm(X.b[(l + 1) * X.k + X.j], P0.alpha) : nrm) / fm.nmax;
             const bool pos = b >= 0.0;
             const double pen = pos ? (((b - nrm) < 0.0) ? 0.0 : b - nrm) : (((b + nrm) > 0.0) ? 0.0 : b + nrm);
+            double *o = Bs + (size_t)(ll * F + ff) * LP;
 #pragma unroll
-            for (int i = 0; i < GP_LMAX; ++i) {
-                if (i < P0.L) {
-                    const double dep = pos ? b + fm.sub_scale[i] * nrm : b - fm.add_scale[i] * nrm;
-                    acc[i] = fma(g, (sc < P0.lambda[i]) ? pen : dep, acc[i]);
+            for (int i = 0; i < LP; ++i) {
+                const double dep = pos ? b + fm.sub_scale[i] * nrm : b - fm.add_scale[i] * nrm;
+                o[i] = (sc < P0.lambda[i]) ? pen : dep;
+            }
+        }
+        __syncthreads();
+        if (on) {
+            const double *bs = Bs + (size_t)f * LP;
+            constexpr int U = 8; // loads of G in flight per thread
+            int ll = 0;
+            for (; ll + U <= m; ll += U) {
+                double g[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[u] = gp[(lc + ll + u) * ld];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double *q = bs + (size_t)(ll + u) * F * LP;
+#pragma unroll
+                    for (int i = 0; i < LP; i += 2) {
+                        const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
+                        acc[i] = fma(g[u], b2.x, acc[i]);
+                        acc[i + 1] = fma(g[u], b2.y, acc[i + 1]);
+                    }
+                }
+            }
+            for (; ll < m; ++ll) {
+                const double g = gp[(lc + ll) * ld];
+                const double *q = bs + (size_t)ll * F * LP;
+#pragma unroll
+                for (int i = 0; i < LP; i += 2) {
+                    const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
+                    acc[i] = fma(g, b2.x, acc[i]);
+                    acc[i + 1] = fma(g, b2.y, acc[i + 1]);
                 }
             }
         }
@@ -219,7 +261,7 @@ __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restri
     if (inr) {
         double *o = part + ((size_t)blockIdx.x * n + pool) * GP_LMAX;
 #pragma unroll
-        for (int i = 0; i < GP_LMAX; ++i) o[i] = acc[i];
+        for (int i = 0; i < GP_LMAX; ++i) o[i] = i < LP ? acc[i] : 0.0;
     }
 }
 
@@ -467,8 +509,21 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                         for (int64_t pool : va[f]) colof[pool] = f * k + j;
                 if (hipMemcpyAsync(colof_dev, colof.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                     return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
-                hipLaunchKernelGGL(k_gp_predict_folds, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, bf, C, colof_dev,
-                                   fm_dev, P0, Proxy{proxy_dev, k, j}, p, n, ld, lpb, W.part);
+                const int LP = (P0.L + 1) & ~1;
+                const int chunk = std::max(4, std::min(64, (int)(49152 / (sizeof(double) * n_folds * LP))));
+                const dim3 grid(nblk2, (n + 255) / 256);
+                const size_t lds = sizeof(double) * chunk * n_folds * LP;
+                const Proxy X{proxy_dev, k, j};
+#define PG_PREDICT_FOLDS(LPV)                                                                                              \
+    case LPV:                                                                                                              \
+        hipLaunchKernelGGL(k_gp_predict_folds<LPV>, grid, dim3(256), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, p, n, \
+                           ld, lpb, chunk, W.part);                                                                        \
+        break;
+                switch (LP) {
+                    PG_PREDICT_FOLDS(2) PG_PREDICT_FOLDS(4) PG_PREDICT_FOLDS(6) PG_PREDICT_FOLDS(8) PG_PREDICT_FOLDS(10)
+                    PG_PREDICT_FOLDS(12) PG_PREDICT_FOLDS(14) PG_PREDICT_FOLDS(16)
+                }
+#undef PG_PREDICT_FOLDS
                 hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
                 if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                     hipStreamSynchronize(ctx->stream) != hipSuccess)
