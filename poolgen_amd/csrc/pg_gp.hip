@@ -187,15 +187,16 @@ struct FoldMasses { double nmax, sub_scale[GP_LMAX], add_scale[GP_LMAX]; };
 // (harmless finite numbers nobody reads), so neither loop needs a guard -- guarded, every FMA became a branch with its
 // own LDS round trip.
 template <int LP>
-__global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
+__global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
                                                           int C, const int32_t *__restrict__ colof,
                                                           const FoldMasses *__restrict__ FM, PathParams P0, Proxy X,
                                                           int64_t p, int n, int64_t ld, int64_t loci_per_block,
                                                           int chunk, double *__restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) double Bs[]; // [chunk][F][LP]
+    extern __shared__ __attribute__((aligned(16))) double Bs[]; // [chunk][F][LS]
+    constexpr int LS = LP + 2; // fold stride: 8 * LS bytes put the folds' 16-byte reads of one lambda pair on distinct banks
     const int k = X.k, j = X.j;
     const int F = C / k;
-    const int pool = blockIdx.y * 256 + threadIdx.x;
+    const int pool = blockIdx.y * blockDim.x + threadIdx.x; // 256 or 512 threads: one block spans up to 512 pools
     const int64_t l0 = (int64_t)blockIdx.x * loci_per_block;
     const int64_t l1 = min(p, l0 + loci_per_block);
     double acc[LP];
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restri
     for (int64_t lc = l0; lc < l1; lc += chunk) {
         const int m = (int)min((int64_t)chunk, l1 - lc);
         __syncthreads();
-        for (int item = threadIdx.x; item < m * F; item += 256) {
+        for (int item = threadIdx.x; item < m * F; item += blockDim.x) {
             const int ll = item / F, ff = item - ll * F;
             const int64_t l = lc + ll;
             const int col = ff * k + j;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restri
             const double sc = (X.b ? gp_norm(X.b[(l + 1) * X.k + X.j], P0.alpha) : nrm) / fm.nmax;
             const bool pos = b >= 0.0;
             const double pen = pos ? (((b - nrm) < 0.0) ? 0.0 : b - nrm) : (((b + nrm) > 0.0) ? 0.0 : b + nrm);
-            double *o = Bs + (size_t)(ll * F + ff) * LP;
+            double *o = Bs + (size_t)(ll * F + ff) * LS;
 #pragma unroll
             for (int i = 0; i < LP; ++i) {
                 const double dep = pos ? b + fm.sub_scale[i] * nrm : b - fm.add_scale[i] * nrm;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restri
         }
         __syncthreads();
         if (on) {
-            const double *bs = Bs + (size_t)f * LP;
+            const double *bs = Bs + (size_t)f * LS;
             constexpr int U = 8; // loads of G in flight per thread
             int ll = 0;
             for (; ll + U <= m; ll += U) {
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restri
                 for (int u = 0; u < U; ++u) g[u] = gp[(lc + ll + u) * ld];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const double *q = bs + (size_t)(ll + u) * F * LP;
+                    const double *q = bs + (size_t)(ll + u) * F * LS;
 #pragma unroll
                     for (int i = 0; i < LP; i += 2) {
                         const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void k_gp_predict_folds(const double *__restri
             }
             for (; ll < m; ++ll) {
                 const double g = gp[(lc + ll) * ld];
-                const double *q = bs + (size_t)ll * F * LP;
+                const double *q = bs + (size_t)ll * F * LS;
 #pragma unroll
                 for (int i = 0; i < LP; i += 2) {
                     const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
@@ -510,13 +511,14 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 if (hipMemcpyAsync(colof_dev, colof.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                     return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
                 const int LP = (P0.L + 1) & ~1;
-                const int chunk = std::max(4, std::min(64, (int)(49152 / (sizeof(double) * n_folds * LP))));
-                const dim3 grid(nblk2, (n + 255) / 256);
-                const size_t lds = sizeof(double) * chunk * n_folds * LP;
+                const int chunk = std::max(4, std::min(64, (int)(49152 / (sizeof(double) * n_folds * (LP + 2)))));
+                const int bthreads = n > 256 ? 512 : 256; // the coefficient stage is shared by all waves of a block
+                const dim3 grid(nblk2, (n + bthreads - 1) / bthreads);
+                const size_t lds = sizeof(double) * chunk * n_folds * (LP + 2);
                 const Proxy X{proxy_dev, k, j};
 #define PG_PREDICT_FOLDS(LPV)                                                                                              \
     case LPV:                                                                                                              \
-        hipLaunchKernelGGL(k_gp_predict_folds<LPV>, grid, dim3(256), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, p, n, \
+        hipLaunchKernelGGL(k_gp_predict_folds<LPV>, grid, dim3(bthreads), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, p, n, \
                            ld, lpb, chunk, W.part);                                                                        \
         break;
                 switch (LP) {

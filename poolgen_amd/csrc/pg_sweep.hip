@@ -23,7 +23,9 @@
 // hardware overlaps one wave's loads with another wave's FMAs.
 #include "pg_common.h"
 #include "pg_stats_device.h"
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -204,6 +206,120 @@ __global__ __launch_bounds__(SW_THREADS) void k_gp_beta(const double *__restrict
         if (ntail)
             sweep_chunk<C, false, false>(G, W + (size_t)nfull * SW_CH * C, tile, l0, D.p, D.ld, nfull * SW_CH,
                                          ntail, lane, false, shift, s2, acc);
+        const int64_t l = l0 + lane;
+        if (l < D.p) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (c < D.k) out[l * D.k + c] = acc[c];
+        }
+    }
+}
+
+// The same pass for many coefficient columns and many pools (the folds of a CV repetition at n = 500: Z is 48 KB).
+// There the wave-uniform operands no longer fit the scalar data cache and every s_load of Z went to L2, serialising
+// the FMAs behind it (k_gp_beta<12>: 3.2 TB/s).  Here Z sits in LDS for the life of the block (uniform-address
+// ds_read_b128 = broadcast) and the global loads of chunk c + 1 are in flight while chunk c is consumed, so one wave per
+// SIMD is enough to keep HBM busy.
+template <bool FULL>
+__device__ __forceinline__ void gpb_load(const double *__restrict__ G, int64_t l0, int64_t p, int64_t ld, int pool0,
+                                         int npool, int lane, double2 (&v)[SW_NLD]) {
+    const int lr = lane / SW_LPR, piece = lane % SW_LPR;
+    int cofs = 2 * piece;
+    if (!FULL) {
+        const int last = (npool - 1) & ~1;
+        cofs = cofs < last ? cofs : last;
+    }
+#pragma unroll
+    for (int r = 0; r < SW_NLD; ++r) {
+        int64_t l = l0 + SW_RPI * r + lr;
+        l = l < p ? l : p - 1;
+        v[r] = *reinterpret_cast<const double2 *>(G + l * ld + pool0 + cofs);
+    }
+}
+template <bool FULL>
+__device__ __forceinline__ void gpb_store(double *tile, int npool, int lane, const double2 (&v)[SW_NLD]) {
+    const int lr = lane / SW_LPR, piece = lane % SW_LPR;
+    const bool col_ok = FULL || 2 * piece < npool, two = FULL || 2 * piece + 1 < npool;
+#pragma unroll
+    for (int r = 0; r < SW_NLD; ++r) {
+        double2 x = v[r];
+        x.x = col_ok ? x.x : 0.0;
+        x.y = two ? x.y : 0.0;
+        *reinterpret_cast<double2 *>(&tile[(SW_RPI * r + lr) * SW_PITCH + 2 * piece]) = x;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(SW_THREADS) void k_gp_beta_lds(const double *__restrict__ G, const double *__restrict__ W,
+                                                            double *__restrict__ out, const SweepDims D, int wdoubles) {
+    static_assert(C % 2 == 0, "even column count");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double *Ws = lds;
+    double *tile = lds + wdoubles + wave * SW_TILE;
+    for (int i = threadIdx.x; i < wdoubles; i += SW_THREADS) Ws[i] = W[i];
+    __syncthreads();
+    const int nfull = D.n / SW_CH;
+    const int ntail = D.n - nfull * SW_CH;
+    const int nch = nfull + (ntail ? 1 : 0);
+    const int64_t wstride = (int64_t)gridDim.x * SW_WAVES;
+    const double *row = tile + lane * SW_PITCH;
+    for (int64_t t = (int64_t)blockIdx.x * SW_WAVES + wave; t < D.ntiles; t += wstride) {
+        const int64_t l0 = t * 64;
+        double acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0;
+        double2 v[SW_NLD];
+        if (nfull) gpb_load<true>(G, l0, D.p, D.ld, 0, SW_CH, lane, v);
+        else gpb_load<false>(G, l0, D.p, D.ld, 0, ntail, lane, v);
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool full = ch < nfull;
+            if (full) gpb_store<true>(tile, SW_CH, lane, v);
+            else gpb_store<false>(tile, ntail, lane, v);
+            __builtin_amdgcn_wave_barrier();
+            if (ch + 1 < nch) { // next chunk's rows travel while this one is consumed
+                if (ch + 1 < nfull) gpb_load<true>(G, l0, D.p, D.ld, (ch + 1) * SW_CH, SW_CH, lane, v);
+                else gpb_load<false>(G, l0, D.p, D.ld, (ch + 1) * SW_CH, ntail, lane, v);
+            }
+            const double *wp = Ws + (size_t)ch * SW_CH * C;
+            const int np = full ? SW_CH : ((ntail + 1) & ~1); // the tail's odd column was stored as zero
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < SW_CH; i += 2) {
+                    const double2 g2 = *reinterpret_cast<const double2 *>(&row[i]);
+#pragma unroll
+                    for (int c = 0; c < C; c += 2) {
+                        const double2 wa = *reinterpret_cast<const double2 *>(&wp[i * C + c]);
+                        acc[c] = fma(g2.x, wa.x, acc[c]);
+                        acc[c + 1] = fma(g2.x, wa.y, acc[c + 1]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; c += 2) {
+                        const double2 wb = *reinterpret_cast<const double2 *>(&wp[(i + 1) * C + c]);
+                        acc[c] = fma(g2.y, wb.x, acc[c]);
+                        acc[c + 1] = fma(g2.y, wb.y, acc[c + 1]);
+                    }
+                }
+            } else {
+                for (int i = 0; i < np; i += 2) {
+                    const double2 g2 = *reinterpret_cast<const double2 *>(&row[i]);
+#pragma unroll
+                    for (int c = 0; c < C; c += 2) {
+                        const double2 wa = *reinterpret_cast<const double2 *>(&wp[i * C + c]);
+                        acc[c] = fma(g2.x, wa.x, acc[c]);
+                        acc[c + 1] = fma(g2.x, wa.y, acc[c + 1]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; c += 2) {
+                        const double2 wb = *reinterpret_cast<const double2 *>(&wp[(i + 1) * C + c]);
+                        acc[c] = fma(g2.y, wb.x, acc[c]);
+                        acc[c + 1] = fma(g2.y, wb.y, acc[c + 1]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         const int64_t l = l0 + lane;
         if (l < D.p) {
 #pragma unroll
@@ -576,6 +692,20 @@ static int launch_gp_beta(pg_ctx *ctx, const double *G, const double *W, double 
     return PG_OK;
 }
 
+template <int C>
+static int launch_gp_beta_lds(pg_ctx *ctx, const double *G, const double *W, double *out, const SweepDims &D, int wdoubles) {
+    const size_t shmem = ((size_t)wdoubles + (size_t)SW_WAVES * SW_TILE) * sizeof(double);
+    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gp_beta_lds<C>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const int64_t blocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
+    const int grid = (int)std::min<int64_t>(blocks, (int64_t)ctx->cus); // one block per CU: Z occupies most of its LDS
+    pg_prof_begin(ctx, PG_K_GP_BETA);
+    hipLaunchKernelGGL(k_gp_beta_lds<C>, dim3(grid), dim3(SW_THREADS), shmem, ctx->stream, G, W, out, D, wdoubles);
+    pg_prof_end(ctx);
+    PG_HIP(ctx, hipGetLastError());
+    return PG_OK;
+}
+
 // ---- internal pieces of gp::ols shared with the ridge path (pg_gp.hip) ---------------------------------
 // V (r x k) = pinv(A) Y_rows with A the principal sub-block `rows` of the full-data X X^T (n x n, host)
 int pg_gp_subset_solve(const double *xxt, int n, const double *Y, int k, const int64_t *rows, int r, double *V) {
@@ -614,6 +744,22 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     const int64_t cap = (int64_t)ctx->cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
     int rc;
+    // many columns x many pools: Z no longer fits the scalar cache -> the LDS-resident variant (see k_gp_beta_lds)
+    const int wdoubles = n_even * cols;
+    const size_t lds_need = ((size_t)wdoubles + (size_t)SW_WAVES * SW_TILE) * sizeof(double);
+    if (cols >= 6 && (cols % 2) == 0 && cols <= 24 && (size_t)wdoubles * sizeof(double) > 12288 && lds_need <= 150 * 1024 &&
+        !std::getenv("POOLGEN_GP_BETA_SCALAR")) {
+        switch (cols) {
+        case 6: rc = launch_gp_beta_lds<6>(ctx, G_dev, ctx->W_dev, out_dev, D, wdoubles); break;
+        case 8: rc = launch_gp_beta_lds<8>(ctx, G_dev, ctx->W_dev, out_dev, D, wdoubles); break;
+        case 12: rc = launch_gp_beta_lds<12>(ctx, G_dev, ctx->W_dev, out_dev, D, wdoubles); break;
+        case 16: rc = launch_gp_beta_lds<16>(ctx, G_dev, ctx->W_dev, out_dev, D, wdoubles); break;
+        default: rc = launch_gp_beta_lds<24>(ctx, G_dev, ctx->W_dev, out_dev, D, wdoubles); break;
+        }
+        if (rc) return rc;
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Z is stack-owned
+        return PG_OK;
+    }
     switch (cols) {
     case 2: rc = launch_gp_beta<2>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
     case 3: rc = launch_gp_beta<3>(ctx, G_dev, ctx->W_dev, out_dev, D, grid); break;
