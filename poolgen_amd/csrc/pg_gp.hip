@@ -20,7 +20,10 @@
 #include "pg_common.h"
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -211,11 +214,11 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
         const int m = (int)min((int64_t)chunk, l1 - lc);
         __syncthreads();
         for (int item = threadIdx.x; item < m * F; item += blockDim.x) {
-            const int ll = item / F, ff = item - ll * F;
+            const int ff = item / m, ll = item - ff * m; // bf is column-major: consecutive threads, consecutive loci
             const int64_t l = lc + ll;
             const int col = ff * k + j;
             const FoldMasses fm = FM[col];
-            const double b = bf[l * C + col];
+            const double b = bf[(size_t)col * p + l];
             const double nrm = gp_norm(b, P0.alpha);
             const double sc = (X.b ? gp_norm(X.b[(l + 1) * X.k + X.j], P0.alpha) : nrm) / fm.nmax;
             const bool pos = b >= 0.0;
@@ -367,6 +370,70 @@ int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int
 }
 
 
+// per column: out[c][q] = max or sum over the blocks' partials, in block order (what the host loop of ridge_path_params does)
+__global__ void k_gp_reduce_parts(const double *__restrict__ part, int ncols, int nb, int64_t col_stride, int elem_stride,
+                                  int use, int is_max, double *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // c * use + q
+    if (idx >= ncols * use) return;
+    const int c = idx / use, q = idx - c * use;
+    const double *src = part + (size_t)c * col_stride + q;
+    double r = 0.0;
+    for (int b = 0; b < nb; ++b) r = is_max ? fmax(r, src[(size_t)b * elem_stride]) : r + src[(size_t)b * elem_stride];
+    out[idx] = r;
+}
+
+// ridge_path_params for all columns of `cols_dev` (COLUMN-major, ncols x p: every column is one contiguous stream) at once: the columns' launches queue up behind
+// each other and the host synchronises twice instead of 2 * ncols times.  skip[c] != 0: column not in use.
+int ridge_path_params_cols(pg_ctx *ctx, const double *cols_dev, int64_t p, int ncols, int k, double alpha,
+                           const std::vector<double> &path, RidgeWork &W, const double *proxy_dev, const std::vector<int> &skip,
+                           std::vector<PathParams> &out) {
+    const int nb = 1024, width = 4 * GP_LMAX;
+    double *red = W.part + (size_t)ncols * nb * width; // room reserved by the caller
+    std::vector<double> h((size_t)ncols * width);
+    out.assign(ncols, PathParams{});
+    PG_HIP(ctx, hipMemsetAsync(W.part, 0, sizeof(double) * (size_t)ncols * nb * width, ctx->stream)); // skipped columns reduce to 0
+    for (int c = 0; c < ncols; ++c) {
+        if (skip[c]) continue;
+        const Proxy X{proxy_dev, k, c % k};
+        if (X.b) hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, X.b, p, X.k, X.j, 1, alpha, W.part + (size_t)c * nb * width);
+        else hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, cols_dev + (size_t)c * p, p, 1, 0, 0, alpha, W.part + (size_t)c * nb * width);
+    }
+    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream, W.part, ncols, nb, (int64_t)nb * width, 1,
+                       1, 1, red);
+    PG_HIP(ctx, hipGetLastError());
+    PG_HIP(ctx, hipMemcpyAsync(h.data(), red, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < ncols; ++c) {
+        PathParams &P = out[c];
+        std::memset(&P, 0, sizeof P);
+        P.alpha = alpha;
+        P.nmax = h[c];
+        P.L = (int)path.size();
+        for (int i = 0; i < P.L; ++i) P.lambda[i] = path[i];
+        if (skip[c]) continue;
+        hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, cols_dev + (size_t)c * p, p, 1, 0, 0, P, Proxy{proxy_dev, k, c % k},
+                           W.part + (size_t)c * nb * width);
+    }
+    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols * width + 255) / 256), dim3(256), 0, ctx->stream, W.part, ncols, nb,
+                       (int64_t)nb * width, width, width, 0, red);
+    PG_HIP(ctx, hipGetLastError());
+    PG_HIP(ctx, hipMemcpyAsync(h.data(), red, sizeof(double) * ncols * width, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < ncols; ++c) {
+        if (skip[c]) continue;
+        PathParams &P = out[c];
+        const double *q = &h[(size_t)c * width];
+        for (int i = 0; i < P.L; ++i) {
+            double sp = q[i], ap = q[GP_LMAX + i], sd = q[2 * GP_LMAX + i], ad = q[3 * GP_LMAX + i];
+            if ((sp > 0.0) & (sd == 0.0)) { ap -= sp; sp = 0.0; }      // "absence of available slots" (:329-335)
+            else if ((ap > 0.0) & (ad == 0.0)) { sp -= ap; ap = 0.0; }
+            P.sub_scale[i] = (sd != 0.0) ? sp / sd : 0.0;
+            P.add_scale[i] = (ad != 0.0) ? ap / ad : 0.0;
+        }
+    }
+    return PG_OK;
+}
+
 // The lambda path with k-fold cross-validation (:461-669) behind penalise_lasso_like / _ridge_like (alpha = 1 / 0, one
 // path), penalise_glmnet (alpha < 0: the 2-D grid alpha x lambda over the same path values, :479-498) and the
 // *_with_iterative_proxy_norms models (proxy != nullptr, :540-553, :655-657).
@@ -403,7 +470,8 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
     const int64_t lpb = (p + nblk - 1) / nblk;
     const int nblk2 = (int)((p + lpb - 1) / lpb);
     RidgeWork W;
-    const size_t part_doubles = std::max<size_t>((size_t)1024 * 4 * GP_LMAX, (size_t)nblk2 * n * GP_LMAX);
+    const size_t part_doubles = std::max<size_t>((size_t)(n_folds * k + 1) * 1024 * 4 * GP_LMAX + (size_t)n_folds * k * 4 * GP_LMAX,
+                                                 (size_t)nblk2 * n * GP_LMAX);
     char *raw = nullptr;
     PG_HIP(ctx, hipMalloc((void **)&raw, sizeof(double) * (part_doubles + (size_t)p * GP_LMAX + (size_t)n * GP_LMAX)));
     W.part = reinterpret_cast<double *>(raw);
@@ -444,7 +512,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
     // every pool with the coefficients of the fold that holds it out.  (Fallback below: one pair of passes per fold.)
     const int C = n_folds * k;
     const bool fused = C <= PG_MAX_SWEEP_COLS && !std::getenv("POOLGEN_RIDGE_PER_FOLD");
-    double *bf = nullptr;       // p x C slopes of the folds' fits
+    double *bf = nullptr;       // C x p (column-major) slopes of the folds' fits
     FoldMasses *fm_dev = nullptr;
     int32_t *colof_dev = nullptr;
     if (fused) {
@@ -456,53 +524,87 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         }
     }
     auto fail2 = [&](int rc) { (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev); return fail(rc); };
-    for (int rep = 0; rep < n_reps && fused; ++rep) {
-        std::vector<std::vector<int64_t>> tr(n_folds), va(n_folds);
-        for (int i = 0; i < n_rows; ++i) {
-            const int f = fold_of[(size_t)rep * n_rows + i];
-            for (int g = 0; g < n_folds; ++g) (g == f ? va[g] : tr[g]).push_back(row_idx[i]);
-        }
-        // host: pinv(X X^T) y of every fold (independent: one thread each), scattered into Z (n x C)
-        std::vector<double> Z((size_t)n * C, 0.0), b0c(C, 0.0);
-        std::vector<int> bad(n_folds, 0);
-        {
-            std::vector<std::thread> th;
-            for (int f = 0; f < n_folds; ++f) {
-                if (va[f].empty() || tr[f].empty()) continue; // an empty fold leaves NaN, as an empty slice would
-                th.emplace_back([&, f] {
-                    const int r = (int)tr[f].size();
-                    std::vector<double> V((size_t)r * k);
-                    if (pg_gp_subset_solve(xxt.data(), n, Y, k, tr[f].data(), r, V.data()) != 0) { bad[f] = 1; return; }
-                    for (int a2 = 0; a2 < r; ++a2)
-                        for (int j = 0; j < k; ++j) {
-                            Z[(size_t)tr[f][a2] * C + f * k + j] = V[(size_t)a2 * k + j];
-                            b0c[f * k + j] += V[(size_t)a2 * k + j];
-                        }
-                });
+    // POOLGEN_GP_TIMING=1: host-side phase times of the repetitions on stderr
+    const bool timing = std::getenv("POOLGEN_GP_TIMING") != nullptr;
+    double t_solve = 0, t_beta = 0, t_params = 0, t_predict = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // The folds' host solves (pinv(X X^T) y on every training block) need nothing from the GPU but X X^T: a background
+    // thread works through the repetitions ahead of the device passes (one worker thread per fold inside).
+    struct RepSolve {
+        std::vector<std::vector<int64_t>> tr, va;
+        std::vector<double> Z, b0c;
+        bool bad = false;
+    };
+    std::vector<RepSolve> solves(fused ? n_reps : 0);
+    std::vector<std::promise<void>> ready(fused ? n_reps : 0);
+    std::thread solver;
+    if (fused)
+        solver = std::thread([&] {
+            for (int rep = 0; rep < n_reps; ++rep) {
+                RepSolve &R = solves[rep];
+                R.tr.assign(n_folds, {}); R.va.assign(n_folds, {});
+                for (int i = 0; i < n_rows; ++i) {
+                    const int f = fold_of[(size_t)rep * n_rows + i];
+                    for (int g = 0; g < n_folds; ++g) (g == f ? R.va[g] : R.tr[g]).push_back(row_idx[i]);
+                }
+                R.Z.assign((size_t)n * C, 0.0); R.b0c.assign(C, 0.0);
+                std::vector<int> badf(n_folds, 0);
+                std::vector<std::thread> th;
+                for (int f = 0; f < n_folds; ++f) {
+                    if (R.va[f].empty() || R.tr[f].empty()) continue; // an empty fold leaves NaN, as an empty slice would
+                    th.emplace_back([&, f] {
+                        const int r = (int)R.tr[f].size();
+                        std::vector<double> V((size_t)r * k);
+                        if (pg_gp_subset_solve(xxt.data(), n, Y, k, R.tr[f].data(), r, V.data()) != 0) { badf[f] = 1; return; }
+                        for (int a2 = 0; a2 < r; ++a2)
+                            for (int j = 0; j < k; ++j) {
+                                R.Z[(size_t)R.tr[f][a2] * C + f * k + j] = V[(size_t)a2 * k + j];
+                                R.b0c[f * k + j] += V[(size_t)a2 * k + j];
+                            }
+                    });
+                }
+                for (auto &x : th) x.join();
+                for (int f = 0; f < n_folds; ++f) R.bad = R.bad || badf[f];
+                ready[rep].set_value();
             }
-            for (auto &x : th) x.join();
-        }
-        for (int f = 0; f < n_folds; ++f)
-            if (bad[f]) return fail2(pg_fail(ctx, PG_ERR_INVALID, "gp_ridge: pinv failed"));
-        int rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Z.data(), C, bf); // :526 for every fold at once
+        });
+    struct Joiner { // every exit path waits for the solver before its captures go away
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{solver};
+    for (int rep = 0; rep < n_reps && fused; ++rep) {
+        double t0 = now();
+        ready[rep].get_future().wait();
+        RepSolve &R = solves[rep];
+        if (R.bad) return fail2(pg_fail(ctx, PG_ERR_INVALID, "gp_ridge: pinv failed"));
+        const std::vector<std::vector<int64_t>> &tr = R.tr, &va = R.va;
+        const std::vector<double> &Z = R.Z, &b0c = R.b0c;
+        t_solve += now() - t0; t0 = now();
+        int rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Z.data(), C, bf, 1); // :526 for every fold at once, column-major
         if (rc) return fail2(rc);
+        t_beta += now() - t0;
         for (int a = 0; a < A; ++a) {
+            t0 = now();
             // the redistribution masses of every (fold, trait) column
             std::vector<FoldMasses> fm(C);
             PathParams P0;
             std::memset(&P0, 0, sizeof P0);
+            std::vector<int> skip(C, 0);
             for (int f = 0; f < n_folds; ++f)
-                for (int j = 0; j < k; ++j) {
-                    if (va[f].empty() || tr[f].empty()) { std::memset(&fm[f * k + j], 0, sizeof(FoldMasses)); fm[f * k + j].nmax = 1.0; continue; }
-                    PathParams P;
-                    rc = ridge_path_params(ctx, bf, p, C, f * k + j, alpha_at(a), path, W, P, 0, Proxy{proxy_dev, k, j});
-                    if (rc) return fail2(rc);
-                    fm[f * k + j].nmax = P.nmax;
-                    for (int i = 0; i < GP_LMAX; ++i) { fm[f * k + j].sub_scale[i] = P.sub_scale[i]; fm[f * k + j].add_scale[i] = P.add_scale[i]; }
-                    P0 = P; // alpha, lambda[], L are the same for every column
-                }
+                for (int j = 0; j < k; ++j) skip[f * k + j] = va[f].empty() || tr[f].empty();
+            std::vector<PathParams> PP;
+            rc = ridge_path_params_cols(ctx, bf, p, C, k, alpha_at(a), path, W, proxy_dev, skip, PP);
+            if (rc) return fail2(rc);
+            for (int c = 0; c < C; ++c) {
+                if (skip[c]) { std::memset(&fm[c], 0, sizeof(FoldMasses)); fm[c].nmax = 1.0; continue; }
+                fm[c].nmax = PP[c].nmax;
+                for (int i = 0; i < GP_LMAX; ++i) { fm[c].sub_scale[i] = PP[c].sub_scale[i]; fm[c].add_scale[i] = PP[c].add_scale[i]; }
+            }
+            P0 = PP[0]; // alpha, lambda[], L are the same for every column
+            P0.nmax = 0.0;
             if (hipMemcpyAsync(fm_dev, fm.data(), sizeof(FoldMasses) * C, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                 return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
+            t_params += now() - t0; t0 = now();
             for (int j = 0; j < k; ++j) {
                 std::vector<int32_t> colof(n, -1);
                 for (int f = 0; f < n_folds; ++f)
@@ -533,8 +635,12 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 for (int f = 0; f < n_folds; ++f)
                     if (!va[f].empty() && !tr[f].empty()) score(rep, f, a, j, b0c[f * k + j], va[f]);
             }
+            t_predict += now() - t0;
         }
     }
+    if (timing)
+        std::fprintf(stderr, "gp path: fold solves %.1f ms, coefficient passes %.1f ms, masses %.1f ms, prediction + scores %.1f ms\n",
+                     1e3 * t_solve, 1e3 * t_beta, 1e3 * t_params, 1e3 * t_predict);
     (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev);
     for (int rep = 0; rep < n_reps && !fused; ++rep)
         for (int fold = 0; fold < n_folds; ++fold) {

@@ -49,6 +49,7 @@ struct SweepDims {
     int64_t p, ld;
     int64_t ntiles;
     int n, m1, k, tdf, ntcoef;
+    int colmajor; // k_gp_beta*: out is k x p instead of p x k
     double dfe; // n - P as f64 (ols.rs:103)
     double tau; // relative singularity threshold on s_gg / g'g
 };
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_gp_beta(const double *__restrict
         if (l < D.p) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                if (c < D.k) out[l * D.k + c] = acc[c];
+                if (c < D.k) out[D.colmajor ? (int64_t)c * D.p + l : l * D.k + c] = acc[c];
         }
     }
 }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_gp_beta_lds(const double *__rest
         if (l < D.p) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                if (c < D.k) out[l * D.k + c] = acc[c];
+                if (c < D.k) out[D.colmajor ? (int64_t)c * D.p + l : l * D.k + c] = acc[c];
         }
     }
 }
@@ -592,6 +593,7 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
     P.D.tdf = ctx->tcoef_df; P.D.ntcoef = ctx->tcoef_len;
     P.D.dfe = (double)n - (double)(ctx->st_m + 2);
     P.D.tau = 1e-12;
+    P.D.colmajor = 0;
     if (ctx->st_m == 0 && ctx->spec_valid && ctx->spec_G == G_dev && ctx->spec_p == p && ctx->spec_n == n &&
         ctx->spec_ld == ld && ctx->spec_k == ctx->st_k && ctx->ph_n == n && ctx->st_Y_matches_ph) {
         // m = 0: the kinship pass already formed the sums of the intercept-only fits from its read of G
@@ -719,7 +721,7 @@ int pg_gp_subset_solve(const double *xxt, int n, const double *Y, int k, const i
 
 // out (p x ncol, device) = G Z for a host Z (n x ncol row-major): the slopes of `ncol` fits in ONE pass over G
 int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Z_host, int ncol,
-                    double *out_dev) {
+                    double *out_dev, int colmajor) {
     const int cols = round_cols(ncol);
     if (cols < 0) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp: at most %d coefficient columns per pass", PG_MAX_SWEEP_COLS);
     const int n_even = (n + 1) & ~1;
@@ -739,7 +741,7 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     PG_HIP(ctx, hipMemcpyAsync(ctx->W_dev, Z.data(), zbytes, hipMemcpyHostToDevice, ctx->stream));
     SweepDims D;
     std::memset(&D, 0, sizeof D);
-    D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = ncol;
+    D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = ncol; D.colmajor = colmajor;
     int64_t blocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
     const int64_t cap = (int64_t)ctx->cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
