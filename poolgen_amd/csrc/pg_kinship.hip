@@ -16,6 +16,7 @@
 // of G.  Each workgroup finally writes its partial tiles to a slab; a second tiny kernel sums
 // the slabs in a fixed order (deterministic, no atomics) and mirrors the lower triangle.
 #include "pg_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -111,6 +112,9 @@ struct KinParams {
     int64_t loci_per_wg;
     double *slabs; // [gridDim.x][npad * npad]
     int n, T, npad, Tb, nb;
+    int merged; // nb >= 4: no workgroups for the diagonal blocks -- every off-diagonal pair (A, B) also takes 1/(nb-1) of
+                // the tiles of A x A and of B x B (64 + 12 + 12 of its 96 tile slots at Tb = 8 instead of 64, or 36 on a
+                // diagonal workgroup), and every pool column is staged nb - 1 times instead of nb
     // fused speculative intercept-only sums (FUSE kernels only)
     const double *ytil; // k x 256 centred phenotypes, zero padded
     double *spec;       // p x (2 + k)
@@ -130,9 +134,10 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     int bi = 0, bj = 0;
     {
         int q = blockIdx.y;
+        const int first = P.merged ? 1 : 0; // merged: pairs with bi < bj only
         for (bi = 0; bi < P.nb; ++bi) {
-            const int cnt = P.nb - bi;
-            if (q < cnt) { bj = bi + q; break; }
+            const int cnt = P.nb - bi - first;
+            if (q < cnt) { bj = bi + first + q; break; }
             q -= cnt;
         }
     }
@@ -151,7 +156,12 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     const int npr = npa + npb; // 16-byte pieces per staged locus row
 
     // ---- this wave's tiles ---------------------------------------------------------------
-    const int ntiles = diag ? Ta * (Ta + 1) / 2 : Ta * Tbb;
+    const int nrect = diag ? 0 : Ta * Tbb;
+    const int NA = Ta * (Ta + 1) / 2, NB = Tbb * (Tbb + 1) / 2, part = P.nb - 1;
+    const int rankA = bj - 1, rankB = bi; // position of the partner among the other blocks, in block order
+    const int cntA = P.merged ? (NA > rankA ? (NA - rankA + part - 1) / part : 0) : 0;
+    const int cntB = P.merged ? (NB > rankB ? (NB - rankB + part - 1) / part : 0) : 0;
+    const int ntiles = diag ? NA : nrect + cntA + cntB;
     // Every wave runs exactly KIN_TPW tile slots so that the k-loop is straight-line code; a slot
     // beyond the tile list recomputes tile 0 into an accumulator that is never stored.
     int acol[KIN_TPW], bcol[KIN_TPW], orow[KIN_TPW], ocol[KIN_TPW];
@@ -161,11 +171,18 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         const int t = wave + KIN_WAVES * u;
         int ti = 0, tj = 0;
         live[u] = t < ntiles;
+        int kind = diag ? 1 : 0; // 0: A x B, 1: inside A, 2: inside B
         if (t < ntiles) {
-            if (diag) {
-                int q = t;
-                for (ti = 0; ti < Ta; ++ti) {
-                    const int cnt = Ta - ti;
+            int q = t, Td = Ta;
+            if (!diag && t >= nrect) {
+                const bool inA = t - nrect < cntA;
+                kind = inA ? 1 : 2;
+                q = inA ? rankA + part * (t - nrect) : rankB + part * (t - nrect - cntA);
+                Td = inA ? Ta : Tbb;
+            }
+            if (kind) {
+                for (ti = 0; ti < Td; ++ti) {
+                    const int cnt = Td - ti;
                     if (q < cnt) { tj = ti + q; break; }
                     q -= cnt;
                 }
@@ -174,10 +191,10 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
                 tj = t - ti * Tbb;
             }
         }
-        acol[u] = 16 * ti;
-        bcol[u] = diag ? 16 * tj : colsA + 16 * tj;
-        orow[u] = a0 + 16 * ti;
-        ocol[u] = b0 + 16 * tj;
+        acol[u] = (kind == 2 ? colsA : 0) + 16 * ti;
+        bcol[u] = (kind == 1 ? 0 : colsA) + 16 * tj;
+        orow[u] = (kind == 2 ? b0 : a0) + 16 * ti;
+        ocol[u] = (kind == 1 ? a0 : b0) + 16 * tj;
     }
 
     // ---- staging assignment (constant over the stages) -------------------------------------
@@ -553,7 +570,8 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     P.npad = P.T * 16;
     if (P.T <= 13) { P.Tb = P.T; P.nb = 1; }
     else { P.Tb = 8; P.nb = (P.T + 7) / 8; }
-    const int npairs = P.nb * (P.nb + 1) / 2;
+    P.merged = (P.nb >= 4 && !std::getenv("POOLGEN_KIN_NO_MERGE")) ? 1 : 0; // 64 + 2 * ceil(36 / (nb - 1)) <= 96 slots
+    const int npairs = P.merged ? P.nb * (P.nb - 1) / 2 : P.nb * (P.nb + 1) / 2;
     int nslab = cus / npairs;
     if (nslab < 1) nslab = 1;
     const int64_t max_slabs = (p + KIN_KC - 1) / KIN_KC;
