@@ -335,3 +335,42 @@ def test_fused_and_two_pass_paths_agree_with_oracle(engine, oracle, p, n, k):
     b2, v2, p2 = engine.ols_sweep(G, k, n)
     assert m2 == 0
     assert torch.allclose(b2, beta, rtol=1e-9, atol=1e-12) and float((p2 - pv).abs().max()) < 1e-11
+
+
+def test_config4_full_size_properties(engine):
+    """BASELINE config 4 shape (500 pools x 5 M loci, ridge-like path with 10-fold CV): size-independent properties.
+    gp::ols interpolates its training pools (n < p: X b = y on the training rows, gp/ols.rs:245-246); lambda = 0 leaves
+    the fit untouched, so the error index of the first path entry equals the one of plain OLS predictions; the fused and
+    the per-fold route give the same error indices; the selected lambda is on the path; the penalised coefficients keep
+    the intercept and the signs (expand_and_contract never crosses zero, gp/penalise.rs:296-313)."""
+    from poolgen_amd import synth
+    n, p = 500, 5_000_000
+    G = synth.genotype_matrix(p, n, "cuda")
+    Y = synth.phenotypes(G[:100000], n, k=1)
+    rows = np.arange(n)
+    folds = np.stack([(rows + r) % 10 for r in range(2)]).astype(np.int32)
+    b_ols = engine.gp_ols(G, Y, rows, n=n)
+    yhat = engine.gp_predict(G, b_ols, n=n)
+    assert np.allclose(yhat, Y, atol=1e-6 * np.abs(Y).max())
+    beta, lam, perf = engine.gp_ridge(G, Y, rows, folds, 10, alpha=0.0, n=n)
+    assert perf.shape == (2, 10, 11, 1) and np.isfinite(perf).all() and lam[0] in [i / 10 for i in range(11)]
+    b, bo = beta.cpu().numpy()[:, 0], b_ols.cpu().numpy()[:, 0]
+    assert b[0] == bo[0]                                         # the intercept is never penalised (:356)
+    assert np.all(b[1:] * bo[1:] >= 0.0)
+    if lam[0] == 0.0:
+        assert np.array_equal(b, bo)
+    # lambda = 0: the held-out predictions are those of the fold's plain OLS fit
+    tr = rows[folds[0] != 3]; va = rows[folds[0] == 3]
+    yh = engine.gp_predict(G, engine.gp_ols(G, Y, tr, n=n), n=n)[va, 0]
+    yt = Y[va, 0]
+    rng_ = yt.max() - yt.min()
+    d = yt - yh
+    r = np.corrcoef(yt, yh)[0, 1]
+    idx = ((1 - abs(round(r * 1e7) / 1e7)) + np.abs(d).sum() / rng_ + (d * d).sum() / rng_ ** 2 + np.sqrt((d * d).sum() / rng_ ** 2) / rng_) / 4
+    assert abs(perf[0, 3, 0, 0] - idx) <= 1e-6 * max(1.0, abs(idx))
+    os.environ["POOLGEN_RIDGE_PER_FOLD"] = "1"
+    try:
+        beta2, lam2, perf2 = engine.gp_ridge(G, Y, rows, folds[:1], 10, alpha=0.0, n=n)
+    finally:
+        del os.environ["POOLGEN_RIDGE_PER_FOLD"]
+    assert np.allclose(perf2[0], perf[0], rtol=1e-7, atol=1e-10)

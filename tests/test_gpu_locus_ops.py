@@ -228,3 +228,48 @@ def test_loader_first_locus_reference_literal(engine, oracle):
     assert (rows[0][0], rows[0][1]) == (g["chromosome"], g["position"])
     assert "".join(AL[int(col_allele[c])] for c in first) == g["alleles"]
     assert G[first, :5].T.reshape(-1).tolist() == g["freq"]
+
+
+def test_config2_full_size_properties(engine, oracle):
+    """BASELINE config 2 shape (100 pools x 1 M loci from counts): size-independent properties of the three operators.
+    A locus' result depends on that locus only: processing the batch in another order permutes the results bit for bit
+    (all alignment classes, units, second-pass lists and compact records differ between the two runs); relabelling the
+    pools together with their sizes and phenotypes leaves chi-square untouched up to summation order; a sampled slice
+    agrees with the oracle."""
+    from poolgen_amd import synth
+    n, L = 100, 1_000_000
+    counts = synth.sync_counts(L, n, "cuda", seed=123)
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    third = (torch.rand(L, 1, generator=g, device="cuda") < 0.1).int()
+    counts[:, :, 2] = third * torch.randint(0, 9, (L, n), generator=g, device="cuda", dtype=torch.int32)
+    Y = synth.phenotypes(synth.genotype_matrix(64, n, "cuda", seed=7), n, k=1, seed=2)
+    ps = np.full(n, 20.0)
+    f, fo = flt_pair(oracle)
+    perm = torch.randperm(L, generator=g, device="cuda")
+    shuffled = counts[perm].contiguous()
+    def same(x, y):
+        return (x == y) | (torch.isnan(x) & torch.isnan(y)) if x.is_floating_point() else (x == y)
+
+    for run in (lambda c: engine.ols_iterate(c, ps, f, Y), lambda c: engine.correlation(c, ps, f, Y), lambda c: engine.chisq(c, ps, f)):
+        a = [x[perm] for x in run(counts)]
+        b = run(shuffled)
+        n_out = b[0]
+        assert bool((a[0] == n_out).all()) and int((n_out > 0).sum()) > 0.9 * L
+        for x, y in zip(a[1:], b[1:]):
+            if x.dim() == 1:                                   # chi-square statistic / p-value: one per emitted locus
+                used = n_out > 0
+            else:                                              # per emitted allele (x traits): entries beyond n_out are unspecified
+                used = torch.arange(x.shape[1], device="cuda")[None, :] < n_out[:, None]
+                if x.dim() == 3:
+                    used = used[:, :, None].expand_as(x)
+            assert bool(same(x, y)[used].all())
+    # chi-square under a relabelling of the pools
+    pp = torch.randperm(n, generator=g, device="cuda")
+    n1, i1, c1, p1 = engine.chisq(counts[:200_000].contiguous(), ps, f)
+    n2, i2, c2, p2 = engine.chisq(counts[:200_000][:, pp].contiguous(), ps, f)
+    assert bool((n1 == n2).all()) and torch.allclose(c1, c2, rtol=1e-10, atol=1e-12, equal_nan=True)
+    # a slice against the oracle
+    sl = slice(500_000, 500_000 + 512)
+    rows = counts[sl].cpu().numpy().astype(np.uint64)
+    res = engine.ols_iterate(counts, ps, f, Y)
+    check_stat_op(tuple(x[sl] for x in res), oracle.ols_iterate_locus, rows, Y, ps, fo, oracle=oracle)
