@@ -178,6 +178,17 @@ struct Lap {
     }
 };
 
+// The results are on disk and the file name is printed: end the process here.  Releasing tens of GB of device and pinned
+// memory buffer by buffer (destructors, hipFree, the HIP runtime's shutdown) took 0.3 s of a 1.4 s run; the driver
+// reclaims everything when the process ends.  PGH_CLEAN_EXIT=1 keeps the orderly teardown (leak checkers).
+static int done_ok() {
+    std::cout.flush();
+    std::cerr.flush();
+    std::fflush(nullptr);
+    if (!std::getenv("PGH_CLEAN_EXIT")) ::_exit(0);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // ols_iter_with_kinship on an input that is read in PIECES (config 5 of BASELINE.json: a file far larger than
 // host memory): while the GPU takes piece c (H2D from pinned memory, loader, partial kinship), the worker
@@ -338,7 +349,7 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
     fclose(fo);
     lap("format + write CSV");
     std::cout << out << "\n";
-    return 0;
+    return done_ok();
 }
 
 // fst (popgen/fst.rs:10-261) and heterozygosity = pi (popgen/pi.rs:115-190) on the loaded matrix: loci and windows on
@@ -388,7 +399,7 @@ static int run_popgen(const Args &a, bool is_fst, Ctx &gpu, const double *G_dev,
         fclose(fo);
         lap("write CSV");
         std::cout << out << "\n";
-        return 0;
+        return done_ok();
     }
     std::string out = a.output, out_win;
     if (out.empty()) { // fst.rs:93-131
@@ -425,7 +436,7 @@ static int run_popgen(const Args &a, bool is_fst, Ctx &gpu, const double *G_dev,
     fclose(fo);
     lap("write CSV");
     std::cout << out << " and " << out_win << "\n"; // main.rs:441
-    return 0;
+    return done_ok();
 }
 
 static int run(int argc, char **argv) {
@@ -462,7 +473,7 @@ static int run(int argc, char **argv) {
         lap("pileup2sync");
         std::cerr << kept << " loci written\n";
         std::cout << out << "\n"; // main.rs:507
-        return 0;
+        return done_ok();
     }
     Ctx gpu; // first: the pinned allocator below needs a HIP context
     lap("start-up");
@@ -590,7 +601,7 @@ static int run(int argc, char **argv) {
         fclose(fo);
         lap("format + write CSV");
         std::cout << out << "\n"; // main.rs:507
-        return 0;
+        return done_ok();
     }
 
     // ---------------- ols_iter_with_kinship (main.rs:280-298) -------------------------------------
@@ -669,7 +680,7 @@ static int run(int argc, char **argv) {
         (void)hipFree(G_dev);
         lap("cross-validation");
         std::cout << out << "\n";
-        return 0;
+        return done_ok();
     }
     if (!a.output.empty()) { FILE *t = create_new(a.output); fclose(t); ::unlink(a.output.c_str()); } // ols.rs:285
     std::vector<double> beta((size_t)p * k), var((size_t)p * k), pval((size_t)p * k);
@@ -698,7 +709,7 @@ static int run(int argc, char **argv) {
     fclose(fo);
     lap("format + write CSV");
     std::cout << out << "\n";
-    return 0;
+    return done_ok();
 }
 
 int main(int argc, char **argv) {

@@ -22,7 +22,7 @@ for rep in 1 2; do
   PGH_TIMING=1 poolgen_amd/csrc/poolgen ols_iter_with_kinship -f $big -p $d/phen.csv --phen-value-col 2 --n-threads $thr -o $d/out.csv 2> $d/timing.$rep.txt
   e=$(date +%s.%N)
   python3 -c "import sys; print('run', sys.argv[1], 'wall %.3f s' % (float(sys.argv[3]) - float(sys.argv[2])))" $rep $s $e
-  cat $d/timing.$rep.txt | tail -12
+  grep -E '^poolgen:' $d/timing.$rep.txt
 done
 wc -l $d/out.csv
 rm -rf $d
