@@ -330,6 +330,80 @@ __global__ __launch_bounds__(SW_THREADS) void k_gp_beta_lds(const double *__rest
     }
 }
 
+// The coefficient pass as a skinny fp64 MFMA GEMM: out (64 loci x 16 columns per wave tile) = G-tile (64 x n) * Z (n x 16).
+// v_mfma_f64_16x16x4_f64 with A = 16 loci x 4 pools from the staged tile, B = 4 pools x 16 columns of Z: one 512-byte
+// conflict-free LDS read of Z per k-step serves four locus groups, where the VALU form needs a broadcast read per FMA
+// operand (k_gp_beta_lds is bound by that LDS return traffic).  Z columns beyond the fits are zero; pools beyond n are
+// zero rows of Z and zero columns of the tile, so every chunk runs the same 8 k-steps.  Output column-major (k x p).
+constexpr int MB_PITCH = SW_CH + 4;          // doubles per tile row: 8 * 36 bytes puts the 16 loci of an A fragment on all banks
+constexpr int MB_TILE = 64 * MB_PITCH;
+typedef double mb_double4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(SW_THREADS) void k_gp_beta_mfma(const double *__restrict__ G, const double *__restrict__ Z16,
+                                                             double *__restrict__ out, const SweepDims D, int zrows) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int fi = lane & 15, kq = lane >> 4;
+    double *Zs = lds;                                  // zrows x 16
+    double *tile = lds + (size_t)zrows * 16 + wave * MB_TILE;
+    for (int i = threadIdx.x; i < zrows * 16; i += SW_THREADS) Zs[i] = Z16[i];
+    __syncthreads();
+    const int nch = (D.n + SW_CH - 1) / SW_CH;
+    const int nfull = D.n / SW_CH;
+    const int ntail = D.n - nfull * SW_CH;
+    const int64_t wstride = (int64_t)gridDim.x * SW_WAVES;
+    const int lr = lane / SW_LPR, piece = lane % SW_LPR;
+    for (int64_t t = (int64_t)blockIdx.x * SW_WAVES + wave; t < D.ntiles; t += wstride) {
+        const int64_t l0 = t * 64;
+        mb_double4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mb_double4{0.0, 0.0, 0.0, 0.0};
+        double2 v[SW_NLD];
+        if (nfull) gpb_load<true>(G, l0, D.p, D.ld, 0, SW_CH, lane, v);
+        else gpb_load<false>(G, l0, D.p, D.ld, 0, ntail, lane, v);
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool full = ch < nfull;
+            const bool col_ok = full || 2 * piece < ntail, two = full || 2 * piece + 1 < ntail;
+#pragma unroll
+            for (int r = 0; r < SW_NLD; ++r) {
+                double2 x = v[r];
+                x.x = col_ok ? x.x : 0.0;
+                x.y = two ? x.y : 0.0;
+                *reinterpret_cast<double2 *>(&tile[(SW_RPI * r + lr) * MB_PITCH + 2 * piece]) = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ch + 1 < nch) { // next chunk's rows travel while this one is multiplied
+                if (ch + 1 < nfull) gpb_load<true>(G, l0, D.p, D.ld, (ch + 1) * SW_CH, SW_CH, lane, v);
+                else gpb_load<false>(G, l0, D.p, D.ld, (ch + 1) * SW_CH, ntail, lane, v);
+            }
+            const double *zp = Zs + (size_t)(ch * SW_CH + kq) * 16 + fi;
+            const double *ap = tile + fi * MB_PITCH + kq;
+#pragma unroll
+            for (int ks = 0; ks < SW_CH / 4; ++ks) {
+                const double b = zp[ks * 64];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g * 16 * MB_PITCH + 4 * ks], b, acc[g], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg -> through the (now idle) tile so that a lane stores
+        // its own locus, 64 consecutive doubles of a column per instruction
+        double *tr = tile; // [16 columns][64 loci]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[fi * 64 + 16 * g + kq + 4 * r] = acc[g][r];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t l = l0 + lane;
+        if (l < D.p) {
+            for (int c = 0; c < D.k; ++c) out[(int64_t)c * D.p + l] = tr[c * 64 + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Intercept-only fits closed from the sums the fused kinship pass left behind (pg_set_phenotypes):
 // spec[l] = { sum g', sum g'^2, sum g' ytil_t }, g' = g - g[0].  With Z = [1]: u = sum g' / sqrt(n).
 __global__ void k_sweep_finish(const double *__restrict__ spec, const double *__restrict__ syy,
@@ -746,6 +820,33 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     const int64_t cap = (int64_t)ctx->cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
     int rc;
+    // the folds' slopes of a CV repetition (column-major, up to 16 columns): the MFMA form
+    const int zrows = (n + SW_CH - 1) / SW_CH * SW_CH;
+    const size_t mfma_lds = ((size_t)zrows * 16 + (size_t)SW_WAVES * MB_TILE) * sizeof(double);
+    if (colmajor && ncol >= 5 && ncol <= 16 && mfma_lds <= 150 * 1024 && !std::getenv("POOLGEN_GP_BETA_VALU")) {
+        std::vector<double> Z16((size_t)zrows * 16, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < ncol; ++c) Z16[(size_t)i * 16 + c] = Z_host[(size_t)i * ncol + c];
+        const size_t zb = Z16.size() * sizeof(double);
+        if (zb > ctx->W_cap) {
+            PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->W_dev) PG_HIP(ctx, hipFree(ctx->W_dev));
+            ctx->W_dev = nullptr; ctx->W_cap = 0;
+            PG_HIP(ctx, hipMalloc((void **)&ctx->W_dev, zb));
+            ctx->W_cap = zb;
+        }
+        PG_HIP(ctx, hipMemcpyAsync(ctx->W_dev, Z16.data(), zb, hipMemcpyHostToDevice, ctx->stream));
+        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gp_beta_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)mfma_lds));
+        const int64_t nblocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
+        const int g2 = (int)std::min<int64_t>(nblocks, (int64_t)ctx->cus);
+        pg_prof_begin(ctx, PG_K_GP_BETA);
+        hipLaunchKernelGGL(k_gp_beta_mfma, dim3(g2), dim3(SW_THREADS), mfma_lds, ctx->stream, G_dev, ctx->W_dev, out_dev, D, zrows);
+        pg_prof_end(ctx);
+        PG_HIP(ctx, hipGetLastError());
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Z16 is stack-owned
+        return PG_OK;
+    }
     // many columns x many pools: Z no longer fits the scalar cache -> the LDS-resident variant (see k_gp_beta_lds)
     const int wdoubles = n_even * cols;
     const size_t lds_need = ((size_t)wdoubles + (size_t)SW_WAVES * SW_TILE) * sizeof(double);
