@@ -69,8 +69,8 @@ __global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k,
 
 // For every lambda_i: subtracted/added masses of the penalised set and the norm masses of the
 // de-penalised set, split by the sign of b (:296-326).  part: [block][4][GP_LMAX].
-__global__ __launch_bounds__(256) void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, int row0, PathParams P,
-                               Proxy X, double *__restrict__ part) {
+__device__ __forceinline__ void gp_path_sums_body(const double *__restrict__ beta, int64_t p, int k, int j, int row0,
+                                                  const PathParams &P, Proxy X, double *__restrict__ part) {
     double sp[GP_LMAX], ap[GP_LMAX], sd[GP_LMAX], ad[GP_LMAX];
 #pragma unroll
     for (int i = 0; i < GP_LMAX; ++i) { sp[i] = 0.0; ap[i] = 0.0; sd[i] = 0.0; ad[i] = 0.0; }
@@ -107,6 +107,20 @@ __global__ __launch_bounds__(256) void k_gp_path_sums(const double *__restrict__
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sm[w][threadIdx.x];
         part[(size_t)blockIdx.x * 4 * GP_LMAX + threadIdx.x] = s;
     }
+}
+__global__ __launch_bounds__(256) void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, int row0, PathParams P,
+                                                      Proxy X, double *__restrict__ part) {
+    gp_path_sums_body(beta, p, k, j, row0, P, X, part);
+}
+// all columns of a column-major matrix in one launch: blockIdx.y = column, its norm maximum from nmax[] (device)
+__global__ __launch_bounds__(256) void k_gp_path_sums_cols(const double *__restrict__ cols, int64_t p, PathParams P, Proxy X, int kx,
+                                                           const double *__restrict__ nmax, const int *__restrict__ skip,
+                                                           double *__restrict__ part) {
+    const int c = blockIdx.y;
+    if (skip[c]) return;
+    P.nmax = nmax[c];
+    X.j = c % kx;
+    gp_path_sums_body(cols + (size_t)c * p, p, 1, 0, 0, P, X, part + (size_t)c * gridDim.x * 4 * GP_LMAX);
 }
 
 // expand_and_contract of one coefficient for lambda_i (:296-352), given the global masses
@@ -269,12 +283,22 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
     }
 }
 
-__global__ void k_gp_predict_reduce(const double *__restrict__ part, int nblocks, int n, double *__restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // pool * GP_LMAX + i
-    if (idx >= n * GP_LMAX) return;
+// 64 outputs x 8 groups of slabs per workgroup; the groups' sums are combined in group order (same result every run)
+__global__ __launch_bounds__(512) void k_gp_predict_reduce(const double *__restrict__ part, int nblocks, int n,
+                                                           double *__restrict__ out) {
+    __shared__ double sm[8][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o; // pool * GP_LMAX + i
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * n * GP_LMAX + idx];
-    out[idx] = s;
+    if (idx < n * GP_LMAX)
+        for (int b = g; b < nblocks; b += 8) s += part[(size_t)b * n * GP_LMAX + idx];
+    sm[g][o] = s;
+    __syncthreads();
+    if (g == 0 && idx < n * GP_LMAX) {
+        double t = sm[0][o];
+        for (int q = 1; q < 8; ++q) t += sm[q][o];
+        out[idx] = t;
+    }
 }
 
 // yhat partials for a plain coefficient matrix: thread = pool, block = slab of loci, up to 8 traits
@@ -371,15 +395,21 @@ int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int
 
 
 // per column: out[c][q] = max or sum over the blocks' partials, in block order (what the host loop of ridge_path_params does)
-__global__ void k_gp_reduce_parts(const double *__restrict__ part, int ncols, int nb, int64_t col_stride, int elem_stride,
-                                  int use, int is_max, double *__restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // c * use + q
+// one wave per output: lane t takes blocks t, t + 64, ...; the 64 lane sums are combined by a fixed butterfly
+__global__ __launch_bounds__(256) void k_gp_reduce_parts(const double *__restrict__ part, int ncols, int nb, int64_t col_stride,
+                                                         int elem_stride, int use, int is_max, double *__restrict__ out) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6); // c * use + q
+    const int lane = threadIdx.x & 63;
     if (idx >= ncols * use) return;
     const int c = idx / use, q = idx - c * use;
     const double *src = part + (size_t)c * col_stride + q;
     double r = 0.0;
-    for (int b = 0; b < nb; ++b) r = is_max ? fmax(r, src[(size_t)b * elem_stride]) : r + src[(size_t)b * elem_stride];
-    out[idx] = r;
+    for (int b = lane; b < nb; b += 64) r = is_max ? fmax(r, src[(size_t)b * elem_stride]) : r + src[(size_t)b * elem_stride];
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(r, off);
+        r = is_max ? fmax(r, o) : r + o;
+    }
+    if (lane == 0) out[idx] = r;
 }
 
 // ridge_path_params for all columns of `cols_dev` (COLUMN-major, ncols x p: every column is one contiguous stream) at once: the columns' launches queue up behind
@@ -398,30 +428,33 @@ int ridge_path_params_cols(pg_ctx *ctx, const double *cols_dev, int64_t p, int n
         if (X.b) hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, X.b, p, X.k, X.j, 1, alpha, W.part + (size_t)c * nb * width);
         else hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, cols_dev + (size_t)c * p, p, 1, 0, 0, alpha, W.part + (size_t)c * nb * width);
     }
-    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream, W.part, ncols, nb, (int64_t)nb * width, 1,
+    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream, W.part, ncols, nb, (int64_t)nb * width, 1,
                        1, 1, red);
     PG_HIP(ctx, hipGetLastError());
-    PG_HIP(ctx, hipMemcpyAsync(h.data(), red, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int c = 0; c < ncols; ++c) {
-        PathParams &P = out[c];
-        std::memset(&P, 0, sizeof P);
-        P.alpha = alpha;
-        P.nmax = h[c];
-        P.L = (int)path.size();
-        for (int i = 0; i < P.L; ++i) P.lambda[i] = path[i];
-        if (skip[c]) continue;
-        hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, cols_dev + (size_t)c * p, p, 1, 0, 0, P, Proxy{proxy_dev, k, c % k},
-                           W.part + (size_t)c * nb * width);
-    }
-    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols * width + 255) / 256), dim3(256), 0, ctx->stream, W.part, ncols, nb,
+    // the maxima stay on the device for the path sums (and travel to the host with them, further down)
+    double *nmax_dev = red + (size_t)ncols * width;
+    int *skip_dev = reinterpret_cast<int *>(nmax_dev + ncols);
+    PG_HIP(ctx, hipMemcpyAsync(nmax_dev, red, sizeof(double) * ncols, hipMemcpyDeviceToDevice, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(skip_dev, skip.data(), sizeof(int) * ncols, hipMemcpyHostToDevice, ctx->stream));
+    PathParams Pc;
+    std::memset(&Pc, 0, sizeof Pc);
+    Pc.alpha = alpha;
+    Pc.L = (int)path.size();
+    for (int i = 0; i < Pc.L; ++i) Pc.lambda[i] = path[i];
+    hipLaunchKernelGGL(k_gp_path_sums_cols, dim3(nb, ncols), dim3(256), 0, ctx->stream, cols_dev, p, Pc, Proxy{proxy_dev, k, 0}, k, nmax_dev,
+                       skip_dev, W.part);
+    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols * width + 3) / 4), dim3(256), 0, ctx->stream, W.part, ncols, nb,
                        (int64_t)nb * width, width, width, 0, red);
     PG_HIP(ctx, hipGetLastError());
+    std::vector<double> hmax(ncols);
     PG_HIP(ctx, hipMemcpyAsync(h.data(), red, sizeof(double) * ncols * width, hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(hmax.data(), nmax_dev, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `skip` (the caller's) has been consumed as well
     for (int c = 0; c < ncols; ++c) {
-        if (skip[c]) continue;
         PathParams &P = out[c];
+        P = Pc;
+        P.nmax = hmax[c];
+        if (skip[c]) continue;
         const double *q = &h[(size_t)c * width];
         for (int i = 0; i < P.L; ++i) {
             double sp = q[i], ap = q[GP_LMAX + i], sd = q[2 * GP_LMAX + i], ad = q[3 * GP_LMAX + i];
@@ -628,7 +661,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                     PG_PREDICT_FOLDS(12) PG_PREDICT_FOLDS(14) PG_PREDICT_FOLDS(16)
                 }
 #undef PG_PREDICT_FOLDS
-                hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
+                hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 63) / 64), dim3(512), 0, ctx->stream, W.part, nblk2, n, W.yhat);
                 if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                     hipStreamSynchronize(ctx->stream) != hipSuccess)
                     return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
@@ -662,7 +695,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                     if (rc) return fail(rc);
                     hipLaunchKernelGGL(k_gp_blambda, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, beta_dev, p, k, j, P, X, W.B);
                     hipLaunchKernelGGL(k_gp_predict, dim3(nblk2, (n + 255) / 256), dim3(256), 0, ctx->stream, G_dev, W.B, p, n, ld, lpb, W.part);
-                    hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 255) / 256), dim3(256), 0, ctx->stream, W.part, nblk2, n, W.yhat);
+                    hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 63) / 64), dim3(512), 0, ctx->stream, W.part, nblk2, n, W.yhat);
                     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                         hipStreamSynchronize(ctx->stream) != hipSuccess)
                         return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
