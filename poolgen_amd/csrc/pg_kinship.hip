@@ -112,6 +112,8 @@ struct KinParams {
     int64_t loci_per_wg;
     double *slabs; // [gridDim.x][npad * npad]
     int n, T, npad, Tb, nb;
+    int split;  // nb == 2: the one pair's tile list (A x B, A x A, B x B: 136 tiles at T = 16) is dealt to `split` = 2
+                // workgroups per slab of loci instead of three workgroups of which two are a third full
     int merged; // nb >= 4: no workgroups for the diagonal blocks -- every off-diagonal pair (A, B) also takes 1/(nb-1) of
                 // the tiles of A x A and of B x B (64 + 12 + 12 of its 96 tile slots at Tb = 8 instead of 64, or 36 on a
                 // diagonal workgroup), and every pool column is staged nb - 1 times instead of nb
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     // ---- which pair of pool blocks ------------------------------------------------------
     int bi = 0, bj = 0;
     {
-        int q = blockIdx.y;
+        int q = blockIdx.y / P.split;
         const int first = P.merged ? 1 : 0; // merged: pairs with bi < bj only
         for (bi = 0; bi < P.nb; ++bi) {
             const int cnt = P.nb - bi - first;
@@ -162,13 +164,14 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     const int cntA = P.merged ? (NA > rankA ? (NA - rankA + part - 1) / part : 0) : 0;
     const int cntB = P.merged ? (NB > rankB ? (NB - rankB + part - 1) / part : 0) : 0;
     const int ntiles = diag ? NA : nrect + cntA + cntB;
+    const int split_id = blockIdx.y % P.split;
     // Every wave runs exactly KIN_TPW tile slots so that the k-loop is straight-line code; a slot
     // beyond the tile list recomputes tile 0 into an accumulator that is never stored.
     int acol[KIN_TPW], bcol[KIN_TPW], orow[KIN_TPW], ocol[KIN_TPW];
     bool live[KIN_TPW];
 #pragma unroll
     for (int u = 0; u < KIN_TPW; ++u) {
-        const int t = wave + KIN_WAVES * u;
+        const int t = split_id + P.split * (wave + KIN_WAVES * u);
         int ti = 0, tj = 0;
         live[u] = t < ntiles;
         int kind = diag ? 1 : 0; // 0: A x B, 1: inside A, 2: inside B
@@ -570,8 +573,11 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     P.npad = P.T * 16;
     if (P.T <= 13) { P.Tb = P.T; P.nb = 1; }
     else { P.Tb = 8; P.nb = (P.T + 7) / 8; }
-    P.merged = (P.nb >= 4 && !std::getenv("POOLGEN_KIN_NO_MERGE")) ? 1 : 0; // 64 + 2 * ceil(36 / (nb - 1)) <= 96 slots
-    const int npairs = P.merged ? P.nb * (P.nb - 1) / 2 : P.nb * (P.nb + 1) / 2;
+    // nb >= 4: 64 + 2 * ceil(36 / (nb - 1)) <= 96 slots; nb == 2: measured -- a win at T = 15, 16 (7.6 -> 6.9 ms at n = 240..256,
+    // 4 M loci), a loss at T = 14 where the diagonal workgroups stage few columns
+    P.merged = ((P.nb >= 4 || (P.nb == 2 && P.T >= 15)) && !std::getenv("POOLGEN_KIN_NO_MERGE")) ? 1 : 0;
+    P.split = (P.merged && P.nb == 2) ? 2 : 1;                                               // nb == 2: all 136 tiles, 68 + 68
+    const int npairs = (P.merged ? P.nb * (P.nb - 1) / 2 : P.nb * (P.nb + 1) / 2) * P.split;
     int nslab = cus / npairs;
     if (nslab < 1) nslab = 1;
     const int64_t max_slabs = (p + KIN_KC - 1) / KIN_KC;
