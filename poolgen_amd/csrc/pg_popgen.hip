@@ -87,6 +87,18 @@ __global__ __launch_bounds__(256) void k_range_mean_1d(const double *__restrict_
     out[gid] = s / (double)(tail[w] + 1 - head[w]);
 }
 
+// a / b as hipcc's own fp64 division computes it for normal-range operands, minus the scaling and fix-up steps those
+// operands do not need (1 - q2 + eps lies in [eps, 1 + eps]; the quotient is 0, NaN or of ordinary size): v_rcp_f64, two
+// Newton steps, then quotient, fused residual, fused correction.  Same helper and same argument as pg_locus_ops.hip; the
+// per-window table is compared bit for bit with the oracle's `/` (tests/test_gpu_popgen.py).
+__device__ __forceinline__ double pop_div(double a, double b) {
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double r1 = fma(fma(-b, r0, 1.0), r0, r0);
+    const double r = fma(fma(-b, r1, 1.0), r1, r1);
+    const double q0 = a * r;
+    return fma(fma(-b, q0, a), r, q0);
+}
+
 constexpr int FT = 8;       // threads per tile edge (one wave per block)
 constexpr int FR = 4;       // pools per thread along each edge: a block covers a (FT*FR)^2 = 32 x 32 tile of pairs
 constexpr int FTILE = FT * FR;
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(FT * FT) void k_fst_ranges(const double *__restrict
         for (int u = 0; u < FR; ++u)
 #pragma unroll
             for (int v = 0; v < FR; ++v) {
-                const double fu = (0.5 * (q1j[u] + q1k[v]) - q2[u][v]) / (1.00 - q2[u][v] + POP_EPS);
+                const double fu = pop_div(0.5 * (q1j[u] + q1k[v]) - q2[u][v], 1.00 - q2[u][v] + POP_EPS);
                 s[u][v] = s[u][v] + (fu < 0.0 ? 0.0 : (fu > 1.0 ? 1.0 : fu)); // NaN passes through, as in the reference
             }
         c0 = c1;
