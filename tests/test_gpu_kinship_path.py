@@ -269,6 +269,23 @@ def test_gp_penalised_family_matches_oracle(engine, oracle, n, p, k, alpha, prox
     assert np.allclose(perf2, perf, rtol=1e-9, atol=1e-12) and np.array_equal(lam2, lam) and np.array_equal(al2, al)
 
 
+@pytest.mark.parametrize("n,p,k,n_folds", [(80, 1500, 2, 10), (40, 900, 2, 10), (120, 2500, 1, 16), (300, 4000, 1, 10)])
+def test_gp_ridge_many_fold_columns(engine, oracle, n, p, k, n_folds):
+    """More fold x trait columns than one MFMA tile holds (20 -> the 24-column VALU forms, Z in LDS or in the scalar
+    cache), exactly 16, and the 10-column MFMA form at a pool count with a ragged last chunk."""
+    G, Y = make(p, n, 91)
+    Y = np.hstack([Y, Y[:, :1] * 0.3 - 1.0])[:, :k]
+    rng = np.random.default_rng(13)
+    rows = np.arange(n)
+    folds = np.stack([rng.permutation(np.arange(n) % n_folds) for _ in range(2)])
+    beta, lam, perf = engine.gp_ridge(G, Y, rows, folds, n_folds, alpha=0.0, n=n)
+    Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])
+    rb, rl, rp = oracle.penalised_lambda_path(Xt, Y, rows, folds, n_folds, alpha=0.0, n=n)
+    assert np.allclose(perf, rp, rtol=1e-6, atol=1e-9)
+    assert np.array_equal(lam, rl)
+    assert np.allclose(beta.cpu().numpy(), rb, rtol=1e-6, atol=1e-8 * np.abs(rb).max())
+
+
 def test_gp_ols_with_duplicated_pools_uses_the_pseudo_inverse(engine, oracle):
     """Two identical pools make X X^T singular: the reference's pinv (helpers.rs:463-482) drops the null
     direction.  The product's fast path (Cholesky) must hand such a matrix to the eigen-based pseudo-inverse."""
