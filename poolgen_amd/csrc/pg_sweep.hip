@@ -559,6 +559,10 @@ extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total,
         PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(K.data(), ctx->pin, sizeof(double) * (size_t)n * n);
     }
+    for (int i = 0; i < n; ++i) // the diagonal is a sum of squares: NaN there <=> some frequency of pool i is NaN
+        if (std::isnan(K[(size_t)i * n + i]))
+            return pg_fail(ctx, PG_ERR_INVALID, "kinship_set: the kinship matrix contains NaN -- pool %d has no coverage at some locus "
+                           "that passed the filters (its frequencies are NaN, base/sync.rs:176-183); the reference's eig() fails on such a matrix too", i);
     const double pd = (double)p_total;
     auto scale_K = [&]() { for (auto &x : K) x = x / pd; }; // kinship = G G^T / p  (gwas/ols.rs:295)
     int m = force_m;
