@@ -1484,9 +1484,9 @@ int orc_theta_pi(const double *Xt, int64_t P, int n, int64_t ld, const int64_t *
  *   (or a ragged pool triplet), -5 indel length is not a digit.
  * ============================================================================================ */
 #define ORC_PILEUP_MAXF 4096
-int orc_pileup_to_sync(const char *line, int remove_ns, double max_base_error_rate, uint64_t min_coverage_depth,
-                       double min_coverage_breadth, double min_allele_frequency, const double *pool_sizes,
-                       int n_pool_sizes, char *out, int cap) {
+int orc_pileup_to_sync2(const char *line, int remove_ns, int keep_lowercase_reference, double max_base_error_rate,
+                        uint64_t min_coverage_depth, double min_coverage_breadth, double min_allele_frequency,
+                        const double *pool_sizes, int n_pool_sizes, char *out, int cap) {
     /* split("\t") */
     const char *fs[ORC_PILEUP_MAXF];
     int fl[ORC_PILEUP_MAXF], nf = 0;
@@ -1603,6 +1603,19 @@ int orc_pileup_to_sync(const char *line, int remove_ns, double max_base_error_ra
             if (cov[i] >= min_coverage_depth) covered++;
         if (covered != min_breadth) { rc = 0; goto done; }
     }
+    if (keep_lowercase_reference) /* :280-299, after the N removal and the coverage test: a lower-case reference allele
+                                     copied in for '.' / ',' becomes its base; whatever is not A/T/C/G in either case or '*'
+                                     -- the 'D' (68) that lparse made of '*' included -- becomes N */
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < ncode[i]; j++)
+                switch (codes[i][j]) {
+                    case 65: case 97: codes[i][j] = 65; break;
+                    case 84: case 116: codes[i][j] = 84; break;
+                    case 67: case 99: codes[i][j] = 67; break;
+                    case 71: case 103: codes[i][j] = 71; break;
+                    case 42: codes[i][j] = 68; break;
+                    default: codes[i][j] = 78;
+                }
     {
         /* to_counts (A,T,C,G,D,N) and to_frequencies: count / row sum (0/0 = NaN) */
         uint64_t cnt[6];
@@ -1641,4 +1654,12 @@ done:
     for (int i = 0; i < n; i++) { free(codes[i]); free(quals[i]); }
     free(cov); free(codes); free(quals); free(ncode); free(nqual);
     return rc;
+}
+
+/* keep_lowercase_reference = false (the CLI default, main.rs:60-62) */
+int orc_pileup_to_sync(const char *line, int remove_ns, double max_base_error_rate, uint64_t min_coverage_depth,
+                       double min_coverage_breadth, double min_allele_frequency, const double *pool_sizes,
+                       int n_pool_sizes, char *out, int cap) {
+    return orc_pileup_to_sync2(line, remove_ns, 0, max_base_error_rate, min_coverage_depth, min_coverage_breadth,
+                               min_allele_frequency, pool_sizes, n_pool_sizes, out, cap);
 }

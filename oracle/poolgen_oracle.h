@@ -171,6 +171,9 @@ int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, co
 
 /* ---- base/pileup.rs: one pileup line -> one sync line (lparse, filter, to_counts, pileup_to_sync) ---------
  * > 0 bytes written (with the trailing newline), 0 = None (dropped), < 0 = the reference panics on this line. */
+int orc_pileup_to_sync2(const char *line, int remove_ns, int keep_lowercase_reference, double max_base_error_rate,
+                        uint64_t min_coverage_depth, double min_coverage_breadth, double min_allele_frequency,
+                        const double *pool_sizes, int n_pool_sizes, char *out, int cap);
 int orc_pileup_to_sync(const char *line, int remove_ns, double max_base_error_rate, uint64_t min_coverage_depth,
                        double min_coverage_breadth, double min_allele_frequency, const double *pool_sizes,
                        int n_pool_sizes, char *out, int cap);

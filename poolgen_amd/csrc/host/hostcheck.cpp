@@ -49,7 +49,8 @@ int main(int argc, char **argv) {
             // hostcheck pileuplines <file> <remove_ns> <max_err> <min_depth> <breadth> <maf> <pool sizes,..>
             // one answer per input line: "K <sync line>" kept, "D" dropped (None), "E" the reference would panic
             PileupFilter f;
-            f.remove_ns = std::atoi(argv[3]) != 0;
+            f.remove_ns = (std::atoi(argv[3]) & 1) != 0;
+            f.keep_lowercase_reference = (std::atoi(argv[3]) & 2) != 0; // bit 1 of the first filter argument
             f.max_base_error_rate = std::strtod(argv[4], nullptr);
             f.min_coverage_depth = std::strtoull(argv[5], nullptr, 10);
             f.min_coverage_breadth = std::strtod(argv[6], nullptr);

@@ -33,7 +33,7 @@ struct Args {
     double max_base_error_rate = 0.01, min_coverage_breadth = 1.0, min_allele_frequency = 0.001,
            max_missingness_rate = 0.0, xxt = 0.75;
     uint64_t min_coverage_depth = 1;
-    bool keep_ns = false, keep_p_minus_1 = false, generate_plots = false, sig_only = false;
+    bool keep_ns = false, keep_p_minus_1 = false, generate_plots = false, sig_only = false, keep_lowercase_reference = false;
     int phen_name_col = 0, phen_pool_size_col = 1, n_threads = 1;
     long stream_chunk_mb = -1; // ols_iter_with_kinship: pieces of this size are parsed / copied / loaded in turn (-1 = automatic)
     std::vector<int> phen_value_col{2};
@@ -85,7 +85,7 @@ static Args parse_args(int argc, char **argv) {
         else if (k == "--keep-p-minus-1") a.keep_p_minus_1 = true;
         else if (k == "--generate-plots") a.generate_plots = true;
         else if (k == "--output-sig-snps-only") a.sig_only = true;
-        else if (k == "--keep-lowercase-reference") { /* pileup only */ }
+        else if (k == "--keep-lowercase-reference") a.keep_lowercase_reference = true; // pileup inputs only (pileup.rs:280-299)
         else if (k == "--stream-chunk-mb") a.stream_chunk_mb = std::stol(val());
         else if (k == "--k-folds") a.k_folds = std::stoi(val());
         else if (k == "--n-reps") a.n_reps = std::stoi(val());
@@ -462,6 +462,7 @@ static int run(int argc, char **argv) {
     if (a.analysis == "pileup2sync") { // main.rs:212-225; text to text, no GPU involved
         PileupFilter pf;
         pf.remove_ns = !a.keep_ns;
+        pf.keep_lowercase_reference = a.keep_lowercase_reference;
         pf.max_base_error_rate = a.max_base_error_rate;
         pf.min_coverage_depth = a.min_coverage_depth;
         pf.min_coverage_breadth = a.min_coverage_breadth;
@@ -486,6 +487,7 @@ static int run(int argc, char **argv) {
     const bool is_pileup = ends_with(a.fname, ".pileup") || ends_with(a.fname, ".mpileup");
     PileupFilter pf;
     pf.remove_ns = !a.keep_ns;
+    pf.keep_lowercase_reference = a.keep_lowercase_reference;
     pf.max_base_error_rate = a.max_base_error_rate;
     pf.min_coverage_depth = a.min_coverage_depth;
     pf.min_coverage_breadth = a.min_coverage_breadth;

@@ -47,6 +47,15 @@ PileupConverter::PileupConverter(const PileupFilter &f) : f_(f) {
     for (int c = 0; c < 128; ++c) special_[c] = (c == '+' || c == '-' || c == '^' || c == '$') ? 1 : 0;
     for (int c = 0; c < 256; ++c) column_[c] = 5; // to_counts (:181-188): A,T,C,G,D, everything else under N
     column_[65] = 0; column_[84] = 1; column_[67] = 2; column_[71] = 3; column_[68] = 4;
+    if (f.keep_lowercase_reference) {
+        // :280-299 remaps the codes AFTER the N removal and the coverage test and before to_counts: either case of
+        // A/T/C/G is the base, '*' is D, everything else -- the 'D' lparse made of '*' included -- is N.  The only codes
+        // that can still be anything but A/T/C/G/D/N are copies of the reference allele, so the remap folds into the
+        // byte -> column table.
+        for (int c = 0; c < 256; ++c) column_[c] = 5;
+        column_['A'] = column_['a'] = 0; column_['T'] = column_['t'] = 1; column_['C'] = column_['c'] = 2;
+        column_['G'] = column_['g'] = 3; column_['*'] = 4;
+    }
 }
 
 bool PileupConverter::decode(const char *b, const char *e, Locus &L) const {

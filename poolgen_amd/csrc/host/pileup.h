@@ -9,6 +9,7 @@ namespace pgh {
 
 struct PileupFilter {            // the FilterStats fields PileupLine::filter reads (pileup.rs:239-337)
     bool remove_ns = true;                 // !--keep-ns
+    bool keep_lowercase_reference = false; // --keep-lowercase-reference (pileup.rs:280-299)
     double max_base_error_rate = 0.01;
     uint64_t min_coverage_depth = 1;
     double min_coverage_breadth = 1.0;
@@ -40,7 +41,7 @@ private:
     uint32_t min_breadth_;
     bool low_quality_[256];   // 10^(-(q-33)/10) > max_base_error_rate
     unsigned char base_[256]; // read code -> allele byte; 0 = "the reference allele"
-    unsigned char column_[256]; // allele byte -> count column (A,T,C,G,D,N = 0..5)
+    unsigned char column_[256]; // allele byte -> count column (A,T,C,G,D,N = 0..5), through the lower-case remap when asked for
     unsigned char special_[128]; // 1 for the read codes that are not a base: + - ^ $
 };
 

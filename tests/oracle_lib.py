@@ -101,15 +101,15 @@ class Oracle:
         return n, chrom.value.decode(), pos.value, counts[:n].copy()
 
     def pileup_to_sync(self, line, pool_sizes, remove_ns=True, max_base_error_rate=0.01, min_coverage_depth=1,
-                       min_coverage_breadth=1.0, min_allele_frequency=0.001):
+                       min_coverage_breadth=1.0, min_allele_frequency=0.001, keep_lowercase_reference=False):
         """One pileup line -> (code, sync line): code > 0 ok, 0 = None (dropped), < 0 = the reference panics."""
         ps = np.ascontiguousarray(pool_sizes, dtype=np.float64)
         buf = C.create_string_buffer(64 + 80 * max(len(ps), line.count("\t")))
-        fn = self.lib.orc_pileup_to_sync
+        fn = self.lib.orc_pileup_to_sync2
         fn.restype = C.c_int
-        fn.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_uint64, C.c_double, C.c_double, C.c_void_p, C.c_int,
+        fn.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_double, C.c_double, C.c_void_p, C.c_int,
                        C.c_char_p, C.c_int]
-        rc = fn(line.encode("latin-1"), int(remove_ns), float(max_base_error_rate), int(min_coverage_depth),
+        rc = fn(line.encode("latin-1"), int(remove_ns), int(keep_lowercase_reference), float(max_base_error_rate), int(min_coverage_depth),
                 float(min_coverage_breadth), float(min_allele_frequency), ps.ctypes.data, len(ps), buf, len(buf))
         return rc, (buf.value.decode("latin-1") if rc > 0 else "")
 

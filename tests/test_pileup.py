@@ -63,16 +63,18 @@ def _random_line(rng, n, weird):
 
 def test_generated_lines_match_oracle(tmp_path, oracle):
     rng = random.Random(20251003)
-    for n, remove_ns, max_err, depth, breadth, maf, weird in [(5, True, 0.01, 1, 1.0, 0.001, False), (3, False, 0.005, 2, 0.5, 0.05, True),
-                                                                (8, True, 0.0005, 1, 0.75, 0.0, True), (2, True, 1.0, 3, 1.0, 0.05, True)]:
+    for n, remove_ns, max_err, depth, breadth, maf, weird, keep_lc in [
+            (5, True, 0.01, 1, 1.0, 0.001, False, False), (3, False, 0.005, 2, 0.5, 0.05, True, False),
+            (8, True, 0.0005, 1, 0.75, 0.0, True, False), (2, True, 1.0, 3, 1.0, 0.05, True, False),
+            (4, True, 0.01, 1, 1.0, 0.001, True, True), (3, False, 0.01, 1, 0.6, 0.02, True, True)]:   # --keep-lowercase-reference (:280-299)
         ps = [1.0 / n] * n
         lines = [_random_line(rng, n if rng.random() > 0.01 else n + 1, weird) for _ in range(1500)]
         p = tmp_path / "g.pileup"; p.write_text("\n".join(lines) + "\n", encoding="latin-1")
-        got = hostcheck("pileuplines", p, int(remove_ns), max_err, depth, breadth, maf, ",".join(map(repr, ps))).splitlines()
+        got = hostcheck("pileuplines", p, int(remove_ns) + 2 * int(keep_lc), max_err, depth, breadth, maf, ",".join(map(repr, ps))).splitlines()
         assert len(got) == len(lines)
         kinds = {"K": 0, "D": 0, "E": 0}
         for line, g in zip(lines, got):
-            rc, text = oracle.pileup_to_sync(line, ps, remove_ns, max_err, depth, breadth, maf)
+            rc, text = oracle.pileup_to_sync(line, ps, remove_ns, max_err, depth, breadth, maf, keep_lowercase_reference=keep_lc)
             want = ("K " + text.rstrip("\n")) if rc > 0 else ("D" if rc == 0 else "E")
             assert g == want, (line, g, want, rc)
             kinds[g[0]] += 1
