@@ -159,6 +159,9 @@ int pg_load_plan_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, 
                      const pg_filter *filter, int keep_p_minus_1, const int64_t *order_dev, int64_t *p_out);
 int pg_load_emit_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,
                      int64_t *col_locus_dev, int32_t *col_allele_dev);
+/* Counts stored as 16-bit integers (the host parser's compact form: half the bytes to pin and to copy) -> the 32-bit
+ * L x n x 6 layout every operator reads.  Both buffers on the device, 16-byte aligned; n_values = L * n * 6. */
+int pg_expand_counts_u16_dev(pg_ctx *ctx, const uint16_t *src_dev, int64_t n_values, uint32_t *dst_dev);
 /* pg_load_emit_dev that also writes the coverages GenotypesAndPhenotypes carries (sync.rs:1129-1152): cov_dev is
  * p x ld like G; every column row of a locus holds, per pool, the depth summed over the locus' surviving alleles. */
 int pg_load_emit_cov_dev(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, int64_t ld,

@@ -104,16 +104,16 @@ Phen parse_phen(const std::string &fname, const std::string &delim, int name_col
 // ---- sync parsing -----------------------------------------------------------------------------
 SyncBatch &SyncBatch::operator=(SyncBatch &&o) noexcept {
     if (this != &o) {
-        if (counts) { if (release) release(counts); else std::free(counts); }
+        if (void *q = counts ? (void *)counts : (void *)counts16) { if (release) release(q); else std::free(q); }
         n = o.n; L = o.L;
         chrom_id = std::move(o.chrom_id); chrom_names = std::move(o.chrom_names); pos = std::move(o.pos);
-        counts = o.counts; release = std::move(o.release);
-        o.counts = nullptr; o.L = 0;
+        counts = o.counts; counts16 = o.counts16; release = std::move(o.release);
+        o.counts = nullptr; o.counts16 = nullptr; o.L = 0;
     }
     return *this;
 }
 SyncBatch::~SyncBatch() {
-    if (counts) { if (release) release(counts); else std::free(counts); }
+    if (void *q = counts ? (void *)counts : (void *)counts16) { if (release) release(q); else std::free(q); }
 }
 
 MappedFile::MappedFile(const std::string &fname) {
@@ -171,12 +171,14 @@ inline bool digits(const char *&p, const char *e, uint64_t &v) {
 struct ThreadOut {
     std::vector<std::string> names; // chromosome names met by this worker, in order
     int64_t lines = 0;              // data lines written
+    bool overflow16 = false;        // a count above 65535 met while storing 16-bit counts
     std::string err;
 };
 
 // Parses the data lines of [b, e) into counts[(base + i) * n * 6 ...], chrom_local, pos.  n == 0: only
 // count the candidate lines (non-empty, not starting with '#') and return that count.
-int64_t parse_range(const char *b, const char *e, int n, uint32_t *counts, int32_t *chrom_local, uint64_t *pos,
+template <typename CT>
+int64_t parse_range(const char *b, const char *e, int n, CT *counts, int32_t *chrom_local, uint64_t *pos,
                     ThreadOut &out) {
     int64_t li = 0;
     const char *p = b;
@@ -213,13 +215,14 @@ int64_t parse_range(const char *b, const char *e, int n, uint32_t *counts, int32
         const char *t3 = (const char *)std::memchr(c + 1, '\t', (size_t)(q - c - 1));
         if (!t3) throw std::runtime_error("sync file: a line has fewer than four tab-separated fields");
         c = t3 + 1;
-        uint32_t *dst = counts + (size_t)li * n * 6;
+        CT *dst = counts + (size_t)li * n * 6;
         for (int i = 0; i < n; ++i) {
             for (int j = 0; j < 6; ++j) {
                 uint64_t v;
                 if (!digits(c, q, v) || v > 0xFFFFFFFFull)
                     throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
-                dst[i * 6 + j] = (uint32_t)v;
+                if (sizeof(CT) == 2 && v > 0xFFFFull) { out.overflow16 = true; throw std::runtime_error("count above 65535"); }
+                dst[i * 6 + j] = (CT)v;
                 if (j < 5) {
                     if (c >= q || *c != ':')
                         throw std::runtime_error("Please check the input sync file as the allele counts are not valid integers.");
@@ -253,12 +256,12 @@ int64_t parse_range(const char *b, const char *e, int n, uint32_t *counts, int32
 
 } // namespace
 
-SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc alloc) {
+SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc alloc, bool compact16) {
     const MappedFile mf(fname);
-    return parse_sync_buffer(mf.data(), mf.data() + mf.size(), n_threads, 0, std::move(alloc));
+    return parse_sync_buffer(mf.data(), mf.data() + mf.size(), n_threads, 0, std::move(alloc), compact16);
 }
 
-SyncBatch parse_sync_buffer(const char *bb, const char *be, int n_threads, int expect_n, SyncAlloc alloc) {
+SyncBatch parse_sync_buffer(const char *bb, const char *be, int n_threads, int expect_n, SyncAlloc alloc, bool compact16) {
     const bool timing = std::getenv("PGH_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_last = now();
@@ -304,7 +307,7 @@ SyncBatch parse_sync_buffer(const char *bb, const char *be, int n_threads, int e
     if (sb.n == 0) return sb;
     std::vector<ThreadOut> out(parts);
     std::vector<int64_t> cand(parts, 0), base(parts + 1, 0);
-    auto run_all = [&](auto &&fn) {
+    auto run_all = [&](auto &&fn) -> bool {
         std::vector<std::thread> th;
         for (int t = 0; t < parts; ++t)
             th.emplace_back([&, t] {
@@ -312,25 +315,47 @@ SyncBatch parse_sync_buffer(const char *bb, const char *be, int n_threads, int e
             });
         for (auto &x : th) x.join();
         for (int t = 0; t < parts; ++t)
+            if (out[t].overflow16) return false; // asked for 16-bit counts and one does not fit: the caller starts over
+        for (int t = 0; t < parts; ++t)
             if (!out[t].err.empty()) throw std::runtime_error(out[t].err);
+        return true;
     };
     // pass 1: candidate lines per range, so that every worker can write straight into its slice
-    run_all([&](int t) { cand[t] = parse_range(buf + cuts[t], buf + cuts[t + 1], 0, nullptr, nullptr, nullptr, out[t]); });
+    run_all([&](int t) { cand[t] = parse_range<uint32_t>(buf + cuts[t], buf + cuts[t + 1], 0, nullptr, nullptr, nullptr, out[t]); });
     lap("count lines");
     for (int t = 0; t < parts; ++t) base[t + 1] = base[t] + cand[t];
     const int64_t Lcand = base[parts];
-    const size_t bytes = sizeof(uint32_t) * (size_t)Lcand * sb.n * 6;
-    sb.counts = static_cast<uint32_t *>(alloc.alloc ? alloc.alloc(bytes ? bytes : 1) : std::malloc(bytes ? bytes : 1));
-    if (alloc.alloc) sb.release = alloc.release ? alloc.release : [](void *) {};
-    if (!sb.counts) throw std::runtime_error("out of memory for the allele counts of " + fname);
     sb.chrom_id.resize(Lcand);
     sb.pos.resize(Lcand);
-    lap("allocate");
-    // pass 2: parse
-    run_all([&](int t) {
-        out[t].lines = parse_range(buf + cuts[t], buf + cuts[t + 1], sb.n, sb.counts + (size_t)base[t] * sb.n * 6,
-                                   sb.chrom_id.data() + base[t], sb.pos.data() + base[t], out[t]);
-    });
+    auto allocate = [&](size_t elem) -> void * {
+        const size_t bytes = elem * (size_t)Lcand * sb.n * 6;
+        void *q = alloc.alloc ? alloc.alloc(bytes ? bytes : 1) : std::malloc(bytes ? bytes : 1);
+        if (alloc.alloc) sb.release = alloc.release ? alloc.release : [](void *) {};
+        if (!q) throw std::runtime_error("out of memory for the allele counts of " + fname);
+        return q;
+    };
+    bool done = false;
+    if (compact16) {
+        sb.counts16 = static_cast<uint16_t *>(allocate(sizeof(uint16_t)));
+        lap("allocate");
+        done = run_all([&](int t) {
+            out[t].lines = parse_range<uint16_t>(buf + cuts[t], buf + cuts[t + 1], sb.n, sb.counts16 + (size_t)base[t] * sb.n * 6,
+                                                 sb.chrom_id.data() + base[t], sb.pos.data() + base[t], out[t]);
+        });
+        if (!done) { // a count above 65535: 32-bit after all (the same allocator hands out a buffer of the right size)
+            if (sb.release) sb.release(sb.counts16); else std::free(sb.counts16);
+            sb.counts16 = nullptr;
+            for (auto &o : out) o = ThreadOut();
+        }
+    }
+    if (!done) {
+        sb.counts = static_cast<uint32_t *>(allocate(sizeof(uint32_t)));
+        lap("allocate");
+        run_all([&](int t) {
+            out[t].lines = parse_range<uint32_t>(buf + cuts[t], buf + cuts[t + 1], sb.n, sb.counts + (size_t)base[t] * sb.n * 6,
+                                                 sb.chrom_id.data() + base[t], sb.pos.data() + base[t], out[t]);
+        });
+    }
     lap("parse");
     // chromosome names: worker-local ids -> global ids in order of first appearance
     std::vector<std::vector<int32_t>> remap(parts);
@@ -348,7 +373,8 @@ SyncBatch parse_sync_buffer(const char *bb, const char *be, int n_threads, int e
         const int64_t r0 = base[t], cnt = out[t].lines;
         for (int64_t i = 0; i < cnt; ++i) sb.chrom_id[r0 + i] = remap[t][sb.chrom_id[r0 + i]];
         if (w != r0 && cnt > 0) {
-            std::memmove(sb.counts + (size_t)w * sb.n * 6, sb.counts + (size_t)r0 * sb.n * 6, sizeof(uint32_t) * (size_t)cnt * sb.n * 6);
+            if (sb.counts16) std::memmove(sb.counts16 + (size_t)w * sb.n * 6, sb.counts16 + (size_t)r0 * sb.n * 6, sizeof(uint16_t) * (size_t)cnt * sb.n * 6);
+            else std::memmove(sb.counts + (size_t)w * sb.n * 6, sb.counts + (size_t)r0 * sb.n * 6, sizeof(uint32_t) * (size_t)cnt * sb.n * 6);
             std::memmove(sb.chrom_id.data() + w, sb.chrom_id.data() + r0, sizeof(int32_t) * cnt);
             std::memmove(sb.pos.data() + w, sb.pos.data() + r0, sizeof(uint64_t) * cnt);
         }

@@ -35,11 +35,13 @@ struct SyncBatch {
     std::vector<int32_t> chrom_id;          // per locus: index into chrom_names
     std::vector<std::string> chrom_names;   // distinct chromosome names in order of first appearance
     std::vector<uint64_t> pos;
-    uint32_t *counts = nullptr;
+    uint32_t *counts = nullptr;             // L x n x 6, the device layout ...
+    uint16_t *counts16 = nullptr;           // ... or, when asked for and every count fits, 16-bit (half the bytes to pin and to copy)
     std::function<void(void *)> release;   // empty = free()
     int64_t size() const { return L; }
     const std::string &chrom(int64_t l) const { return chrom_names[chrom_id[l]]; }
-    size_t counts_bytes() const { return sizeof(uint32_t) * (size_t)L * n * 6; }
+    size_t counts_bytes() const { return (counts16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (size_t)L * n * 6; }
+    const void *counts_raw() const { return counts16 ? (const void *)counts16 : (const void *)counts; }
     SyncBatch() = default;
     SyncBatch(const SyncBatch &) = delete;
     SyncBatch &operator=(const SyncBatch &) = delete;
@@ -70,10 +72,12 @@ private:
 // lines whose position is not an integer are skipped (both are ErrorKind::Other, which per_chunk
 // answers with `continue`, sync.rs:111-128, :829-846); allele counts that are not integers are an error
 // (`expect`, :141).  Only the first six ':'-separated counts of a pool are used, as in the reference.
-SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc alloc = SyncAlloc());
+// compact16: store the counts as 16-bit integers when all of them fit (otherwise the batch comes back 32-bit as usual)
+SyncBatch parse_sync_file(const std::string &fname, int n_threads, SyncAlloc alloc = SyncAlloc(), bool compact16 = false);
 // the same for a byte range [b, e) that starts at a line start (a chunk of a file streamed in pieces); expect_n > 0
 // fixes the number of pools (0 = take it from the first data line of the range)
-SyncBatch parse_sync_buffer(const char *b, const char *e, int n_threads, int expect_n, SyncAlloc alloc = SyncAlloc());
+SyncBatch parse_sync_buffer(const char *b, const char *e, int n_threads, int expect_n, SyncAlloc alloc = SyncAlloc(),
+                            bool compact16 = false);
 
 extern const char ALLELES[7];
 

@@ -38,11 +38,16 @@ int main(int argc, char **argv) {
                 std::cout << "\n";
             }
         } else if (mode == "parse") {
-            const SyncBatch sb = parse_sync_file(argv[2], std::atoi(argv[3]));
-            std::cout << sb.size() << " " << sb.n << "\n";
+            // hostcheck parse <sync> <threads> [16]: "16" asks for 16-bit counts; the first line then ends with the width in use
+            const bool want16 = argc > 4 && std::string(argv[4]) == "16";
+            const SyncBatch sb = parse_sync_file(argv[2], std::atoi(argv[3]), SyncAlloc(), want16);
+            std::cout << sb.size() << " " << sb.n;
+            if (want16) std::cout << " " << (sb.counts16 ? 16 : 32);
+            std::cout << "\n";
             for (int64_t l = 0; l < sb.size(); ++l) {
                 std::cout << sb.chrom(l) << " " << sb.pos[l];
-                for (int i = 0; i < sb.n * 6; ++i) std::cout << " " << sb.counts[(size_t)l * sb.n * 6 + i];
+                for (int i = 0; i < sb.n * 6; ++i)
+                    std::cout << " " << (sb.counts16 ? (uint32_t)sb.counts16[(size_t)l * sb.n * 6 + i] : sb.counts[(size_t)l * sb.n * 6 + i]);
                 std::cout << "\n";
             }
         } else if (mode == "pileuplines") {

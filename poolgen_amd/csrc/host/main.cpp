@@ -199,6 +199,31 @@ static int done_ok() {
 // ---------------------------------------------------------------------------------------------------------
 struct UnsortedInput : std::runtime_error { using std::runtime_error::runtime_error; };
 
+// The counts of a parsed batch -> the 32-bit device buffer the operators read.  A 16-bit batch (every count fits: the
+// usual case) crosses the bus at half the size and is widened on the device; `stage16` is a reusable device scratch.
+struct CountsUpload {
+    uint16_t *stage16 = nullptr;
+    size_t cap16 = 0;
+    ~CountsUpload() { if (stage16) (void)hipFree(stage16); }
+    void operator()(Ctx &gpu, const SyncBatch &sb, uint32_t *counts_dev) {
+        auto hip_ok = [](hipError_t e, const char *what) {
+            if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+        };
+        if (!sb.counts16) {
+            hip_ok(hipMemcpyAsync(counts_dev, sb.counts, sb.counts_bytes(), hipMemcpyHostToDevice, nullptr), "H2D counts");
+            return;
+        }
+        if (sb.counts_bytes() > cap16) {
+            if (stage16) hip_ok(hipFree(stage16), "free");
+            stage16 = nullptr;
+            cap16 = sb.counts_bytes() + sb.counts_bytes() / 8;
+            hip_ok(hipMalloc((void **)&stage16, cap16), "device memory for the compact counts");
+        }
+        hip_ok(hipMemcpyAsync(stage16, sb.counts16, sb.counts_bytes(), hipMemcpyHostToDevice, nullptr), "H2D counts");
+        gpu.ok(pg_expand_counts_u16_dev(gpu.c, stage16, (int64_t)sb.L * sb.n * 6, counts_dev), "expand counts");
+    }
+};
+
 static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap, size_t chunk_bytes, bool is_pileup,
                                 const PileupFilter &pf, const pg_filter &flt) {
     auto hip_ok = [](hipError_t e, const char *what) {
@@ -234,7 +259,7 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
     auto parse_piece = [&](int c) {
         const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
         return is_pileup ? parse_pileup_buffer(b, e, a.n_threads, pf, alloc_for(c & 1))
-                         : parse_sync_buffer(b, e, a.n_threads, n, alloc_for(c & 1));
+                         : parse_sync_buffer(b, e, a.n_threads, n, alloc_for(c & 1), true);
     };
     std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, 0);
     std::vector<double *> Gs;
@@ -248,12 +273,17 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
     hip_ok(hipMalloc((void **)&S_dev, sizeof(double) * n2 * n2), "device memory");
     uint32_t *counts_dev = nullptr;
     size_t counts_cap = 0;
+    CountsUpload upload;
     std::string last_chrom;
     uint64_t last_pos = 0;
     bool have_last = false;
+    double t_wait = 0, t_host = 0, t_gpu = 0; // PGH_TIMING: waiting for the parser | host bookkeeping | copy + device work
+    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int c = 0; c < nchunks; ++c) {
+        double t0 = clk();
         SyncBatch sb = next.get();
         if (c + 1 < nchunks) next = std::async(std::launch::async, parse_piece, c + 1);
+        t_wait += clk() - t0; t0 = clk();
         if (sb.L == 0) continue;
         if (sb.n != n) throw std::runtime_error("the number of pools in the input and in the phenotype file differ");
         for (int64_t l = 0; l < sb.L; ++l) { // sortedness, within and across pieces
@@ -267,12 +297,14 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
             } else { last_chrom = ch; have_last = true; }
             last_pos = sb.pos[l];
         }
-        if (sb.counts_bytes() > counts_cap) {
+        t_host += clk() - t0; t0 = clk();
+        const size_t bytes32 = sizeof(uint32_t) * (size_t)sb.L * n * 6;
+        if (bytes32 > counts_cap) {
             if (counts_dev) hip_ok(hipFree(counts_dev), "free");
-            counts_cap = sb.counts_bytes() + sb.counts_bytes() / 8;
+            counts_cap = bytes32 + bytes32 / 8;
             hip_ok(hipMalloc((void **)&counts_dev, counts_cap), "device memory for the counts");
         }
-        hip_ok(hipMemcpyAsync(counts_dev, sb.counts, sb.counts_bytes(), hipMemcpyHostToDevice, nullptr), "H2D counts");
+        upload(gpu, sb, counts_dev);
         int64_t pc = 0;
         gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, sb.L, n, ph.pool_sizes.data(), &flt, a.keep_p_minus_1 ? 1 : 0, nullptr, &pc), "load");
         if (pc == 0) continue;
@@ -288,6 +320,7 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
         hip_ok(hipMemcpy(col_locus.data(), col_locus_dev, sizeof(int64_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
         hip_ok(hipMemcpy(col_allele.data(), col_allele_dev, sizeof(int32_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
         (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
+        t_gpu += clk() - t0; t0 = clk();
         std::vector<int32_t> remap(sb.chrom_names.size());
         for (size_t i = 0; i < sb.chrom_names.size(); ++i) {
             int g = -1;
@@ -300,12 +333,16 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
             lab_pos.push_back(sb.pos[col_locus[q]]);
             lab_al.push_back(ALLELES[col_allele[q]]);
         }
+        t_host += clk() - t0; t0 = clk();
         gpu.ok(pg_kinship_partial_dev(gpu.c, G, pc, n2, ld, S_dev), "kinship");
         hip_ok(hipMemcpy(S_piece.data(), S_dev, sizeof(double) * n2 * n2, hipMemcpyDeviceToHost), "D2H kinship");
         for (size_t i = 0; i < S_total.size(); ++i) S_total[i] += S_piece[i];
         Gs.push_back(G);
         ps.push_back(pc);
+        t_gpu += clk() - t0;
     }
+    if (std::getenv("PGH_TIMING"))
+        std::fprintf(stderr, "poolgen: pieces: waited for the parser %.3f s, host bookkeeping %.3f s, copies + device %.3f s\n", t_wait, t_host, t_gpu);
     if (counts_dev) (void)hipFree(counts_dev);
     for (auto &sl : slot) if (sl.p) (void)hipHostFree(sl.p);
     lap("pieces: parse | H2D + loader + partial kinship");
@@ -523,7 +560,9 @@ static int run(int argc, char **argv) {
         sb = parse_pileup_file(a.fname, a.n_threads, pf, pinned);
         lap("pileup -> counts");
     } else {
-        sb = parse_sync_file(a.fname, a.n_threads, pinned);
+        // the analyses on the loaded matrix copy the counts themselves: 16-bit counts when they fit (the batch operators'
+        // host-buffer entry points take the 32-bit layout)
+        sb = parse_sync_file(a.fname, a.n_threads, pinned, known.at(a.analysis) >= 3);
         lap("parse sync");
     }
     if (sb.size() == 0) throw std::runtime_error("no loci in " + a.fname);
@@ -628,9 +667,10 @@ static int run(int argc, char **argv) {
     };
     uint32_t *counts_dev = nullptr;
     int64_t *order_dev = nullptr;
-    hip_ok(hipMalloc((void **)&counts_dev, sb.counts_bytes()), "device memory for the counts");
+    hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * (size_t)L * n * 6), "device memory for the counts");
     hip_ok(hipMalloc((void **)&order_dev, sizeof(int64_t) * L), "device memory");
-    hip_ok(hipMemcpy(counts_dev, sb.counts, sb.counts_bytes(), hipMemcpyHostToDevice), "H2D counts");
+    CountsUpload upload;
+    upload(gpu, sb, counts_dev);
     hip_ok(hipMemcpy(order_dev, order.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice), "H2D order");
     int64_t p = 0;
     const bool kpm1 = mode == 7 ? false : a.keep_p_minus_1; // heterozygosity: "we need all alleles in each locus" (main.rs:445)

@@ -1497,6 +1497,41 @@ extern "C" int pg_chisq_batch(pg_ctx *ctx, const uint32_t *counts, int64_t L, in
                                        allele_ids, nullptr, chi2, pval);
 }
 
+namespace {
+// 16-bit counts (what the host parser stores when every count fits) -> the 32-bit device layout; 8 values per thread
+__global__ __launch_bounds__(256) void k_expand_u16(const uint4_t *__restrict__ src, uint4_t *__restrict__ dst, int64_t n8,
+                                                    const uint16_t *__restrict__ src_tail, uint32_t *__restrict__ dst_tail,
+                                                    int ntail) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n8) {
+        const uint4_t v = src[i];
+        uint4_t a, b;
+        a.x = v.x & 0xFFFFu; a.y = v.x >> 16; a.z = v.y & 0xFFFFu; a.w = v.y >> 16;
+        b.x = v.z & 0xFFFFu; b.y = v.z >> 16; b.z = v.w & 0xFFFFu; b.w = v.w >> 16;
+        dst[2 * i] = a;
+        dst[2 * i + 1] = b;
+    }
+    if (i == 0)
+        for (int t = 0; t < ntail; ++t) dst_tail[t] = src_tail[t];
+}
+} // namespace
+
+extern "C" int pg_expand_counts_u16_dev(pg_ctx *ctx, const uint16_t *src_dev, int64_t n_values, uint32_t *dst_dev) {
+    if (!ctx) return PG_ERR_INVALID;
+    PG_CHECK(ctx, src_dev && dst_dev && n_values >= 0, "expand_counts: bad arguments");
+    PG_CHECK(ctx, (reinterpret_cast<uintptr_t>(src_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_dev) & 15) == 0,
+             "expand_counts: buffers must be 16-byte aligned");
+    if (n_values == 0) return PG_OK;
+    PG_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n8 = n_values / 8;
+    const int ntail = (int)(n_values - 8 * n8);
+    const int64_t blocks = std::max<int64_t>(1, (n8 + 255) / 256);
+    hipLaunchKernelGGL(k_expand_u16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4_t *>(src_dev),
+                       reinterpret_cast<uint4_t *>(dst_dev), n8, src_dev + 8 * n8, dst_dev + 8 * n8, ntail);
+    PG_HIP(ctx, hipGetLastError());
+    return PG_OK;
+}
+
 extern "C" int pg_load_plan_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const double *pool_sizes,
                                 const pg_filter *filter, int keep_p_minus_1, const int64_t *order_dev, int64_t *p_out) {
     if (!ctx) return PG_ERR_INVALID;

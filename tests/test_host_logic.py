@@ -101,3 +101,20 @@ def test_seeded_k_split_matches_restatement():
         assert [int(x) for x in out] == [kk] + g
     r = subprocess.run([str(HC), "ksplit", "10", "10", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "number of splits" in r.stderr
+
+
+def test_sync_parser_16_bit_counts(tmp_path):
+    """The compact form of the counts (what the kinship paths copy to the GPU): same numbers, and a count above 65535
+    anywhere in the input sends the whole batch back to 32 bits."""
+    small = "".join("chr%d\t%d\tN\t%d:%d:0:0:0:%d\t7:65535:0:1:0:0\t0:0:0:0:0:0\n" % (1 + i // 40, 10 + i, i, 3 * i, i % 5) for i in range(100))
+    p = tmp_path / "s.sync"; p.write_text(small)
+    for threads in (1, 3):
+        a = run("parse", p, threads).splitlines()
+        b = run("parse", p, threads, 16).splitlines()
+        assert b[0] == a[0] + " 16" and b[1:] == a[1:]
+    big = small + "chr9\t5\tN\t1:2:3:4:5:6\t65536:0:0:0:0:0\t1:1:1:1:1:1\n" + small.replace("chr", "chs")
+    p.write_text(big)
+    for threads in (1, 4):
+        a = run("parse", p, threads).splitlines()
+        b = run("parse", p, threads, 16).splitlines()
+        assert b[0] == a[0] + " 32" and b[1:] == a[1:]
