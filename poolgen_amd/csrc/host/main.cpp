@@ -389,6 +389,145 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
     return done_ok();
 }
 
+// chisq_test / pearson_corr / ols_iter (main.rs:245-271): the per-locus operators know nothing beyond their own line, so
+// the file is taken in pieces whatever its size -- the worker threads parse piece c + 1 into one of two pinned buffers
+// (16-bit counts when they fit) while the GPU takes piece c and its rows are formatted and appended, in file order
+// (sync.rs:927-946).  Nothing of the size of the input is ever allocated, pinned or copied in one go.
+static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap, int mode, size_t chunk_bytes, bool is_pileup,
+                              const PileupFilter &pf, const pg_filter &flt) {
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    };
+    const MappedFile mf(a.fname);
+    const std::vector<size_t> cuts = mf.cuts(std::max<size_t>(1, (mf.size() + chunk_bytes - 1) / chunk_bytes));
+    const int nchunks = (int)cuts.size() - 1;
+    const int n = ph.n, k = ph.k;
+    std::string out = a.output;
+    if (out.empty()) out = basename_no_ext(a.fname) + "-" + unix_time_string() + "-" + a.analysis + ".csv"; // sync.rs:903
+    { FILE *t = create_new(out); fclose(t); ::unlink(out.c_str()); } // probe, as the reference does before any work (sync.rs:906)
+    // ols_iter drops the pools without phenotype first (ols.rs:206); pearson_corr keeps every pool (pairwise-complete inside)
+    std::vector<int> keep(n);
+    std::iota(keep.begin(), keep.end(), 0);
+    std::vector<double> Y = ph.phen, ps = ph.pool_sizes;
+    if (mode == 2) {
+        keep = complete_pools(ph);
+        if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
+        if ((int)keep.size() != n) {
+            std::cerr << "warning: " << n - keep.size() << " pools without phenotype removed (pool sizes subset accordingly)\n";
+            Y.clear(); ps.clear();
+            for (int i : keep) { ps.push_back(ph.pool_sizes[i]); for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]); }
+        }
+    }
+    const int n2 = (int)keep.size();
+    const bool subset = n2 != n;
+    struct Slot { void *p = nullptr; size_t cap = 0; } slot[2];
+    auto alloc_for = [&](int i) {
+        SyncAlloc al;
+        al.alloc = [&slot, i](size_t bytes) -> void * {
+            if (bytes > slot[i].cap) {
+                if (slot[i].p) (void)hipHostFree(slot[i].p);
+                slot[i].p = nullptr; slot[i].cap = 0;
+                const size_t want = bytes + bytes / 8;
+                if (hipHostMalloc(&slot[i].p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+                slot[i].cap = want;
+            }
+            return slot[i].p;
+        };
+        al.release = [](void *) {};
+        return al;
+    };
+    auto parse_piece = [&](int c) {
+        const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
+        return is_pileup ? parse_pileup_buffer(b, e, a.n_threads, pf, alloc_for(c & 1))
+                         : parse_sync_buffer(b, e, a.n_threads, 0, alloc_for(c & 1), !subset);
+    };
+    std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, 0);
+    FILE *fo = nullptr;
+    uint32_t *counts_dev = nullptr;
+    int32_t *n_out_dev = nullptr, *ids_dev = nullptr;
+    double *mf_dev = nullptr, *stat_dev = nullptr, *pv_dev = nullptr;
+    int64_t cap_loci = 0;
+    CountsUpload upload;
+    std::vector<uint32_t> counts2;
+    std::vector<int32_t> n_out, ids;
+    std::vector<double> mfq, stat, pv;
+    const size_t per_stat = mode == 0 ? 1 : (size_t)PG_MAX_OUT * k;
+    int64_t total = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        SyncBatch sb = next.get();
+        if (c + 1 < nchunks) next = std::async(std::launch::async, parse_piece, c + 1);
+        if (sb.L == 0) continue;
+        if (sb.n != n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
+        const int64_t L = sb.L;
+        total += L;
+        if (L > cap_loci) {
+            for (void *q : {(void *)counts_dev, (void *)n_out_dev, (void *)ids_dev, (void *)mf_dev, (void *)stat_dev, (void *)pv_dev})
+                if (q) (void)hipFree(q);
+            cap_loci = L + L / 8;
+            hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * (size_t)cap_loci * n * 6), "device memory for the counts");
+            hip_ok(hipMalloc((void **)&n_out_dev, sizeof(int32_t) * cap_loci), "device memory");
+            hip_ok(hipMalloc((void **)&ids_dev, sizeof(int32_t) * cap_loci * PG_MAX_OUT), "device memory");
+            hip_ok(hipMalloc((void **)&mf_dev, sizeof(double) * cap_loci * PG_MAX_OUT), "device memory");
+            hip_ok(hipMalloc((void **)&stat_dev, sizeof(double) * cap_loci * per_stat), "device memory");
+            hip_ok(hipMalloc((void **)&pv_dev, sizeof(double) * cap_loci * per_stat), "device memory");
+        }
+        if (subset) { // rare: drop the pools without phenotype on the host (32-bit counts), then one copy
+            counts2.resize((size_t)L * n2 * 6);
+            for (int64_t l = 0; l < L; ++l)
+                for (int i = 0; i < n2; ++i) std::memcpy(&counts2[((size_t)l * n2 + i) * 6], &sb.counts[((size_t)l * n + keep[i]) * 6], 24);
+            hip_ok(hipMemcpy(counts_dev, counts2.data(), sizeof(uint32_t) * counts2.size(), hipMemcpyHostToDevice), "H2D counts");
+        } else
+            upload(gpu, sb, counts_dev);
+        if (mode == 0)
+            gpu.ok(pg_chisq_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, n_out_dev, ids_dev, stat_dev, pv_dev), "chisq_test");
+        else if (mode == 1)
+            gpu.ok(pg_pearson_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, Y.data(), k, n_out_dev, ids_dev, mf_dev, stat_dev, pv_dev),
+                   "pearson_corr");
+        else
+            gpu.ok(pg_ols_iter_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, Y.data(), k, n_out_dev, ids_dev, mf_dev, stat_dev, pv_dev),
+                   "ols_iter");
+        n_out.resize(L); ids.resize((size_t)L * PG_MAX_OUT); mfq.resize((size_t)L * PG_MAX_OUT);
+        stat.resize((size_t)L * per_stat); pv.resize((size_t)L * per_stat);
+        hip_ok(hipMemcpy(n_out.data(), n_out_dev, sizeof(int32_t) * L, hipMemcpyDeviceToHost), "D2H results");
+        hip_ok(hipMemcpy(ids.data(), ids_dev, sizeof(int32_t) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
+        if (mode != 0) hip_ok(hipMemcpy(mfq.data(), mf_dev, sizeof(double) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
+        hip_ok(hipMemcpy(stat.data(), stat_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
+        hip_ok(hipMemcpy(pv.data(), pv_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
+        if (!fo) {
+            fo = create_new(out);
+            fputs(mode == 0 ? "#chr,pos,alleles,statistic,pvalue\n"                 // sync.rs:766
+                            : "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n", fo); // sync.rs:950
+        }
+        write_rows_parallel(fo, L, a.n_threads, [&](int64_t l, std::string &line) {
+            if (n_out[l] <= 0) return;
+            if (mode == 0) { // chisq_test.rs:37-45
+                std::string al;
+                for (int j = 0; j < n_out[l] && j < PG_MAX_OUT; ++j) al.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + j]]);
+                line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + al + "," + roundup_own(stat[l], 6) + "," +
+                        rust_display(pv[l]) + "\n";
+            } else {
+                for (int i = 0; i < n_out[l]; ++i)
+                    for (int j = 0; j < k; ++j) {
+                        const size_t e = ((size_t)l * PG_MAX_OUT + i) * k + j;
+                        const double f = mfq[(size_t)l * PG_MAX_OUT + i];
+                        line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + ALLELES[ids[(size_t)l * PG_MAX_OUT + i]] + ",";
+                        if (mode == 2) // ols.rs:263-271
+                            line += roundup_own(f, 8) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
+                                    roundup_own(pv[e], 12) + "\n";
+                        else // correlation_test.rs:117-124
+                            line += rust_display(f) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
+                                    rust_display(pv[e]) + "\n";
+                    }
+            }
+        });
+    }
+    if (total == 0) throw std::runtime_error("no loci in " + a.fname);
+    fclose(fo);
+    lap("pieces: parse | H2D + operator + D2H + format + write");
+    std::cout << out << "\n"; // main.rs:507
+    return done_ok();
+}
+
 // fst (popgen/fst.rs:10-261) and heterozygosity = pi (popgen/pi.rs:115-190) on the loaded matrix: loci and windows on
 // the host (count_loci, define_sliding_windows), the per-locus arithmetic and the means on the GPU, the files as written
 // by the reference.
@@ -555,6 +694,11 @@ static int run(int argc, char **argv) {
             }
         }
     }
+    if (known.at(a.analysis) <= 2) {
+        size_t piece = (size_t)(a.stream_chunk_mb > 0 ? a.stream_chunk_mb : 128) << 20;
+        if (const char *e = std::getenv("PGH_STREAM_CHUNK_BYTES")) piece = (size_t)std::strtoull(e, nullptr, 10); // tests: small pieces
+        return run_batch_streamed(a, ph, gpu, lap, known.at(a.analysis), piece, is_pileup, pf, flt);
+    }
     SyncBatch sb;
     if (is_pileup) {
         sb = parse_pileup_file(a.fname, a.n_threads, pf, pinned);
@@ -570,80 +714,6 @@ static int run(int argc, char **argv) {
     const int n = sb.n, k = ph.k;
     const int64_t L = sb.size();
     const int mode = known.at(a.analysis);
-
-    if (mode <= 2) {
-        std::string out = a.output;
-        if (out.empty()) out = basename_no_ext(a.fname) + "-" + unix_time_string() + "-" + a.analysis + ".csv"; // sync.rs:903
-        // probe, as the reference does before any work (sync.rs:906)
-        { FILE *t = create_new(out); fclose(t); ::unlink(out.c_str()); }
-        std::vector<int32_t> n_out(L), ids((size_t)L * PG_MAX_OUT);
-        std::vector<double> mf((size_t)L * PG_MAX_OUT), stat, pv;
-        std::string header;
-        if (mode == 0) {
-            stat.resize(L); pv.resize(L);
-            gpu.ok(pg_chisq_batch(gpu.c, sb.counts, L, n, ph.pool_sizes.data(), &flt, n_out.data(), ids.data(),
-                                  stat.data(), pv.data()), "chisq_test");
-            header = "#chr,pos,alleles,statistic,pvalue\n"; // sync.rs:766
-        } else {
-            // pearson_corr keeps every pool (pairwise-complete inside); ols_iter drops incomplete pools first
-            std::vector<uint32_t> counts2;
-            std::vector<double> Y = ph.phen, ps = ph.pool_sizes;
-            int n2 = n;
-            const uint32_t *cptr = sb.counts;
-            if (mode == 2) {
-                const std::vector<int> keep = complete_pools(ph);
-                if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
-                if ((int)keep.size() != n) {
-                    std::cerr << "warning: " << n - keep.size() << " pools without phenotype removed (pool sizes subset accordingly)\n";
-                    n2 = (int)keep.size();
-                    counts2.resize((size_t)L * n2 * 6);
-                    for (int64_t l = 0; l < L; ++l)
-                        for (int i = 0; i < n2; ++i)
-                            std::memcpy(&counts2[((size_t)l * n2 + i) * 6], &sb.counts[((size_t)l * n + keep[i]) * 6], 24);
-                    Y.clear(); ps.clear();
-                    for (int i : keep) { ps.push_back(ph.pool_sizes[i]); for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]); }
-                    cptr = counts2.data();
-                }
-            }
-            stat.resize((size_t)L * PG_MAX_OUT * k); pv.resize((size_t)L * PG_MAX_OUT * k);
-            if (mode == 1)
-                gpu.ok(pg_pearson_batch(gpu.c, cptr, L, n2, ps.data(), &flt, Y.data(), k, n_out.data(), ids.data(),
-                                        mf.data(), stat.data(), pv.data()), "pearson_corr");
-            else
-                gpu.ok(pg_ols_iter_batch(gpu.c, cptr, L, n2, ps.data(), &flt, Y.data(), k, n_out.data(), ids.data(),
-                                         mf.data(), stat.data(), pv.data()), "ols_iter");
-            header = "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n"; // sync.rs:950
-        }
-        lap("GPU operator (incl. H2D/D2H)");
-        FILE *fo = create_new(out);
-        fputs(header.c_str(), fo);
-        write_rows_parallel(fo, L, a.n_threads, [&](int64_t l, std::string &line) {
-            if (n_out[l] <= 0) return;
-            if (mode == 0) { // chisq_test.rs:37-45
-                std::string al;
-                for (int j = 0; j < n_out[l] && j < PG_MAX_OUT; ++j) al.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + j]]);
-                line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + al + "," + roundup_own(stat[l], 6) + "," +
-                        rust_display(pv[l]) + "\n";
-            } else {
-                for (int i = 0; i < n_out[l]; ++i)
-                    for (int j = 0; j < k; ++j) {
-                        const size_t e = ((size_t)l * PG_MAX_OUT + i) * k + j;
-                        const double f = mf[(size_t)l * PG_MAX_OUT + i];
-                        line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + ALLELES[ids[(size_t)l * PG_MAX_OUT + i]] + ",";
-                        if (mode == 2) // ols.rs:263-271
-                            line += roundup_own(f, 8) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
-                                    roundup_own(pv[e], 12) + "\n";
-                        else // correlation_test.rs:117-124
-                            line += rust_display(f) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
-                                    rust_display(pv[e]) + "\n";
-                    }
-            }
-        });
-        fclose(fo);
-        lap("format + write CSV");
-        std::cout << out << "\n"; // main.rs:507
-        return done_ok();
-    }
 
     // ---------------- ols_iter_with_kinship (main.rs:280-298) -------------------------------------
     // load(): filter + frequencies per locus, then sort by (chromosome, position) (sync.rs:1092-1101).  The
