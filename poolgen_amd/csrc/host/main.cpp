@@ -675,14 +675,14 @@ static int run(int argc, char **argv) {
     flt.min_allele_frequency = a.min_allele_frequency;
     flt.max_missingness_rate = a.max_missingness_rate;
     if (a.analysis == "ols_iter_with_kinship") {
-        // inputs above 1 GiB are taken in pieces of 256 MiB of text (parse of piece c + 1 overlaps the GPU work on
+        // inputs above 256 MiB are taken in pieces of 128 MiB of text, above 1 GiB in pieces of 256 MiB (parse of piece c + 1 overlaps the GPU work on
         // piece c, and the pinned buffers stay small); an unsorted input falls back to the whole-file path unless
         // the pieces were asked for explicitly
         struct stat st;
         const size_t fsize = ::stat(a.fname.c_str(), &st) == 0 ? (size_t)st.st_size : 0;
         const bool automatic = a.stream_chunk_mb < 0 && !std::getenv("PGH_STREAM_CHUNK_BYTES");
         long mb = a.stream_chunk_mb;
-        if (mb < 0) mb = fsize > ((size_t)1 << 30) ? 256 : 0;
+        if (mb < 0) mb = fsize > ((size_t)1 << 30) ? 256 : (fsize > ((size_t)256 << 20) ? 128 : 0); // no whole-file pinned buffer beyond 256 MiB
         size_t piece = (size_t)(mb > 0 ? mb : 0) << 20;
         if (const char *e = std::getenv("PGH_STREAM_CHUNK_BYTES")) piece = (size_t)std::strtoull(e, nullptr, 10); // tests: small pieces
         if (piece > 0 && fsize > piece) {
