@@ -1,3 +1,5 @@
+#!/bin/bash
+# usage: tools/parse_exp.sh -- parser and CLI phase times on a 1.09 GB sync text (400 k loci x 200 pools), several thread counts
 d=/tmp/pg_px; rm -rf $d; mkdir -p $d
 python3 tools/gen_sync.py $d/base.sync $d/phen.csv 200 100000
 for i in 1 2 3 4; do cat $d/base.sync >> $d/big.sync; done
