@@ -1011,14 +1011,16 @@ extern "C" int pg_gp_proxy_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
     for (int a = 0; a < nr; ++a)
         for (int j = 0; j < k; ++j) { Ys[(size_t)a * k + j] = Y[(size_t)row_idx[a] * k + j]; ymean[j] += Ys[(size_t)a * k + j]; }
     for (int j = 0; j < k; ++j) ymean[j] /= (double)nr; // row 0 (:170-172)
-    // the training pools' columns, compacted (the sweep reads whole rows of pools)
-    const int64_t ld2 = nr + (nr & 1);
+    // the training pools' columns, compacted (the sweep reads whole rows of pools) -- unless they are all pools in order
+    bool identity = nr == n && (ld % 2) == 0 && (reinterpret_cast<uintptr_t>(G_dev) & 15) == 0;
+    for (int a = 0; a < nr && identity; ++a) identity = row_idx[a] == a;
+    const int64_t ld2 = identity ? ld : nr + (nr & 1);
     double *Gs = nullptr, *scratch = nullptr;
     int32_t *rows_dev = nullptr;
     std::vector<int32_t> rows32(nr);
     for (int a = 0; a < nr; ++a) rows32[a] = (int32_t)row_idx[a];
-    auto cleanup = [&] { (void)hipFree(Gs); (void)hipFree(scratch); (void)hipFree(rows_dev); };
-    if (hipMalloc((void **)&Gs, sizeof(double) * (size_t)p * ld2) != hipSuccess ||
+    auto cleanup = [&] { if (!identity) (void)hipFree(Gs); (void)hipFree(scratch); (void)hipFree(rows_dev); };
+    if ((!identity && hipMalloc((void **)&Gs, sizeof(double) * (size_t)p * ld2) != hipSuccess) ||
         hipMalloc((void **)&scratch, sizeof(double) * (size_t)p * k) != hipSuccess ||
         hipMalloc((void **)&rows_dev, sizeof(int32_t) * nr) != hipSuccess) {
         cleanup();
@@ -1028,8 +1030,10 @@ extern "C" int pg_gp_proxy_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
         cleanup();
         return pg_fail(ctx, PG_ERR_HIP, "gp_proxy: H2D failed");
     }
-    hipLaunchKernelGGL(k_gather_pools, dim3((unsigned)(((size_t)p * ld2 + 255) / 256)), dim3(256), 0, ctx->stream, G_dev, p, ld,
-                       rows_dev, nr, ld2, Gs);
+    if (identity) Gs = const_cast<double *>(G_dev);
+    else
+        hipLaunchKernelGGL(k_gather_pools, dim3((unsigned)(((size_t)p * ld2 + 255) / 256)), dim3(256), 0, ctx->stream, G_dev, p, ld,
+                           rows_dev, nr, ld2, Gs);
     int rc = pg_covariates_set(ctx, nr, ev.data(), 1, Ys.data(), k);
     if (rc == PG_OK) rc = pg_ols_sweep_dev(ctx, Gs, p, nr, ld2, proxy_dev + k, scratch, scratch);
     if (rc == PG_OK) {
