@@ -211,11 +211,13 @@ int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
  *                                          picked by the norms of pg_gp_proxy_dev's coefficients (fitted once on
  *                                          row_idx, :543, :656), the amounts by the fit's own norms (:262-283).
  * alphas_out[k] (host, optional), lambdas_out[k]; perf_out (optional) n_reps x n_folds x A x L x k, A = 1 or L.
- * With iterative_proxy the covariate state of ctx (pg_covariates_set / pg_kinship_set) is overwritten. */
+ * With iterative_proxy the covariate state of ctx (pg_covariates_set / pg_kinship_set) is overwritten.
+ * XXt_host_or_null: the full-data X X^T of pg_gp_xxt_dev (host, n x n) when the caller already has it -- a harness that
+ * fits many models on the same genotypes computes it once. */
 int pg_gp_penalised_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
                         int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
                         int n_folds, double alpha, int iterative_proxy, double lambda_step, double *beta_dev,
-                        double *alphas_out, double *lambdas_out, double *perf_out);
+                        double *alphas_out, double *lambdas_out, double *perf_out, const double *XXt_host_or_null);
 /* gp::ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199): proxy_dev (1+p) x k on the device, row 0 = the
  * trait means over the training pools, row 1+l = the locus coefficient of y ~ [1 | PC1 | g_l] on the training pools
  * (PC1: leading eigenvector of the reference's centred X X^T of those pools, :115-141, with its two indexing quirks:

@@ -60,7 +60,7 @@ SIGNATURES = {
     "pg_gp_xxt_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp]),
     "pg_gp_ols_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _vp]),
     "pg_gp_ridge_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _i, _i, _d, _d, _vp, _vp, _vp]),
-    "pg_gp_penalised_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _i, _i, _d, _i, _d, _vp, _vp, _vp, _vp]),
+    "pg_gp_penalised_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _i, _i, _d, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "pg_gp_proxy_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _vp, _vp]),
     "pg_expand_counts_u16_dev": (_i, [_vp, _vp, _i64, _vp]),
     "pg_load_emit_cov_dev": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),

@@ -95,7 +95,7 @@ std::string gp_cross_validate(pg_ctx *ctx, const double *G_dev, int64_t p, int n
         }
         std::vector<double> lam(m), al(m);
         ok(ctx, pg_gp_penalised_dev(ctx, G_dev, p, n, ld, Y.data(), m, rows.data(), nr, folds.data(), inner_reps, nf, models[mi].alpha,
-                                    models[mi].proxy, 0.1, beta_dev, al.data(), lam.data(), nullptr), models[mi].base);
+                                    models[mi].proxy, 0.1, beta_dev, al.data(), lam.data(), nullptr, xxt.data()), models[mi].base);
         name = std::string(models[mi].base) + "-alphas_";
         for (int j = 0; j < m; ++j) name += (j ? "_" : "") + rust_display(al[j]);
         name += "-lambdas_";

@@ -473,7 +473,7 @@ int ridge_path_params_cols(pg_ctx *ctx, const double *cols_dev, int64_t p, int n
 int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y, int k,
                    const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps, int n_folds, double alpha,
                    const double *proxy_dev, double lambda_step, double *beta_dev, double *alphas_out, double *lambdas_out,
-                   double *perf_out) {
+                   double *perf_out, const double *xxt_host_or_null) {
     const int maxu = (int)std::llround(1.0 / lambda_step);
     const int L = maxu + 1;
     PG_CHECK(ctx, L <= GP_LMAX, "gp_ridge: at most %d lambdas on the path", GP_LMAX);
@@ -485,7 +485,8 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
 
     // the full-data X X^T once; every training subset uses a principal sub-block
     std::vector<double> xxt((size_t)n * n);
-    {
+    if (xxt_host_or_null) std::memcpy(xxt.data(), xxt_host_or_null, sizeof(double) * (size_t)n * n);
+    else {
         if (ctx->S_n < n) {
             PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->S_dev) PG_HIP(ctx, hipFree(ctx->S_dev));
@@ -759,13 +760,13 @@ extern "C" int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int 
              "gp_ridge: bad shape");
     PG_CHECK(ctx, alpha >= 0.0 && alpha <= 1.0 && lambda_step > 0.0 && lambda_step <= 1.0, "gp_ridge: bad alpha / lambda step");
     return penalised_path(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, fold_of, n_reps, n_folds, alpha, nullptr, lambda_step,
-                          beta_dev, nullptr, lambdas_out, perf_out);
+                          beta_dev, nullptr, lambdas_out, perf_out, nullptr);
 }
 
 extern "C" int pg_gp_penalised_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
                                    int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
                                    int n_folds, double alpha, int iterative_proxy, double lambda_step, double *beta_dev,
-                                   double *alphas_out, double *lambdas_out, double *perf_out) {
+                                   double *alphas_out, double *lambdas_out, double *perf_out, const double *XXt_host_or_null) {
     if (!ctx) return PG_ERR_INVALID;
     PG_CHECK(ctx, G_dev && Y && row_idx && fold_of && beta_dev && lambdas_out, "gp_penalised: null pointer");
     PG_CHECK(ctx, p > 0 && n >= 3 && k >= 1 && k <= 8 && n_rows >= 3 && n_rows <= n && n_reps >= 1 && n_folds >= 2,
@@ -775,11 +776,11 @@ extern "C" int pg_gp_penalised_dev(pg_ctx *ctx, const double *G_dev, int64_t p, 
     if (iterative_proxy) { // the same proxy serves every fold and the final fit (:543, :656: always on `row_idx`)
         PG_HIP(ctx, hipSetDevice(ctx->device));
         PG_HIP(ctx, hipMalloc((void **)&proxy, sizeof(double) * (size_t)(p + 1) * k));
-        const int rc = pg_gp_proxy_dev(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, nullptr, proxy);
+        const int rc = pg_gp_proxy_dev(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, XXt_host_or_null, proxy);
         if (rc) { (void)hipFree(proxy); return rc; }
     }
     const int rc = penalised_path(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, fold_of, n_reps, n_folds, alpha, proxy, lambda_step,
-                                  beta_dev, alphas_out, lambdas_out, perf_out);
+                                  beta_dev, alphas_out, lambdas_out, perf_out, XXt_host_or_null);
     if (proxy) (void)hipFree(proxy);
     return rc;
 }

@@ -313,7 +313,7 @@ class Engine:
         return yhat
 
     def gp_penalised(self, G: torch.Tensor, Y, row_idx, fold_of, n_folds: int, alpha: float, iterative_proxy: bool = False,
-                     lambda_step: float = 0.1, n: int | None = None):
+                     lambda_step: float = 0.1, n: int | None = None, XXt=None):
         """Every model behind penalised_lambda_path_with_k_fold_cross_validation (gp/penalise.rs:461-669): alpha in
         [0, 1] one lambda path, alpha < 0 the alpha x lambda grid of penalise_glmnet, iterative_proxy the
         *_with_iterative_proxy_norms variants.  Returns (beta (1+p) x k on the device, alphas[k], lambdas[k],
@@ -328,10 +328,12 @@ class Engine:
         beta = torch.empty((p + 1, k), dtype=torch.float64, device=G.device)
         al, lam = np.empty(k), np.empty(k)
         perf = np.empty((fo.shape[0], n_folds, A, L, k))
+        xh = None if XXt is None else _host_f64(XXt)   # kept alive across the call
         self._check(self._lib.pg_gp_penalised_dev(self._ctx, self._dev(G, torch.float64), p, n, ld, Yh.ctypes.data, k,
                                                   ri.ctypes.data, len(ri), fo.ctypes.data, fo.shape[0], int(n_folds),
                                                   float(alpha), int(bool(iterative_proxy)), float(lambda_step),
-                                                  beta.data_ptr(), al.ctypes.data, lam.ctypes.data, perf.ctypes.data),
+                                                  beta.data_ptr(), al.ctypes.data, lam.ctypes.data, perf.ctypes.data,
+                                                  None if xh is None else xh.ctypes.data),
                     "pg_gp_penalised_dev")
         return beta, al, lam, perf
 

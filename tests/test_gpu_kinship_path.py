@@ -267,6 +267,9 @@ def test_gp_penalised_family_matches_oracle(engine, oracle, n, p, k, alpha, prox
     finally:
         del os.environ["POOLGEN_RIDGE_PER_FOLD"]
     assert np.allclose(perf2, perf, rtol=1e-9, atol=1e-12) and np.array_equal(lam2, lam) and np.array_equal(al2, al)
+    # and the caller's own X X^T (the CV harness computes it once for all its fits) changes nothing
+    beta3, al3, lam3, perf3 = engine.gp_penalised(G, Y, rows, folds, n_folds, alpha, proxy, n=n, XXt=engine.gp_xxt(G, n).cpu().numpy())
+    assert np.array_equal(perf3, perf) and np.array_equal(beta3.cpu().numpy(), beta.cpu().numpy())
 
 
 @pytest.mark.parametrize("n,p,k,n_folds", [(80, 1500, 2, 10), (40, 900, 2, 10), (120, 2500, 1, 16), (300, 4000, 1, 10)])
