@@ -417,8 +417,11 @@ __global__ __launch_bounds__(256) void k_gp_reduce_parts(const double *__restric
 int ridge_path_params_cols(pg_ctx *ctx, const double *cols_dev, int64_t p, int ncols, int k, double alpha,
                            const std::vector<double> &path, RidgeWork &W, const double *proxy_dev, const std::vector<int> &skip,
                            std::vector<PathParams> &out) {
-    const int nb = 1024, width = 4 * GP_LMAX;
-    double *red = W.part + (size_t)ncols * nb * width; // room reserved by the caller
+    // blocks per column: enough to fill the chip on a long column, few on a short one (every block's 64 partial sums are
+    // cleared, written and reduced again: at p = 2e5 that overhead was most of the mass step)
+    const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(32, p / 2048));
+    const int width = 4 * GP_LMAX;
+    double *red = W.part + (size_t)ncols * nb * width; // room reserved by the caller (sized for nb = 1024)
     std::vector<double> h((size_t)ncols * width);
     out.assign(ncols, PathParams{});
     PG_HIP(ctx, hipMemsetAsync(W.part, 0, sizeof(double) * (size_t)ncols * nb * width, ctx->stream)); // skipped columns reduce to 0
