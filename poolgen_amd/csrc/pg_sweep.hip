@@ -514,7 +514,7 @@ extern "C" int pg_covariates_set(pg_ctx *ctx, int n, const double *Cmat, int m, 
         PG_HIP(ctx, hipMalloc((void **)&ctx->W_dev, wbytes));
         ctx->W_cap = wbytes;
     }
-    if (!ctx->syy_dev) PG_HIP(ctx, hipMalloc((void **)&ctx->syy_dev, sizeof(double) * 64));
+    if (!ctx->syy_dev) PG_HIP(ctx, hipMalloc((void **)&ctx->syy_dev, sizeof(double) * 66));
     PG_CHECK(ctx, k <= 64, "covariates: at most 64 traits per call");
     PG_HIP(ctx, hipMemcpyAsync(ctx->W_dev, W.data(), wbytes, hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(ctx->syy_dev, syy.data(), sizeof(double) * k, hipMemcpyHostToDevice,
@@ -544,6 +544,24 @@ extern "C" int pg_covariates_set(pg_ctx *ctx, int n, const double *Cmat, int m, 
     return PG_OK;
 }
 
+namespace {
+// sum of all entries and trace of S (n x n): what the first fast exit of the n_eigenvecs rule needs, without the matrix
+// crossing the bus.  One workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void k_sum_trace(const double *__restrict__ S, int n, double *__restrict__ out) {
+    __shared__ double sm[2][1024];
+    double tot = 0.0, tr = 0.0;
+    for (int i = threadIdx.x; i < n * n; i += 1024) tot += S[i];
+    for (int i = threadIdx.x; i < n; i += 1024) tr += S[(size_t)i * n + i];
+    sm[0][threadIdx.x] = tot; sm[1][threadIdx.x] = tr;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) { sm[0][threadIdx.x] += sm[0][threadIdx.x + off]; sm[1][threadIdx.x] += sm[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sm[0][0]; out[1] = sm[1][0]; }
+}
+} // namespace
+
 extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total, int n,
                               const double *Y, int k, double var_explained, int force_m, int *m_out,
                               double *K_out, double *evals_out) {
@@ -553,8 +571,24 @@ extern "C" int pg_kinship_set(pg_ctx *ctx, const double *S_dev, int64_t p_total,
     std::vector<double> K((size_t)n * n), ev(n), V;
     {
         // through the context's pinned buffer: a D2H into pageable memory is staged by the runtime
-        int prc = pg_pin_reserve(ctx, sizeof(double) * (size_t)n * n);
+        int prc = pg_pin_reserve(ctx, sizeof(double) * ((size_t)n * n + 2));
         if (prc) return prc;
+        if (force_m < 0 && !evals_out && !K_out) {
+            // the common outcome (m = 0 by the Rayleigh quotient of the ones vector, see below) is decided from two numbers
+            // formed on the device; only when that test does not settle it does the matrix come over
+            if (!ctx->syy_dev) PG_HIP(ctx, hipMalloc((void **)&ctx->syy_dev, sizeof(double) * 66));
+            double *two = ctx->syy_dev + 64; // behind the 64 trait slots
+            hipLaunchKernelGGL(k_sum_trace, dim3(1), dim3(1024), 0, ctx->stream, S_dev, n, two);
+            PG_HIP(ctx, hipGetLastError());
+            double *hp = static_cast<double *>(ctx->pin) + (size_t)n * n;
+            PG_HIP(ctx, hipMemcpyAsync(hp, two, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+            PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const double tot = hp[0], tr = hp[1];
+            if (tr > 0.0 && std::isfinite(tot) && (tot / n) / tr >= var_explained + 1e-9) {
+                if (m_out) *m_out = 0;
+                return pg_covariates_set(ctx, n, nullptr, 0, Y, k);
+            }
+        }
         PG_HIP(ctx, hipMemcpyAsync(ctx->pin, S_dev, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
         PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(K.data(), ctx->pin, sizeof(double) * (size_t)n * n);
