@@ -29,9 +29,24 @@ std::string rust_display(double x) {
     return std::string(buf, r.ptr);
 }
 
+void append_rust_display(std::string &out, double x) {
+    if (std::isnan(x)) { out += "NaN"; return; }
+    if (std::isinf(x)) { out += x > 0 ? "inf" : "-inf"; return; }
+    char buf[400];
+    auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::fixed);
+    out.append(buf, r.ptr);
+}
+
 double sensible_round(double x, int n_digits) {
-    const std::string e = "1e" + std::to_string(n_digits);
-    const double factor = std::strtod(e.c_str(), nullptr);
+    // 10^n: exact in binary64 up to n = 22, so the table equals what parsing "1e<n>" gives (the reference parses the string)
+    static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
+                                   1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    double factor;
+    if (n_digits >= 0 && n_digits <= 22) factor = P10[n_digits];
+    else {
+        const std::string e = "1e" + std::to_string(n_digits);
+        factor = std::strtod(e.c_str(), nullptr);
+    }
     return std::round(x * factor) / factor; // f64::round: half away from zero
 }
 

@@ -12,6 +12,7 @@ namespace pgh {
 
 // ---- formatting -------------------------------------------------------------------------------
 std::string rust_display(double x);                      // Rust `{}` for f64
+void append_rust_display(std::string &out, double x);    // the same, appended in place (no temporary)
 double sensible_round(double x, int n_digits);           // helpers.rs:103-108
 std::string roundup_own(double x, int n_digits);         // helpers.rs:111-117
 

@@ -162,7 +162,30 @@ static void write_rows_parallel(FILE *fo, int64_t count, int n_threads, F fn) {
                 for (int64_t i = lo; i < hi; ++i) fn(i, out);
             });
         for (auto &x : th) x.join();
-        for (const std::string &x : text) fwrite(x.data(), 1, x.size(), fo);
+        // every worker copies its own text into the file at its own offset: the page-cache copy of a sequential write() was
+        // the slower half of this phase
+        std::fflush(fo);
+        const int fd = fileno(fo);
+        off_t off = ftello(fo);
+        std::vector<off_t> at(parts);
+        for (int t = 0; t < parts; ++t) { at[t] = off; off += (off_t)text[t].size(); }
+        std::vector<int> failed(parts, 0);
+        th.clear();
+        for (int t = 0; t < parts; ++t)
+            th.emplace_back([&, t] {
+                const char *q = text[t].data();
+                size_t left = text[t].size();
+                off_t o = at[t];
+                while (left > 0) {
+                    const ssize_t w = ::pwrite(fd, q, left, o);
+                    if (w <= 0) { failed[t] = 1; return; }
+                    q += w; o += w; left -= (size_t)w;
+                }
+            });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < parts; ++t)
+            if (failed[t]) throw std::runtime_error("write failed (disk full?)");
+        fseeko(fo, off, SEEK_SET);
     }
 }
 
@@ -381,7 +404,9 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
         // coefficient i carries label i of the (1+p)-long vectors whose entry 0 is "intercept" (ols.rs:421-425)
         if (i == 0) text += "intercept,0,intercept";
         else { text += chrom_names[lab_chr[i - 1]]; text += ","; text += std::to_string(lab_pos[i - 1]); text += ","; text.push_back(lab_al[i - 1]); }
-        text += ",Pheno_" + std::to_string(j) + "," + rust_display(beta[(size_t)i * k + j]) + "," + rust_display(pval[(size_t)i * k + j]) + "\n";
+        text += ",Pheno_"; text += std::to_string(j); text.push_back(',');
+        append_rust_display(text, beta[(size_t)i * k + j]); text.push_back(',');
+        append_rust_display(text, pval[(size_t)i * k + j]); text.push_back('\n');
     });
     fclose(fo);
     lap("format + write CSV");
@@ -815,8 +840,10 @@ static int run(int argc, char **argv) {
         const int64_t j = r / p, i = r - j * p; // rows are trait-major (ols.rs:411-433)
         // the reference labels coefficient i with entry i of the (1+p)-long label vectors, i.e.
         // shifted by the intercept entry (ols.rs:421-425) -- reproduced as is
-        text += lab_chr[i] + "," + std::to_string(lab_pos[i]) + "," + lab_al[i] + ",Pheno_" + std::to_string(j) + "," +
-                rust_display(beta[(size_t)i * k + j]) + "," + rust_display(pval[(size_t)i * k + j]) + "\n";
+        text += lab_chr[i]; text.push_back(','); text += std::to_string(lab_pos[i]); text.push_back(','); text += lab_al[i];
+        text += ",Pheno_"; text += std::to_string(j); text.push_back(',');
+        append_rust_display(text, beta[(size_t)i * k + j]); text.push_back(',');
+        append_rust_display(text, pval[(size_t)i * k + j]); text.push_back('\n');
     });
     fclose(fo);
     lap("format + write CSV");
