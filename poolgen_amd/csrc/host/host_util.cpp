@@ -56,6 +56,14 @@ std::string roundup_own(double x, int n_digits) {
     return rust_display(sensible_round(x, n_digits));
 }
 
+void append_roundup_own(std::string &out, double x, int n_digits) {
+    const size_t at = out.size();
+    append_rust_display(out, x);
+    if ((int)(out.size() - at) < n_digits) return; // shorter than n_digits characters: printed as it is (helpers.rs:112-115)
+    out.resize(at);
+    append_rust_display(out, sensible_round(x, n_digits));
+}
+
 static std::string trim(const std::string &s) {
     size_t a = 0, b = s.size();
     while (a < b && std::isspace((unsigned char)s[a])) ++a;

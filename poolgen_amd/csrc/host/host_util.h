@@ -15,6 +15,7 @@ std::string rust_display(double x);                      // Rust `{}` for f64
 void append_rust_display(std::string &out, double x);    // the same, appended in place (no temporary)
 double sensible_round(double x, int n_digits);           // helpers.rs:103-108
 std::string roundup_own(double x, int n_digits);         // helpers.rs:111-117
+void append_roundup_own(std::string &out, double x, int n_digits); // the same, appended in place
 
 // ---- phenotypes ---------------------------------------------------------------------------------
 struct Phen {

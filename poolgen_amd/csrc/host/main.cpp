@@ -528,20 +528,23 @@ static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap,
             if (mode == 0) { // chisq_test.rs:37-45
                 std::string al;
                 for (int j = 0; j < n_out[l] && j < PG_MAX_OUT; ++j) al.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + j]]);
-                line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + al + "," + roundup_own(stat[l], 6) + "," +
-                        rust_display(pv[l]) + "\n";
+                line += sb.chrom(l); line.push_back(','); line += std::to_string(sb.pos[l]); line.push_back(','); line += al; line.push_back(',');
+                append_roundup_own(line, stat[l], 6); line.push_back(',');
+                append_rust_display(line, pv[l]); line.push_back('\n');
             } else {
                 for (int i = 0; i < n_out[l]; ++i)
                     for (int j = 0; j < k; ++j) {
                         const size_t e = ((size_t)l * PG_MAX_OUT + i) * k + j;
                         const double f = mfq[(size_t)l * PG_MAX_OUT + i];
-                        line += sb.chrom(l) + "," + std::to_string(sb.pos[l]) + "," + ALLELES[ids[(size_t)l * PG_MAX_OUT + i]] + ",";
-                        if (mode == 2) // ols.rs:263-271
-                            line += roundup_own(f, 8) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
-                                    roundup_own(pv[e], 12) + "\n";
-                        else // correlation_test.rs:117-124
-                            line += rust_display(f) + ",Pheno_" + std::to_string(j) + "," + roundup_own(stat[e], 6) + "," +
-                                    rust_display(pv[e]) + "\n";
+                        line += sb.chrom(l); line.push_back(','); line += std::to_string(sb.pos[l]); line.push_back(',');
+                        line.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + i]]); line.push_back(',');
+                        if (mode == 2) append_roundup_own(line, f, 8); // ols.rs:263-271
+                        else append_rust_display(line, f);             // correlation_test.rs:117-124
+                        line += ",Pheno_"; line += std::to_string(j); line.push_back(',');
+                        append_roundup_own(line, stat[e], 6); line.push_back(',');
+                        if (mode == 2) append_roundup_own(line, pv[e], 12);
+                        else append_rust_display(line, pv[e]);
+                        line.push_back('\n');
                     }
             }
         });
