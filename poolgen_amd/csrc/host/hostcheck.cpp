@@ -28,6 +28,10 @@ int main(int argc, char **argv) {
             while (std::getline(std::cin, line)) {
                 char *end; const double x = std::strtod(line.c_str(), &end); const int nd = std::atoi(end);
                 std::cout << rust_display(x) << " " << roundup_own(x, nd) << "\n";
+                // the in-place forms the CSV writers use must print the same characters
+                std::string a1 = "x", a2 = "y";
+                append_rust_display(a1, x); append_roundup_own(a2, x, nd);
+                if (a1 != "x" + rust_display(x) || a2 != "y" + roundup_own(x, nd)) throw std::runtime_error("append_* differ from the string forms for " + line);
             }
         } else if (mode == "phen") {
             std::vector<int> cols; for (auto &t : splitc(argv[6])) cols.push_back(std::stoi(t));
