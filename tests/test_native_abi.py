@@ -140,3 +140,28 @@ def test_host_sliding_windows_match_reference_literals_and_oracle(native, oracle
         w, s, m = int(rng.integers(1, 500)), int(rng.integers(1, 300)), int(rng.integers(1, 6))
         h, t = oracle.sliding_windows(chrom, pos, w, s, m)
         assert run(chrom, pos, w, s, m) == (h.tolist(), t.tolist())
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (what cgo / bindgen / ctypes users see), and a C program
+    linked against the library must resolve every entry point it names."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include "poolgen_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    pg_ctx *c = 0;\n'
+                   '    int rc = pg_create(&c, 0, 0);            /* no GPU here: must fail loudly, not fall back */\n'
+                   '    printf("%d %s\\n", rc, pg_version());\n'
+                   '    int64_t head[4], tail[4]; int32_t chr[4] = {0, 0, 0, 1}; uint64_t pos[4] = {1, 40, 200, 5};\n'
+                   '    printf("%lld\\n", (long long)pg_host_sliding_windows(chr, pos, 4, 100, 50, 1, head, tail));\n'
+                   '    if (c) pg_destroy(c);\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = ROOT / "poolgen_amd" / "csrc"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(ROOT / "include"), str(src), "-o", str(exe),
+                           "-L", str(libdir), "-lpoolgen_hip", f"-Wl,-rpath,{libdir}"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    first, second = r.stdout.splitlines()[:2]
+    if not torch.cuda.is_available():
+        assert first.split()[0] != "0"                    # pg_create refused
+    assert second == "3"                                   # [0..1], [2], [3]: what the oracle gives for these four loci
