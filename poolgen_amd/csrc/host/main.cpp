@@ -50,8 +50,28 @@ static double parse_valid_freq(const std::string &v, const std::string &flag) { 
     return x;
 }
 
+static const char *USAGE =
+    "poolgen <analysis> -f <input> -p <phenotypes.csv> [flags]      (MI355X build of the per-locus regression path)\n"
+    "analyses: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship,\n"
+    "          genomic_prediction_cross_validation, fst, heterozygosity\n"
+    "  -f, --fname <file>                 *.sync, or *.pileup / *.mpileup (converted in memory)\n"
+    "  -p, --phen-fname <file>            delimited file: pool name, pool size, trait value(s)\n"
+    "  -o, --output <file>                must not exist; default: derived from the input name and the time\n"
+    "      --phen-delim <,>  --phen-name-col <0>  --phen-pool-size-col <1>  --phen-value-col <2[,3..]>\n"
+    "      --max-base-error-rate <0.01>  --min-coverage-depth <1>  --min-coverage-breadth <1.0>\n"
+    "      --min-allele-frequency <0.001>  --max-missingness-rate <0.0>  --keep-ns  --keep-lowercase-reference\n"
+    "      --keep-p-minus-1                drop the major allele of every locus when loading the matrix\n"
+    "  -x, --xxt-eigen-variance-explained <0.75>   ols_iter_with_kinship: the n_eigenvecs rule's threshold\n"
+    "      --k-folds <10>  --n-reps <3>  --seed <42>     genomic_prediction_cross_validation\n"
+    "      --window-size-bp <100>  --window-slide-size-bp <50>  --min-loci-per-window <10>   fst, heterozygosity\n"
+    "      --n-threads <1>                 parser / writer threads\n"
+    "      --stream-chunk-mb <N>           size of the pieces the input is taken in (0: whole file, kinship path only)\n"
+    "environment: PGH_TIMING=1 prints the phases' wall-clock on stderr\n";
+
 static Args parse_args(int argc, char **argv) {
     Args a;
+    for (int i = 1; i < argc; ++i)
+        if (std::string(argv[i]) == "-h" || std::string(argv[i]) == "--help") { std::cout << USAGE; std::exit(0); }
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
         std::string k = argv[i], v;
@@ -96,7 +116,7 @@ static Args parse_args(int argc, char **argv) {
         else if (k.rfind("-", 0) == 0) throw std::runtime_error("unknown flag " + k);
         else pos.push_back(k);
     }
-    if (pos.size() != 1) throw std::runtime_error("usage: poolgen <analysis> -f <sync> -p <phen.csv> [flags]");
+    if (pos.size() != 1) throw std::runtime_error("usage: poolgen <analysis> -f <sync> -p <phen.csv> [flags]   (--help lists them)");
     a.analysis = pos[0];
     if (a.fname.empty() || a.phen_fname.empty()) throw std::runtime_error("-f/--fname and -p/--phen-fname are required");
     return a;
