@@ -773,7 +773,7 @@ int orc_n_eigenvecs_rule(const double *ev, int n, double threshold) {
 void orc_kinship(const double *G, int64_t p, int n, int64_t ld, double *K, int n_threads) {
     int nt = 1;
 #ifdef _OPENMP
-    nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+    nt = n_threads > 0 ? n_threads : (omp_get_max_threads() < 8 ? omp_get_max_threads() : 8); /* a test oracle: never the whole box */
 #endif
     (void)n_threads;
     double *part = (double *)calloc((size_t)nt * n * n, sizeof(double));
@@ -831,7 +831,7 @@ int orc_ols_with_covariate(const double *G, int64_t p, int n, int64_t ld, const 
     int P = m + 2;
     int nt = 1;
 #ifdef _OPENMP
-    nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+    nt = n_threads > 0 ? n_threads : (omp_get_max_threads() < 8 ? omp_get_max_threads() : 8); /* a test oracle: never the whole box */
 #endif
 #pragma omp parallel num_threads(nt)
     {
@@ -1035,7 +1035,7 @@ int orc_gp_ols(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, 
     if (s0 < (double)n) return -1; /* gp/ols.rs:26-31 */
     int nt = 1;
 #ifdef _OPENMP
-    nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+    nt = n_threads > 0 ? n_threads : (omp_get_max_threads() < 8 ? omp_get_max_threads() : 8); /* a test oracle: never the whole box */
 #endif
     (void)n_threads;
     int r = n_rows;

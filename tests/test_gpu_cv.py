@@ -182,3 +182,37 @@ def test_cli_cross_validation(oracle, tmp_path):
     r = subprocess.run([str(CLI), "genomic_prediction_cross_validation", "-f", str(tmp_path / "x.sync"), "-p", str(tmp_path / "x.csv"),
                         "--phen-value-col", "2,3", "--k-folds", str(kf), "--n-reps", "1", "-o", str(out)], capture_output=True, text=True)
     assert r.returncode != 0 and "Unable to create file" in r.stderr
+
+
+def test_cli_cv_reference_property(tmp_path):
+    """The reference's own check of the harness (gp/cv.rs:426-570, test_cv): n = 100 pools, p = 1 000 loci with uniform
+    allele frequencies, two traits at h2 = 0.75; the mean Pearson correlation of penalise_glmnet over folds and replicates
+    rounds to 1 for both (`mean_cor[(3, *)].round() == 1.0`).  As written there, BOTH traits carry the two-locus signal:
+    `multiply_views_xx(.., &vec![0])` (:493-500) forms x b for column 0 of b only and `&xb + e` (:510) broadcasts it onto
+    the two noise columns -- the "polygenic" second column of b is never used (a min-norm fit of a fully polygenic trait
+    at p = 10 n could not reach 0.5: this harness gives 0.09 for it, as theory says)."""
+    rng = np.random.default_rng(2025)
+    n, p, h2 = 100, 1000, 0.75
+    f = rng.uniform(0.02, 0.98, size=(n, p))
+    a = np.rint(f * 100).astype(int).clip(1, 99)
+    F = a / 100.0
+    b0 = np.zeros(p); b0[rng.integers(0, p, size=2)] = 1.0
+    xb = F @ b0
+    ve = xb.var() / h2 - xb.var()
+    y = xb[:, None] + rng.normal(size=(n, 2)) * np.sqrt(ve)
+    with open(tmp_path / "s.sync", "w") as fh:
+        for l in range(p):
+            fh.write("dummy_chr\t%d\tN\t" % (l + 1) + "\t".join("%d:%d:0:0:0:0" % (a[i, l], 100 - a[i, l]) for i in range(n)) + "\n")
+    (tmp_path / "p.csv").write_text("#pool,size,y0,y1\n" + "".join("pool-%d,20,%r,%r\n" % (i, float(y[i, 0]), float(y[i, 1])) for i in range(n)))
+    out = tmp_path / "cv.csv"
+    r = subprocess.run([str(CLI), "genomic_prediction_cross_validation", "-f", str(tmp_path / "s.sync"), "-p", str(tmp_path / "p.csv"),
+                        "--phen-value-col", "2,3", "--n-threads", "4", "--k-folds", "10", "--n-reps", "2", "--seed", "3", "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cor = {}
+    for line in out.read_text().splitlines()[1:]:
+        rep, fold, model, trait, c = line.split(",")[:5]
+        cor.setdefault((model.split("-")[0], int(trait)), []).append(float(c))
+    for trait in (0, 1):
+        assert round(float(np.mean(cor[("penalise_glmnet", trait)]))) == 1
+        assert len(cor[("ols", trait)]) == 20                                    # 2 replicates x 10 folds
