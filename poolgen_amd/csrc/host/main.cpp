@@ -18,6 +18,7 @@
 #include <iostream>
 #include <map>
 #include "gp_cv.h"
+#include "operators.h"
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
@@ -544,29 +545,8 @@ static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap,
                             : "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n", fo); // sync.rs:950
         }
         write_rows_parallel(fo, L, a.n_threads, [&](int64_t l, std::string &line) {
-            if (n_out[l] <= 0) return;
-            if (mode == 0) { // chisq_test.rs:37-45
-                std::string al;
-                for (int j = 0; j < n_out[l] && j < PG_MAX_OUT; ++j) al.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + j]]);
-                line += sb.chrom(l); line.push_back(','); line += std::to_string(sb.pos[l]); line.push_back(','); line += al; line.push_back(',');
-                append_roundup_own(line, stat[l], 6); line.push_back(',');
-                append_rust_display(line, pv[l]); line.push_back('\n');
-            } else {
-                for (int i = 0; i < n_out[l]; ++i)
-                    for (int j = 0; j < k; ++j) {
-                        const size_t e = ((size_t)l * PG_MAX_OUT + i) * k + j;
-                        const double f = mfq[(size_t)l * PG_MAX_OUT + i];
-                        line += sb.chrom(l); line.push_back(','); line += std::to_string(sb.pos[l]); line.push_back(',');
-                        line.push_back(ALLELES[ids[(size_t)l * PG_MAX_OUT + i]]); line.push_back(',');
-                        if (mode == 2) append_roundup_own(line, f, 8); // ols.rs:263-271
-                        else append_rust_display(line, f);             // correlation_test.rs:117-124
-                        line += ",Pheno_"; line += std::to_string(j); line.push_back(',');
-                        append_roundup_own(line, stat[e], 6); line.push_back(',');
-                        if (mode == 2) append_roundup_own(line, pv[e], 12);
-                        else append_rust_display(line, pv[e]);
-                        line.push_back('\n');
-                    }
-            }
+            format_locus_rows(mode, sb.chrom(l), sb.pos[l], n_out[l], &ids[(size_t)l * PG_MAX_OUT], &mfq[(size_t)l * PG_MAX_OUT],
+                              &stat[(size_t)l * per_stat], &pv[(size_t)l * per_stat], k, line);
         });
     }
     if (total == 0) throw std::runtime_error("no loci in " + a.fname);

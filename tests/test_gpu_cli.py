@@ -215,3 +215,13 @@ def test_batch_operators_in_pieces_equal_one_piece(tmp_path, analysis, extra):
     r = subprocess.run(base + ["-o", str(many)], capture_output=True, text=True, env={**os.environ, "PGH_STREAM_CHUNK_BYTES": "20000"})
     assert r.returncode == 0, r.stderr
     assert one.read_bytes() == many.read_bytes() and one.stat().st_size > 10000
+
+
+def test_operator_interface_reference_unit_tests():
+    """`apitest`: the reference's operator-level unit tests transcribed to the C++ mirror of its interface
+    (host/operators.h: FilterStats, LocusCounts, LocusCountsAndPhenotypes, chisq / correlation / ols_iterate returning
+    Option<String>): gwas/correlation_test.rs:136-182 and tables/chisq_test.rs:53-82 with their expected lines."""
+    exe = ROOT / "poolgen_amd" / "csrc" / "apitest"
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "apitest: all checks passed" in r.stdout and "FAIL" not in r.stdout
