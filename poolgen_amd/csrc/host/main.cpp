@@ -643,6 +643,141 @@ static int run_popgen(const Args &a, bool is_fst, Ctx &gpu, const double *G_dev,
     return done_ok();
 }
 
+// GenotypesAndPhenotypes (base/structs_and_traits.rs:139-148) with the matrix resident in HBM: the reference's dense
+// n x (1 + p) `intercept_and_allele_frequencies` is here p x ld locus-major on the device, the column of ones implied; the
+// three label vectors keep the leading "intercept" entry (sync.rs:1121-1126).
+struct GenotypesAndPhenotypes {
+    std::vector<std::string> chromosome, allele; // 1 + p entries
+    std::vector<uint64_t> position;
+    double *intercept_and_allele_frequencies = nullptr; // device
+    int64_t p = 0, ld = 0;
+    int n = 0, k = 0;
+    std::vector<double> phenotypes;                     // n x k
+    std::vector<std::string> pool_names;
+    double *coverages = nullptr;                        // device, laid out like the matrix (pg_load_emit_cov_dev); optional
+    GenotypesAndPhenotypes() = default;
+    GenotypesAndPhenotypes(const GenotypesAndPhenotypes &) = delete;
+    GenotypesAndPhenotypes &operator=(const GenotypesAndPhenotypes &) = delete;
+    GenotypesAndPhenotypes(GenotypesAndPhenotypes &&o) noexcept { *this = std::move(o); }
+    GenotypesAndPhenotypes &operator=(GenotypesAndPhenotypes &&o) noexcept {
+        std::swap(chromosome, o.chromosome); std::swap(allele, o.allele); std::swap(position, o.position);
+        std::swap(intercept_and_allele_frequencies, o.intercept_and_allele_frequencies); std::swap(p, o.p); std::swap(ld, o.ld);
+        std::swap(n, o.n); std::swap(k, o.k); std::swap(phenotypes, o.phenotypes); std::swap(pool_names, o.pool_names);
+        std::swap(coverages, o.coverages);
+        return *this;
+    }
+    ~GenotypesAndPhenotypes() { (void)hipFree(intercept_and_allele_frequencies); (void)hipFree(coverages); }
+};
+
+// FileSyncPhen::into_genotypes_and_phenotypes (base/sync.rs:1106-1179) = load (:1044-1104: filter + frequencies per locus,
+// sorted by (chromosome, position)) + the dense fill.  The host only sorts the locus order; filter, frequencies and the
+// column layout run on the GPU from the parsed counts (pg_load_plan_dev / pg_load_emit[_cov]_dev), and the matrix never
+// exists in host memory.  `remove_missing`: drop the pools without phenotype (what ols_with_covariate does first,
+// gwas/ols.rs:287); the popgen tools keep every pool.
+static GenotypesAndPhenotypes into_genotypes_and_phenotypes(Ctx &gpu, const SyncBatch &sb, const Phen &ph, const pg_filter &flt,
+                                                            bool keep_p_minus_1, bool remove_missing, bool with_coverages, Lap &lap) {
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    };
+    const int n = sb.n, k = ph.k;
+    const int64_t L = sb.size();
+    std::vector<int64_t> order(L);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        const int c = sb.chrom(x).compare(sb.chrom(y));
+        return c != 0 ? c < 0 : sb.pos[x] < sb.pos[y];
+    });
+    std::vector<int> keep(n);
+    std::iota(keep.begin(), keep.end(), 0);
+    if (remove_missing) keep = complete_pools(ph);
+    if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
+    GenotypesAndPhenotypes g;
+    g.n = (int)keep.size();
+    g.k = k;
+    g.ld = g.n + (g.n & 1);
+    std::vector<int32_t> pool_map(n, -1);
+    for (int i = 0; i < g.n; ++i) pool_map[keep[i]] = i;
+    uint32_t *counts_dev = nullptr;
+    int64_t *order_dev = nullptr;
+    hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * (size_t)L * n * 6), "device memory for the counts");
+    hip_ok(hipMalloc((void **)&order_dev, sizeof(int64_t) * L), "device memory");
+    CountsUpload upload;
+    upload(gpu, sb, counts_dev);
+    hip_ok(hipMemcpy(order_dev, order.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice), "H2D order");
+    gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, L, n, ph.pool_sizes.data(), &flt, keep_p_minus_1 ? 1 : 0, order_dev, &g.p), "load");
+    if (g.p <= 0) throw std::runtime_error("no loci passed the filters");
+    int64_t *col_locus_dev = nullptr;
+    int32_t *col_allele_dev = nullptr;
+    hip_ok(hipMalloc((void **)&g.intercept_and_allele_frequencies, sizeof(double) * (size_t)g.p * g.ld), "device memory for the genotype matrix");
+    hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * g.p), "device memory");
+    hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * g.p), "device memory");
+    if (with_coverages) {
+        hip_ok(hipMalloc((void **)&g.coverages, sizeof(double) * (size_t)g.p * g.ld), "device memory for the coverages");
+        gpu.ok(pg_load_emit_cov_dev(gpu.c, pool_map.data(), g.n, g.intercept_and_allele_frequencies, g.ld, col_locus_dev, col_allele_dev,
+                                    g.coverages), "load");
+    } else
+        gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), g.n, g.intercept_and_allele_frequencies, g.ld, col_locus_dev, col_allele_dev), "load");
+    lap("sort + H2D + GPU loader");
+    hip_ok(hipFree(counts_dev), "free");
+    hip_ok(hipFree(order_dev), "free");
+    std::vector<int64_t> col_locus(g.p);
+    std::vector<int32_t> col_allele(g.p);
+    hip_ok(hipMemcpy(col_locus.data(), col_locus_dev, sizeof(int64_t) * g.p, hipMemcpyDeviceToHost), "D2H labels");
+    hip_ok(hipMemcpy(col_allele.data(), col_allele_dev, sizeof(int32_t) * g.p, hipMemcpyDeviceToHost), "D2H labels");
+    (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
+    g.chromosome.assign(1, "intercept"); g.allele.assign(1, "intercept"); g.position.assign(1, 0);
+    g.chromosome.reserve(g.p + 1); g.allele.reserve(g.p + 1); g.position.reserve(g.p + 1);
+    for (int64_t c = 0; c < g.p; ++c) {
+        g.chromosome.push_back(sb.chrom(col_locus[c])); g.position.push_back(sb.pos[col_locus[c]]);
+        g.allele.push_back(std::string(1, ALLELES[col_allele[c]]));
+    }
+    for (int i : keep) {
+        g.pool_names.push_back(ph.pool_names[i]);
+        for (int j = 0; j < k; ++j) g.phenotypes.push_back(ph.phen[(size_t)i * k + j]);
+    }
+    return g;
+}
+
+// gwas::ols_with_covariate (gwas/ols.rs:278-436): kinship, eigen rule, one fit per (column, trait), the CSV; returns the
+// name of the file it wrote.
+static std::string ols_with_covariate(Ctx &gpu, GenotypesAndPhenotypes &g, double xxt_eigen_variance_explained,
+                                      const std::string &fname_input, const std::string &fname_output, int n_threads, Lap &lap) {
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    };
+    const int64_t p = g.p;
+    const int k = g.k;
+    if (!fname_output.empty()) { FILE *t = create_new(fname_output); fclose(t); ::unlink(fname_output.c_str()); } // ols.rs:285
+    std::vector<double> beta((size_t)p * k), pval((size_t)p * k);
+    int m = 0;
+    double *out_dev = nullptr;
+    hip_ok(hipMalloc((void **)&out_dev, sizeof(double) * 3 * (size_t)p * k), "device memory for the results");
+    gpu.ok(pg_ols_kinship_dev(gpu.c, g.intercept_and_allele_frequencies, p, g.n, g.ld, g.phenotypes.data(), k, xxt_eigen_variance_explained, -1,
+                              &m, nullptr, out_dev, out_dev + (size_t)p * k, out_dev + 2 * (size_t)p * k), "ols_iter_with_kinship");
+    gpu.ok(pg_synchronize(gpu.c), "ols_iter_with_kinship");
+    hip_ok(hipMemcpy(beta.data(), out_dev, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
+    hip_ok(hipMemcpy(pval.data(), out_dev + 2 * (size_t)p * k, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
+    (void)hipFree(out_dev);
+    lap("kinship + fits + D2H");
+    std::string out = fname_output;
+    if (out.empty()) // ols.rs:393-398
+        out = basename_no_ext(fname_input) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";
+    FILE *fo = create_new(out);
+    fputs("#chr,pos,alleles,phenotype,statistic,pvalue\n", fo); // ols.rs:409
+    write_rows_parallel(fo, (int64_t)k * p, n_threads, [&](int64_t r, std::string &text) {
+        const int64_t j = r / p, i = r - j * p; // rows are trait-major (ols.rs:411-433)
+        // the reference labels coefficient i with entry i of the (1+p)-long label vectors, i.e.
+        // shifted by the intercept entry (ols.rs:421-425; SURVEY.md section 3.2) -- reproduced as is
+        text += g.chromosome[i]; text.push_back(','); text += std::to_string(g.position[i]); text.push_back(','); text += g.allele[i];
+        text += ",Pheno_"; text += std::to_string(j); text.push_back(',');
+        append_rust_display(text, beta[(size_t)i * k + j]); text.push_back(',');
+        append_rust_display(text, pval[(size_t)i * k + j]); text.push_back('\n');
+    });
+    fclose(fo);
+    lap("format + write CSV");
+    return out;
+}
+
 static int run(int argc, char **argv) {
     const Args a = parse_args(argc, argv);
     Lap lap;
@@ -739,117 +874,29 @@ static int run(int argc, char **argv) {
     }
     if (sb.size() == 0) throw std::runtime_error("no loci in " + a.fname);
     if (sb.n != ph.n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
-    const int n = sb.n, k = ph.k;
-    const int64_t L = sb.size();
+    const int k = ph.k;
     const int mode = known.at(a.analysis);
 
-    // ---------------- ols_iter_with_kinship (main.rs:280-298) -------------------------------------
-    // load(): filter + frequencies per locus, then sort by (chromosome, position) (sync.rs:1092-1101).  The
-    // host only sorts the locus order; filter, frequencies and the column layout run on the GPU from the
-    // parsed counts (pg_load_plan_dev / pg_load_emit_dev), and G never exists in host memory.
-    std::vector<int64_t> order(L);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
-        const int c = sb.chrom(x).compare(sb.chrom(y));
-        return c != 0 ? c < 0 : sb.pos[x] < sb.pos[y];
-    });
-    std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
-    if (mode >= 6) { keep.resize(n); std::iota(keep.begin(), keep.end(), 0); } // fst / heterozygosity use every pool (main.rs:427-455)
-    if (keep.empty()) throw std::runtime_error("All pools have missing data. Please check the phenotype file.");
-    const int n2 = (int)keep.size();
-    const int64_t ld = n2 + (n2 & 1);
-    std::vector<int32_t> pool_map(n, -1);
-    for (int i = 0; i < n2; ++i) pool_map[keep[i]] = i;
-    auto hip_ok = [](hipError_t e, const char *what) {
-        if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
-    };
-    uint32_t *counts_dev = nullptr;
-    int64_t *order_dev = nullptr;
-    hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * (size_t)L * n * 6), "device memory for the counts");
-    hip_ok(hipMalloc((void **)&order_dev, sizeof(int64_t) * L), "device memory");
-    CountsUpload upload;
-    upload(gpu, sb, counts_dev);
-    hip_ok(hipMemcpy(order_dev, order.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice), "H2D order");
-    int64_t p = 0;
+    // ---------------- the analyses on the loaded matrix (main.rs:280-298, :397-455) ---------------------------
     const bool kpm1 = mode == 7 ? false : a.keep_p_minus_1; // heterozygosity: "we need all alleles in each locus" (main.rs:445)
-    gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, L, n, ph.pool_sizes.data(), &flt, kpm1 ? 1 : 0, order_dev, &p), "load");
-    if (p <= 0) throw std::runtime_error("no loci passed the filters");
-    double *G_dev = nullptr, *out_dev = nullptr, *cov_dev = nullptr;
-    int64_t *col_locus_dev = nullptr;
-    int32_t *col_allele_dev = nullptr;
-    hip_ok(hipMalloc((void **)&G_dev, sizeof(double) * (size_t)p * ld), "device memory for the genotype matrix");
-    hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * p), "device memory");
-    hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * p), "device memory");
-    if (mode >= 6) {
-        hip_ok(hipMalloc((void **)&cov_dev, sizeof(double) * (size_t)p * ld), "device memory for the coverages");
-        gpu.ok(pg_load_emit_cov_dev(gpu.c, pool_map.data(), n2, G_dev, ld, col_locus_dev, col_allele_dev, cov_dev), "load");
-    } else
-        gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G_dev, ld, col_locus_dev, col_allele_dev), "load");
-    lap("sort + H2D + GPU loader");
-    hip_ok(hipFree(counts_dev), "free");
-    hip_ok(hipFree(order_dev), "free");
-    std::vector<int64_t> col_locus(p);
-    std::vector<int32_t> col_allele(p);
-    hip_ok(hipMemcpy(col_locus.data(), col_locus_dev, sizeof(int64_t) * p, hipMemcpyDeviceToHost), "D2H labels");
-    hip_ok(hipMemcpy(col_allele.data(), col_allele_dev, sizeof(int32_t) * p, hipMemcpyDeviceToHost), "D2H labels");
-    // labels carry the leading "intercept" entry of the reference matrix (sync.rs:1121-1126)
-    std::vector<std::string> lab_chr{"intercept"}, lab_al{"intercept"};
-    std::vector<uint64_t> lab_pos{0};
-    lab_chr.reserve(p + 1); lab_al.reserve(p + 1); lab_pos.reserve(p + 1);
-    for (int64_t c = 0; c < p; ++c) {
-        lab_chr.push_back(sb.chrom(col_locus[c])); lab_pos.push_back(sb.pos[col_locus[c]]);
-        lab_al.push_back(std::string(1, ALLELES[col_allele[c]]));
-    }
-    std::vector<double> Y;
-    for (int i : keep) for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]);
-    if (mode >= 6) {
-        (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
-        const int rc = run_popgen(a, mode == 6, gpu, G_dev, cov_dev, p, n2, ld, lab_chr, lab_pos, ph.pool_names, lap);
-        (void)hipFree(G_dev); (void)hipFree(cov_dev);
-        return rc;
-    }
+    GenotypesAndPhenotypes genotypes_and_phenotypes =
+        into_genotypes_and_phenotypes(gpu, sb, ph, flt, kpm1, /*remove_missing=*/mode < 6, /*with_coverages=*/mode >= 6, lap);
+    GenotypesAndPhenotypes &g = genotypes_and_phenotypes;
+    if (mode >= 6) // fst / heterozygosity use every pool (main.rs:427-455)
+        return run_popgen(a, mode == 6, gpu, g.intercept_and_allele_frequencies, g.coverages, g.p, g.n, g.ld, g.chromosome, g.position,
+                          g.pool_names, lap);
     if (mode == 5) { // genomic_prediction_cross_validation (main.rs:397-426)
-        CvLabels labels{lab_chr, lab_al, lab_pos};
+        CvLabels labels{g.chromosome, g.allele, g.position};
         CvArgs ca;
         ca.k_folds = a.k_folds; ca.n_reps = a.n_reps; ca.seed = a.seed; ca.n_threads = a.n_threads;
         ca.fname_input = a.fname; ca.fname_output = a.output;
-        std::vector<std::string> names;
-        for (int i : keep) names.push_back(ph.pool_names[i]);
-        (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
-        const std::string out = gp_cross_validate(gpu.c, G_dev, p, n2, ld, Y, k, names, labels, ca);
-        (void)hipFree(G_dev);
+        const std::string out = gp_cross_validate(gpu.c, g.intercept_and_allele_frequencies, g.p, g.n, g.ld, g.phenotypes, k, g.pool_names,
+                                                  labels, ca);
         lap("cross-validation");
         std::cout << out << "\n";
         return done_ok();
     }
-    if (!a.output.empty()) { FILE *t = create_new(a.output); fclose(t); ::unlink(a.output.c_str()); } // ols.rs:285
-    std::vector<double> beta((size_t)p * k), var((size_t)p * k), pval((size_t)p * k);
-    int m = 0;
-    hip_ok(hipMalloc((void **)&out_dev, sizeof(double) * 3 * (size_t)p * k), "device memory for the results");
-    gpu.ok(pg_ols_kinship_dev(gpu.c, G_dev, p, n2, ld, Y.data(), k, a.xxt, -1, &m, nullptr, out_dev, out_dev + (size_t)p * k,
-                              out_dev + 2 * (size_t)p * k), "ols_iter_with_kinship");
-    gpu.ok(pg_synchronize(gpu.c), "ols_iter_with_kinship");
-    hip_ok(hipMemcpy(beta.data(), out_dev, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
-    hip_ok(hipMemcpy(var.data(), out_dev + (size_t)p * k, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
-    hip_ok(hipMemcpy(pval.data(), out_dev + 2 * (size_t)p * k, sizeof(double) * (size_t)p * k, hipMemcpyDeviceToHost), "D2H results");
-    (void)hipFree(G_dev); (void)hipFree(out_dev); (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
-    lap("kinship + fits + D2H");
-    std::string out = a.output;
-    if (out.empty()) // ols.rs:393-398
-        out = basename_no_ext(a.fname) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";
-    FILE *fo = create_new(out);
-    fputs("#chr,pos,alleles,phenotype,statistic,pvalue\n", fo); // ols.rs:409
-    write_rows_parallel(fo, (int64_t)k * p, a.n_threads, [&](int64_t r, std::string &text) {
-        const int64_t j = r / p, i = r - j * p; // rows are trait-major (ols.rs:411-433)
-        // the reference labels coefficient i with entry i of the (1+p)-long label vectors, i.e.
-        // shifted by the intercept entry (ols.rs:421-425; SURVEY.md section 3.2) -- reproduced as is
-        text += lab_chr[i]; text.push_back(','); text += std::to_string(lab_pos[i]); text.push_back(','); text += lab_al[i];
-        text += ",Pheno_"; text += std::to_string(j); text.push_back(',');
-        append_rust_display(text, beta[(size_t)i * k + j]); text.push_back(',');
-        append_rust_display(text, pval[(size_t)i * k + j]); text.push_back('\n');
-    });
-    fclose(fo);
-    lap("format + write CSV");
+    const std::string out = ols_with_covariate(gpu, g, a.xxt, a.fname, a.output, a.n_threads, lap);
     std::cout << out << "\n";
     return done_ok();
 }
