@@ -44,25 +44,71 @@ double pearson_sensible(const std::vector<double> &x, const std::vector<double> 
     return std::round(r * 1e7) / 1e7;
 }
 
-struct Model {
-    const char *base;  // function_name!() of the reference
-    bool penalised;
-    double alpha;      // < 0: the alpha x lambda grid of penalise_glmnet
-    int proxy;         // the *_with_iterative_proxy_norms variants
+// What every model function of the reference receives, `(x, y, row_idx)` (main.rs:402-411), in this build's terms: the
+// matrix in HBM, the phenotypes, the one full-data X X^T, and the generator the inner folds are drawn from.
+struct GpData {
+    pg_ctx *ctx;
+    const double *G_dev;
+    int64_t p;
+    int n;
+    int64_t ld;
+    const std::vector<double> *Y;
+    int k;
+    const std::vector<double> *xxt;
+    SplitMix64 *rng;
 };
+// fn(&Array2<f64>, &Array2<f64>, &Vec<usize>) -> io::Result<(Array2<f64>, String)>: b_hat ((1 + p) x k) to the device buffer,
+// the model's name returned
+using GpModelFn = std::string (*)(const GpData &, const std::vector<int64_t> &row_idx, double *b_hat_dev);
+
+std::string ols(const GpData &d, const std::vector<int64_t> &row_idx, double *b_hat_dev) { // gp/ols.rs:8-101
+    ok(d.ctx, pg_gp_ols_dev(d.ctx, d.G_dev, d.p, d.n, d.ld, d.Y->data(), d.k, row_idx.data(), (int)row_idx.size(), d.xxt->data(), b_hat_dev), "ols");
+    return "ols";
+}
+
+// penalised_lambda_path_with_k_fold_cross_validation(x, y, row_idx, alpha, iterative, 0.1, 10) (gp/penalise.rs:461-669) and the
+// name the callers build from its alphas and lambdas (:118-129)
+std::string penalised(const char *function_name, double alpha, int iterative, const GpData &d, const std::vector<int64_t> &rows,
+                      double *b_hat_dev) {
+    const int nr = (int)rows.size(), inner_reps = 10;
+    int nf = 0;
+    std::vector<int32_t> folds((size_t)inner_reps * nr);
+    for (int rep = 0; rep < inner_reps; ++rep) { // 10 repetitions of k_split(row_idx, 10) (:509-512)
+        std::vector<int64_t> perm = d.rng->permutation(nr), order(nr);
+        for (int i = 0; i < nr; ++i) order[i] = rows[perm[i]]; // a shuffle of the row VALUES indexes the group list (:452-456)
+        const std::vector<int32_t> g = k_split(nr, 10, order, nf);
+        for (int i = 0; i < nr; ++i) folds[(size_t)rep * nr + i] = g[i]; // group nf: the left-over, never validated
+    }
+    std::vector<double> lam(d.k), al(d.k);
+    ok(d.ctx, pg_gp_penalised_dev(d.ctx, d.G_dev, d.p, d.n, d.ld, d.Y->data(), d.k, rows.data(), nr, folds.data(), inner_reps, nf, alpha,
+                                  iterative, 0.1, b_hat_dev, al.data(), lam.data(), nullptr, d.xxt->data()), function_name);
+    std::string name = std::string(function_name) + "-alphas_";
+    for (int j = 0; j < d.k; ++j) name += (j ? "_" : "") + rust_display(al[j]);
+    name += "-lambdas_";
+    for (int j = 0; j < d.k; ++j) name += (j ? "_" : "") + rust_display(lam[j]);
+    return name;
+}
+std::string penalise_lasso_like(const GpData &d, const std::vector<int64_t> &r, double *b) { return penalised("penalise_lasso_like", 1.00, 0, d, r, b); }   // :101-130
+std::string penalise_ridge_like(const GpData &d, const std::vector<int64_t> &r, double *b) { return penalised("penalise_ridge_like", 0.00, 0, d, r, b); }   // :133-159
+std::string penalise_glmnet(const GpData &d, const std::vector<int64_t> &r, double *b) { return penalised("penalise_glmnet", -0.1, 0, d, r, b); }           // :162-188
+std::string penalise_lasso_like_with_iterative_proxy_norms(const GpData &d, const std::vector<int64_t> &r, double *b) {                                     // :191-217
+    return penalised("penalise_lasso_like_with_iterative_proxy_norms", 1.00, 1, d, r, b);
+}
+std::string penalise_ridge_like_with_iterative_proxy_norms(const GpData &d, const std::vector<int64_t> &r, double *b) {                                     // :220-246
+    return penalised("penalise_ridge_like_with_iterative_proxy_norms", 1.00, 1, d, r, b); // alpha = 1 here too, as written (:225-227)
+}
 
 } // namespace
 
 std::string gp_cross_validate(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const std::vector<double> &Y,
                               int m, const std::vector<std::string> &pool_names, const CvLabels &labels, const CvArgs &a) {
-    // main.rs:402-411, in that order; the "ridge-like" proxy model passes alpha = 1 as the lasso-like one does
-    // (penalise.rs:225-227)
-    const Model models[] = {{"ols", false, 0.0, 0},
-                            {"penalise_glmnet", true, -0.1, 0},
-                            {"penalise_lasso_like", true, 1.0, 0},
-                            {"penalise_ridge_like", true, 0.0, 0},
-                            {"penalise_lasso_like_with_iterative_proxy_norms", true, 1.0, 1},
-                            {"penalise_ridge_like_with_iterative_proxy_norms", true, 1.0, 1}};
+    // the `functions` vector of main.rs:402-411, in that order
+    const GpModelFn functions[] = {ols,
+                                   penalise_glmnet,
+                                   penalise_lasso_like,
+                                   penalise_ridge_like,
+                                   penalise_lasso_like_with_iterative_proxy_norms,
+                                   penalise_ridge_like_with_iterative_proxy_norms};
     const int nmod = 6;
     const int k = a.k_folds, r = a.n_reps;
     SplitMix64 rng(a.seed);
@@ -76,31 +122,8 @@ std::string gp_cross_validate(pg_ctx *ctx, const double *G_dev, int64_t p, int n
         hip_ok(hipMemcpy(xxt.data(), S, sizeof(double) * n * n, hipMemcpyDeviceToHost), "D2H");
         (void)hipFree(S);
     }
-    // one fit of model `mi` on `rows` -> beta_dev, and the name the reference gives it
-    auto fit = [&](int mi, const std::vector<int64_t> &rows, std::string &name) {
-        if (!models[mi].penalised) {
-            ok(ctx, pg_gp_ols_dev(ctx, G_dev, p, n, ld, Y.data(), m, rows.data(), (int)rows.size(), xxt.data(), beta_dev), "ols");
-            name = models[mi].base;
-            return;
-        }
-        // penalised_lambda_path_with_k_fold_cross_validation(.., alpha, false, 0.1, 10): 10 repetitions of k_split(rows, 10)
-        const int nr = (int)rows.size(), inner_reps = 10;
-        int nf = 0;
-        std::vector<int32_t> folds((size_t)inner_reps * nr);
-        for (int rep = 0; rep < inner_reps; ++rep) {
-            std::vector<int64_t> perm = rng.permutation(nr), order(nr);
-            for (int i = 0; i < nr; ++i) order[i] = rows[perm[i]]; // a shuffle of the row VALUES indexes the group list (penalise.rs:452-456)
-            const std::vector<int32_t> g = k_split(nr, 10, order, nf);
-            for (int i = 0; i < nr; ++i) folds[(size_t)rep * nr + i] = g[i]; // group nf: the left-over, never validated
-        }
-        std::vector<double> lam(m), al(m);
-        ok(ctx, pg_gp_penalised_dev(ctx, G_dev, p, n, ld, Y.data(), m, rows.data(), nr, folds.data(), inner_reps, nf, models[mi].alpha,
-                                    models[mi].proxy, 0.1, beta_dev, al.data(), lam.data(), nullptr, xxt.data()), models[mi].base);
-        name = std::string(models[mi].base) + "-alphas_";
-        for (int j = 0; j < m; ++j) name += (j ? "_" : "") + rust_display(al[j]);
-        name += "-lambdas_";
-        for (int j = 0; j < m; ++j) name += (j ? "_" : "") + rust_display(lam[j]);
-    };
+    const GpData data{ctx, G_dev, p, n, ld, &Y, m, &xxt, &rng};
+    auto fit = [&](int mi, const std::vector<int64_t> &rows, std::string &name) { name = functions[mi](data, rows, beta_dev); };
     const size_t cells = (size_t)r * k * nmod * m;
     std::vector<double> cor(cells, NAN), mbe(cells, NAN), mae(cells, NAN), mse(cells, NAN), rmse(cells, NAN);
     std::vector<double> yvp((size_t)r * nmod * n * 2 * m, NAN); // predicted traits, then expected traits
