@@ -114,3 +114,25 @@ def test_cli_pileup2sync_subcommand(tmp_path):
     lines = out.read_text().splitlines()
     assert lines[0] == "#chr\tpos\tref\tG1\tG2\tG3\tG4\tG5"
     assert lines[1].split("\t")[-1] == "0:1:5:0:0:0" and len(lines) == 2
+
+
+def test_cli_keep_lowercase_reference_flag(tmp_path, oracle):
+    """--keep-lowercase-reference reaches the converter (pileup.rs:280-299): on lines whose reference allele is lower
+    case the sync counts differ from the default, and both equal the oracle's."""
+    exe = ROOT / "poolgen_amd" / "csrc" / "poolgen"
+    rng = random.Random(99)
+    lines = [l for l in (_random_line(rng, 5, False) for _ in range(600)) if l.split("\t")[2] in "acgt"][:120]
+    assert len(lines) > 50
+    p = tmp_path / "lc.pileup"; p.write_text("\n".join(lines) + "\n", encoding="latin-1")
+    phen = Path(__file__).parent / "golden" / "test.csv"
+    ps = [0.2] * 5
+    outs = {}
+    for flag in (False, True):
+        out = tmp_path / f"o{int(flag)}.sync"
+        args = [str(exe), "pileup2sync", "-f", str(p), "-p", str(phen), "--min-allele-frequency", "0.0", "-o", str(out)]
+        r = subprocess.run(args + (["--keep-lowercase-reference"] if flag else []), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[flag] = out.read_text().splitlines()[1:]
+        want = [oracle.pileup_to_sync(l, ps, True, 0.01, 1, 1.0, 0.0, keep_lowercase_reference=flag)[1].rstrip("\n") for l in lines]
+        assert outs[flag] == [w for w in want if w]
+    assert outs[False] != outs[True]
