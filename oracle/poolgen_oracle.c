@@ -1264,6 +1264,17 @@ int orc_gp_proxy(const double *Xt, int64_t P, int n, int64_t ld, const double *Y
     return 0;
 }
 
+/* The fits inside the penalised path go through this pointer: NULL = orc_gp_ols (the literal restatement).  The exact
+ * arbiter's tests install exq_gp_ols (oracle/poolgen_exact.c, same signature) so that everything DOWNSTREAM of the fits
+ * (expand_and_contract, error_index, the arg-min / mode rules) is evaluated on binary128-accurate coefficients. */
+typedef int (*orc_gp_ols_fn)(const double *, int64_t, int, int64_t, const double *, int, const int64_t *, int, double *, int);
+static orc_gp_ols_fn orc_gp_ols_hook = NULL;
+void orc_set_gp_ols_hook(void *fn) { orc_gp_ols_hook = (orc_gp_ols_fn)fn; }
+static int path_gp_ols(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k, const int64_t *row_idx,
+                       int n_rows, double *beta, int n_threads) {
+    return (orc_gp_ols_hook ? orc_gp_ols_hook : orc_gp_ols)(Xt, P, n, ld, Y, k, row_idx, n_rows, beta, n_threads);
+}
+
 /* penalised_lambda_path_with_k_fold_cross_validation (:461-669), every mode: alpha >= 0 one lambda path (a = 1),
  * alpha < 0 the grid of path values for alpha too (a = l, :479-498); iterative: the proxy coefficients above, fitted
  * on row_idx (:543, :656), pick the penalised set.  The reference draws the folds with an unseeded rand::thread_rng
@@ -1293,14 +1304,14 @@ int orc_penalised_path_general(const double *Xt, int64_t P, int n, int64_t ld, c
                 if (fold_of[rep * n_rows + i] == fold) iva[nv++] = row_idx[i];
                 else itr[nt++] = row_idx[i];
             }
-            orc_gp_ols(Xt, P, n, ld, Y, k, itr, nt, b_hat, n_threads); /* :526 */
+            path_gp_ols(Xt, P, n, ld, Y, k, itr, nt, b_hat, n_threads); /* :526 */
             for (int a = 0; a < A; a++)
                 for (int li = 0; li < L; li++) {
                     orc_expand_and_contract(b_hat, iterative ? b_proxy : b_hat, P, k, alpha >= 0.0 ? alpha : path[a], path[li], b_new);
                     orc_error_index(Xt, P, n, ld, b_new, k, Y, iva, nv, &perf_l[(((rep * nfolds + fold) * A + a) * L + li) * k]);
                 }
         }
-    orc_gp_ols(Xt, P, n, ld, Y, k, row_idx, n_rows, b_hat, n_threads); /* :573 */
+    path_gp_ols(Xt, P, n, ld, Y, k, row_idx, n_rows, b_hat, n_threads); /* :573 */
     memcpy(beta, b_hat, sizeof(double) * P * k);
     int *acount = (int *)malloc(sizeof(int) * L * 2);
     int *lcount = acount + L;

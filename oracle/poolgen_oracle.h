@@ -169,6 +169,9 @@ int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, co
                               int nfolds, double alpha, double lambda_step, double *beta,
                               double *lambdas_out, double *perf, int n_threads);
 
+/* the fits inside the penalised path: NULL = orc_gp_ols; the exact arbiter's tests install exq_gp_ols (poolgen_exact.c) */
+void orc_set_gp_ols_hook(void *fn);
+
 /* ---- base/pileup.rs: one pileup line -> one sync line (lparse, filter, to_counts, pileup_to_sync) ---------
  * > 0 bytes written (with the trailing newline), 0 = None (dropped), < 0 = the reference panics on this line. */
 int orc_pileup_to_sync2(const char *line, int remove_ns, int keep_lowercase_reference, double max_base_error_rate,

@@ -22,6 +22,13 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def exact():
+    """The binary128 arbiter (oracle/poolgen_exact.c; test infrastructure)."""
+    import oracle_lib
+    return oracle_lib.load_exact()
+
+
+@pytest.fixture(scope="session")
 def native():
     from poolgen_amd import load_library
     return load_library()

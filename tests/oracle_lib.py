@@ -21,9 +21,9 @@ class OrcHdr(C.Structure):
     _fields_ = [("n_alleles", C.c_int), ("allele_ids", C.c_int * 5), ("mean_freq", C.c_double * 5)]
 
 
-def build():
-    so = ODIR / "liboracle.so"
-    src = [ODIR / "poolgen_oracle.c", ODIR / "poolgen_oracle.h"]
+def build(name="liboracle.so"):
+    so = ODIR / name
+    src = [ODIR / "poolgen_oracle.c", ODIR / "poolgen_oracle.h", ODIR / "poolgen_exact.c"]
     if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in src):
         subprocess.check_call(["make", "-C", str(ODIR), "-s"])
     return so
@@ -347,7 +347,98 @@ class Oracle:
         return out
 
 
+class Exact:
+    """oracle/libexact.so: the binary128 arbiter (poolgen_exact.c).  Same inputs as the oracle, results rounded once."""
+
+    def __init__(self, lib, oracle_lib_handle=None):
+        self.lib = lib
+        self._orc = oracle_lib_handle
+        d, i, i64, vp = C.c_double, C.c_int, C.c_int64, C.c_void_p
+        lib.exq_t_two_sided_p.restype = d; lib.exq_t_two_sided_p.argtypes = [d, i]
+        lib.exq_ols_covariate.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, vp, vp, vp, i]
+        lib.exq_kinship.argtypes = [vp, i64, i, i64, vp, i]
+        lib.exq_sym_eig.argtypes = [vp, i, vp, vp]
+        lib.exq_kinship_covariates.argtypes = [vp, i64, i, i64, d, i, vp, vp, vp, i]
+        lib.exq_gp_ols.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i]
+
+    def t_two_sided_p(self, t_abs, df):
+        return self.lib.exq_t_two_sided_p(float(t_abs), int(df))
+
+    def ols_covariate(self, G, Y, C_=None, n=None, threads=0):
+        """exact cells of ols_with_covariate for given covariates (n x m or None) -> dict(beta, var, t, pval), each p x k"""
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        p, ld = G.shape
+        n = ld if n is None else n
+        Y = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        k = Y.shape[1]
+        m, cptr = 0, None
+        if C_ is not None:
+            C_ = np.ascontiguousarray(C_, dtype=np.float64).reshape(n, -1)
+            m, cptr = C_.shape[1], C_.ctypes.data
+        beta, var, t, pv = (np.empty((p, k)) for _ in range(4))
+        rc = self.lib.exq_ols_covariate(G.ctypes.data, p, n, ld, Y.ctypes.data, k, cptr, m, beta.ctypes.data, var.ctypes.data,
+                                        t.ctypes.data, pv.ctypes.data, threads)
+        assert rc == 0, rc
+        return dict(beta=beta, var=var, t=t, pval=pv)
+
+    def kinship(self, G, n=None, threads=0):
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        p, ld = G.shape
+        n = ld if n is None else n
+        K = np.empty((n, n))
+        self.lib.exq_kinship(G.ctypes.data, p, n, ld, K.ctypes.data, threads)
+        return K
+
+    def sym_eig(self, A):
+        A = np.ascontiguousarray(A, dtype=np.float64); n = A.shape[0]
+        ev = np.empty(n); V = np.empty((n, n))
+        self.lib.exq_sym_eig(A.ctypes.data, n, ev.ctypes.data, V.ctypes.data)
+        return ev, V
+
+    def kinship_covariates(self, G, var_explained=0.75, force_m=-1, n=None, threads=0):
+        """K, eigenvalues and the m leading eigenvectors, binary128 end to end -> (m, K, evals, C n x m)"""
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        p, ld = G.shape
+        n = ld if n is None else n
+        K = np.empty((n, n)); ev = np.empty(n); Cb = np.zeros((n, n))
+        m = self.lib.exq_kinship_covariates(G.ctypes.data, p, n, ld, float(var_explained), int(force_m), K.ctypes.data,
+                                            ev.ctypes.data, Cb.ctypes.data, threads)
+        return m, K, ev, Cb.reshape(-1)[: n * m].reshape(n, m).copy()
+
+    def ols_with_covariate(self, G, Y, var_explained=0.75, force_m=-1, n=None, threads=0):
+        """the whole of ols_with_covariate's numeric core in binary128 (K -> eig -> rule -> fits)"""
+        m, K, ev, Cm = self.kinship_covariates(G, var_explained, force_m, n, threads)
+        out = self.ols_covariate(G, Y, Cm if m > 0 else None, n, threads)
+        out.update(m=m, K=K, evals=ev, cov=Cm)
+        return out
+
+    def gp_ols(self, Xt, Y, row_idx, n=None, threads=0):
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        P, ld = Xt.shape
+        n = ld if n is None else n
+        Y = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        ri = np.ascontiguousarray(row_idx, dtype=np.int64)
+        beta = np.empty((P, Y.shape[1]))
+        rc = self.lib.exq_gp_ols(Xt.ctypes.data, P, n, ld, Y.ctypes.data, Y.shape[1], ri.ctypes.data, len(ri), beta.ctypes.data, threads)
+        return rc, beta
+
+    def install_into_oracle(self, oracle, on=True):
+        """the oracle's penalised path then takes its fold fits from exq_gp_ols (everything downstream stays the oracle's)"""
+        fn = C.cast(self.lib.exq_gp_ols, C.c_void_p) if on else C.c_void_p(None)
+        oracle.lib.orc_set_gp_ols_hook.argtypes = [C.c_void_p]
+        oracle.lib.orc_set_gp_ols_hook.restype = None
+        oracle.lib.orc_set_gp_ols_hook(fn)
+
+
 _ORACLE = None
+_EXACT = None
+
+
+def load_exact() -> Exact:
+    global _EXACT
+    if _EXACT is None:
+        _EXACT = Exact(C.CDLL(str(build("libexact.so"))))
+    return _EXACT
 
 
 def load() -> Oracle:
