@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--force-m", type=int, default=-1, help=">=0 forces the number of kinship PCs")
     ap.add_argument("--ld", type=int, default=0, help="leading dimension of G in doubles (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep-legs", action="store_true", help="skip the two untimed legs that measure k_ols_sweep")
+    ap.add_argument("--sweep-steps", type=int, default=5, help="steps per sweep leg (after the timed region)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     args = ap.parse_args()
 
@@ -100,12 +102,23 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from poolgen_amd import Engine, synth
-    from poolgen_amd.distributed import ols_with_covariate_sharded, shard_range
+    from poolgen_amd.distributed import ols_with_covariate_sharded, setup_comm, shard_range
 
     n, p_total, k = args.pools, args.loci, 1
     lo, hi = shard_range(p_total, rank, world)
     p_local = hi - lo
     eng = Engine(dev_index)
+    # the kinship all-reduce runs inside libpoolgen_hip on its own RCCL communicator (pg_comm_*); torch.distributed only
+    # carries the 128-byte unique id and the timing barriers.  Falls back to torch.distributed's all-reduce only if the
+    # library cannot set its communicator up (reported in the JSON line as "allreduce").
+    allreduce_impl = "none (1 rank)"
+    if world > 1:
+        try:
+            allreduce_impl = "RCCL inside libpoolgen_hip (pg_allreduce_sum_dev)" if setup_comm(eng) else \
+                f"torch.distributed ({os.environ.get('POOLGEN_BENCH_BACKEND', 'nccl')})"
+        except Exception as e:  # keep the run alive: the scaling numbers are worth more than the purity of the path
+            print(f"warning: library communicator unavailable ({e}); using torch.distributed all_reduce", file=sys.stderr)
+            allreduce_impl = "torch.distributed (library communicator failed: %s)" % type(e).__name__
     G = synth.genotype_matrix(p_local, n, dev, start=lo, ld=(args.ld or None))
     # phenotype: 10 causal loci spread over the WHOLE matrix; any rank can regenerate any locus
     causal = [(p_total * (2 * i + 1)) // 20 for i in range(10)]
@@ -143,6 +156,44 @@ def main():
     red_ms, red_n = eng.profile_get("kinship_reduce")
     sw_ms, sw_n = eng.profile_get("sweep")
     fin_ms, fin_n = eng.profile_get("sweep_finish")
+
+    # ---- after the timed region: the general path, so that the per-locus sweep (north_star's HBM-roofline kernel) has a
+    # driver-run number too.  At the default -x 0.75 the eigen rule gives m = 0 and the fits are closed from sums fused into
+    # the kinship pass: k_ols_sweep is never launched by the headline.  Two extra legs of `extra` steps each:
+    #   two_pass : same analysis with the fusion off -> kinship (no fused sums) + k_ols_sweep with [1 | g]   (m = 0)
+    #   m8       : --force-m 8 -> host eigenvectors + k_ols_sweep with [1 | C(8) | g]                           (m = 8)
+    legs = {}
+    extra = 0 if args.no_sweep_legs else args.sweep_steps
+    if extra > 0 and args.force_m < 0:
+        for tag, fm, env in (("two_pass", -1, "1"), ("m8", 8, None)):
+            old = os.environ.get("POOLGEN_TWO_PASS")
+            if env:
+                os.environ["POOLGEN_TWO_PASS"] = env
+            try:
+                def leg_step():
+                    return ols_with_covariate_sharded(eng, G, p_total, Y, args.var_explained, fm, n, out)
+                leg_step(); leg_step()
+                eng.profile_reset()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(extra):
+                    lm = leg_step()[0]
+                fence()
+                ldt = time.perf_counter() - t1
+            finally:
+                if env:
+                    if old is None:
+                        del os.environ["POOLGEN_TWO_PASS"]
+                    else:
+                        os.environ["POOLGEN_TWO_PASS"] = old
+            if world > 1:
+                tt = torch.tensor([ldt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ldt = float(tt.item())
+            lk_ms, lk_n = eng.profile_get("kinship")
+            ls_ms, ls_n = eng.profile_get("sweep")
+            legs[tag] = dict(m=int(lm), ms_per_step=ldt / extra * 1e3, kin_avg=lk_ms / max(lk_n, 1),
+                             sw_avg=ls_ms / max(ls_n, 1), sw_n=int(ls_n))
     eng.profile(False)
 
     if rank == 0:
@@ -152,33 +203,36 @@ def main():
         sw_avg = sw_ms / max(sw_n, 1)
         sweep_bytes = (8.0 * n + 24.0 * k) * p_local       # 8n read + 24k written per locus
         kin_flops = 2.0 * n * n * p_local                   # reference computes the full product
-        sweep_gbs = sweep_bytes / (sw_avg * 1e-3) / 1e9 if sw_avg > 0 else 0.0
         kin_tflops = kin_flops / (kin_avg * 1e-3) / 1e12 if kin_avg > 0 else 0.0
-        traffic = None
+        traffic_db = {}
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                key = "kinship" if kin_avg >= sw_avg else "sweep"
                 if tj.get("workload") == f"{n}x{p_local}":
-                    traffic = tj.get(key + "_hbm_bytes_per_launch")
+                    traffic_db = tj
             except Exception:
-                traffic = None
+                traffic_db = {}
+        traffic_note = ("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command "
+                        "(counters cannot be read from inside the process); file profiles/pmc_traffic.json, see its 'source'")
         tiles = (n + 15) // 16
+        # MFMA work the kernel EXECUTES: 16x16x4 tiles of the upper triangle (n <= 208) incl. padding to a multiple of 16
+        # and the lower halves of the diagonal tiles; USEFUL = the n (n + 1) / 2 distinct products of the triangle
         kin_exec_flops = (tiles * (tiles + 1) // 2 if tiles <= 13 else tiles * tiles) * 512.0 * p_local
-        kin_exec_tflops = kin_exec_flops / (kin_avg * 1e-3) / 1e12 if kin_avg > 0 else 0.0
-        if kin_avg >= sw_avg:
-            # achieved = ALGORITHMIC flops (2 n^2 p, the full product the reference forms) / time; the
-            # kernel executes only the upper triangle, so the MFMA pipe utilisation is reported next to it
-            roof = {"kernel": "k_kinship_syrk", "bound": "mfma", "achieved": kin_tflops,
-                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kin_tflops / FP64_MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "avg_ms": kin_avg, "launches": kin_n,
-                    "executed_mfma_tflops": kin_exec_tflops,
-                    "executed_mfma_frac": kin_exec_tflops / FP64_MFMA_PEAK_TFLOPS}
-        else:
-            roof = {"kernel": "k_ols_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": sw_avg,
-                    "launches": sw_n}
+        kin_useful_flops = float(n) * (n + 1) * p_local
+        per_s = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"kernel": "k_kinship_syrk", "bound": "mfma",
+                "achieved": per_s(kin_exec_flops, kin_avg), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": per_s(kin_exec_flops, kin_avg) / FP64_MFMA_PEAK_TFLOPS,
+                "what": "EXECUTED fp64 MFMA flop/s (matrix-pipe utilisation); the peak is AMD's datasheet 78.6 TFLOP/s, confirmed at "
+                        "78.0 by tools/microbench.hip (profiles/r02_microbench.log)",
+                "useful_tflops": per_s(kin_useful_flops, kin_avg),
+                "useful_frac": per_s(kin_useful_flops, kin_avg) / FP64_MFMA_PEAK_TFLOPS,
+                "algorithmic_tflops": kin_tflops,
+                "algorithmic_note": "2 n^2 p / time (SURVEY 8d: the reference forms the full product); exceeds the peak because only "
+                                    "one triangle is computed -- not a utilisation",
+                "traffic": traffic_db.get("kinship_hbm_bytes_per_launch"), "traffic_note": traffic_note,
+                "avg_ms": kin_avg, "launches": kin_n}
         rec = {
             "metric": "loci/sec ols_iter_with_kinship, 200 pools x 10M loci",
             "value": value, "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,19 +241,34 @@ def main():
             "config": {"workload": f"ols_iter_with_kinship {n} pools x {p_total} loci (BASELINE configs[2])",
                        "pools": n, "loci_total": p_total, "loci_per_gpu": p_local, "traits": k,
                        "xxt_eigen_variance_explained": args.var_explained, "n_eigenvecs": m,
-                       "parallelism": f"locus-sharded x{world}, 1 all-reduce of {n}x{n} fp64"},
+                       "parallelism": f"locus-sharded x{world}, 1 all-reduce of {n}x{n} fp64", "allreduce": allreduce_impl},
             "roofline": roof,
             "kernels": {
-                "k_kinship_syrk": {"avg_ms": kin_avg, "tflops_algorithmic": kin_tflops,
-                                   "frac_of_fp64_mfma_peak": kin_tflops / FP64_MFMA_PEAK_TFLOPS},
+                "k_kinship_syrk": {"avg_ms": kin_avg, "executed_mfma_tflops": per_s(kin_exec_flops, kin_avg),
+                                   "useful_tflops": per_s(kin_useful_flops, kin_avg), "algorithmic_tflops": kin_tflops},
                 "k_kinship_reduce": {"avg_ms": red_ms / max(red_n, 1)},
-                "k_ols_sweep": ({"avg_ms": sw_avg, "gbs_algorithmic": sweep_gbs,
-                                 "frac_of_hbm_peak": sweep_gbs / HBM_PEAK_GBS} if sw_n else
-                                {"avg_ms": 0.0, "note": "not launched: m = 0 fits closed from the sums fused into the kinship pass"}),
+                "k_ols_sweep": ({"avg_ms": sw_avg, "gbs_algorithmic": sweep_bytes / (sw_avg * 1e-3) / 1e9,
+                                 "frac_of_hbm_peak": sweep_bytes / (sw_avg * 1e-3) / 1e9 / HBM_PEAK_GBS} if sw_n else
+                                {"avg_ms": 0.0, "note": "not launched by the headline: m = 0 fits closed from the sums fused into the "
+                                                        "kinship pass; see roofline_sweep for the general path"}),
                 "k_sweep_finish": {"avg_ms": fin_ms / max(fin_n, 1), "launches": fin_n},
                 "host_eig_and_glue_ms": ms_per_step - kin_avg - sw_avg - red_ms / max(red_n, 1) - fin_ms / max(fin_n, 1),
             },
         }
+        if legs:
+            rs = {"kernel": "k_ols_sweep", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "bytes_per_locus": 8.0 * n + 24.0 * k, "loci_per_launch": p_local, "steps_per_leg": extra,
+                  "what": "algorithmic bytes (SURVEY 8d: 8n read + 24k written per locus) / HIP-event launch time, measured after "
+                          "the timed headline region in the same process", "traffic_note": traffic_note}
+            for tag, L in legs.items():
+                gbs = sweep_bytes / (L["sw_avg"] * 1e-3) / 1e9 if L["sw_avg"] > 0 else 0.0
+                rs[tag] = {"n_eigenvecs": L["m"], "avg_ms": L["sw_avg"], "launches": L["sw_n"], "achieved": gbs,
+                           "frac": gbs / HBM_PEAK_GBS, "ms_per_step": L["ms_per_step"],
+                           "loci_per_s": p_total / (L["ms_per_step"] * 1e-3), "kinship_avg_ms": L["kin_avg"],
+                           "traffic": traffic_db.get(f"sweep_{tag}_hbm_bytes_per_launch")}
+            rs["achieved"] = rs["two_pass"]["achieved"]; rs["frac"] = rs["two_pass"]["frac"]
+            rs["traffic"] = rs["two_pass"]["traffic"]
+            rec["roofline_sweep"] = rs
         if world == 1 and not args.no_cpu_baseline:
             s = min(args.cpu_sample, p_local)
             rec["cpu_baseline"] = cpu_baseline(G[:s, :n].cpu().numpy(), Y, args.var_explained, args.force_m)

@@ -66,7 +66,7 @@ int pg_synchronize(pg_ctx *ctx);
 /* Per-kernel HIP-event timing (used by bench.py for the roofline record). */
 enum pg_kernel_id { PG_K_KINSHIP = 0, PG_K_KINSHIP_REDUCE = 1, PG_K_SWEEP = 2, PG_K_OLS_ITER = 3,
                     PG_K_PEARSON = 4, PG_K_CHISQ = 5, PG_K_GP_XXT = 6, PG_K_GP_BETA = 7,
-                    PG_K_SWEEP_FINISH = 8, PG_K_COUNT = 9 };
+                    PG_K_SWEEP_FINISH = 8, PG_K_ALLREDUCE = 9, PG_K_COUNT = 10 };
 int pg_profile_enable(pg_ctx *ctx, int on);
 int pg_profile_reset(pg_ctx *ctx);
 /* Synchronises, then returns total milliseconds and launch count of one kernel id. */
@@ -76,7 +76,7 @@ int pg_profile_get(pg_ctx *ctx, int kernel_id, double *total_ms, int64_t *launch
  * ols_iter_with_kinship   == gwas::ols_with_covariate (gwas/ols.rs:278-436, numeric core
  * :291-370; CLI main.rs:280-298).  Staged so that loci can be sharded over GPUs:
  *   1. pg_kinship_partial_dev : S_r = G_r^T-contraction over this rank's loci (unscaled)
- *   2. (multi-GPU) all-reduce(sum) of S over ranks -- RCCL via the caller
+ *   2. (multi-GPU) pg_allreduce_sum_dev : sum of S over the ranks (RCCL, see "Multi-GPU" below)
  *   3. pg_kinship_set        : K = S / p_total, eigen-decomposition, n_eigenvecs rule,
  *                               orthonormal basis of [1 | C], projected phenotypes
  *   4. pg_ols_sweep_dev      : per-column fit of y ~ [1 | C | g], last coefficient
@@ -114,6 +114,34 @@ int pg_ols_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64
 int pg_ols_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, const double *Y,
                    int k, double var_explained, int force_m, int *m_out, double *K_out,
                    double *beta, double *var, double *pval);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-GPU: loci shard over the GPUs of a node in contiguous slabs, one pg_ctx (= one GPU, one host thread or
+ * process) per rank.  The reference's parallel axis is the same one -- a worker per file chunk (base/sync.rs:913-939)
+ * -- and the only quantity that needs every worker's loci is the kinship sum (gwas/ols.rs:291-295): ONE in-place
+ * RCCL all-reduce(sum) of n x n doubles over xGMI (320 KB at n = 200: latency-bound).  Outputs stay sharded (rank
+ * order = locus order).  ols_iter / pearson_corr / chisq_test need no exchange at all.
+ *   bootstrap: one rank calls pg_comm_unique_id and hands the PG_COMM_ID_BYTES to the others by any means (threads
+ *   of one process: shared memory; processes: a file, MPI, a torch.distributed store); then EVERY rank calls
+ *   pg_comm_init_rank(ctx, id, nranks, rank) -- collective, like ncclCommInitRank.  RCCL itself is loaded on first use.
+ * pg_allreduce_sum_dev is the identity on a context without communicator, so single-GPU callers may use the
+ * sharded entry point unchanged.
+ * ------------------------------------------------------------------------------------- */
+#define PG_COMM_ID_BYTES 128
+int pg_comm_unique_id(void *id_out);
+int pg_comm_init_rank(pg_ctx *ctx, const void *id, int nranks, int rank);
+int pg_comm_destroy(pg_ctx *ctx);
+int pg_comm_size(const pg_ctx *ctx);
+int pg_comm_rank(const pg_ctx *ctx);
+int pg_comm_version(int *version_out); /* ncclGetVersion of the RCCL that was loaded */
+/* In-place sum over the ranks, enqueued on the context's stream (ordered with the kernels around it). */
+int pg_allreduce_sum_dev(pg_ctx *ctx, double *buf_dev, int64_t count);
+/* One rank's share of ols_iter_with_kinship: partial kinship of its p_local columns -> all-reduce -> the n x n
+ * step with p_total (every rank computes the same m, basis and projected phenotypes) -> sweep of its own slab.
+ * beta/var/pval: p_local x k on this rank's device. */
+int pg_ols_kinship_sharded_dev(pg_ctx *ctx, const double *G_dev, int64_t p_local, int64_t p_total, int n, int64_t ld,
+                               const double *Y, int k, double var_explained, int force_m, int *m_out, double *K_out,
+                               double *beta_dev, double *var_dev, double *pval_dev);
 
 /* ---------------------------------------------------------------------------------------
  * Sync-derived per-locus operators.  The reference calls these once per text line through

@@ -49,6 +49,14 @@ SIGNATURES = {
     "pg_ols_sweep_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "pg_ols_kinship_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _d, _i, _pi, _vp, _vp, _vp, _vp]),
     "pg_ols_kinship": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _d, _i, _pi, _vp, _vp, _vp, _vp]),
+    "pg_comm_unique_id": (_i, [_vp]),
+    "pg_comm_init_rank": (_i, [_vp, _vp, _i, _i]),
+    "pg_comm_destroy": (_i, [_vp]),
+    "pg_comm_size": (_i, [_vp]),
+    "pg_comm_rank": (_i, [_vp]),
+    "pg_comm_version": (_i, [_pi]),
+    "pg_allreduce_sum_dev": (_i, [_vp, _vp, _i64]),
+    "pg_ols_kinship_sharded_dev": (_i, [_vp, _vp, _i64, _i64, _i, _i64, _vp, _i, _d, _i, _pi, _vp, _vp, _vp, _vp]),
     "pg_ols_iter_batch_dev": (_i, _batch),
     "pg_pearson_batch_dev": (_i, _batch),
     "pg_chisq_batch_dev": (_i, [_vp, _vp, _i64, _i, _vp, _pf, _vp, _vp, _vp, _vp]),
@@ -76,7 +84,7 @@ SIGNATURES = {
 }
 
 KERNEL_IDS = {"kinship": 0, "kinship_reduce": 1, "sweep": 2, "ols_iter": 3, "pearson": 4,
-              "chisq": 5, "gp_xxt": 6, "gp_beta": 7, "sweep_finish": 8}
+              "chisq": 5, "gp_xxt": 6, "gp_beta": 7, "sweep_finish": 8, "allreduce": 9}
 
 
 def load_library():

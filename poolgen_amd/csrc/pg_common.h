@@ -60,6 +60,9 @@ struct pg_ctx {
     // small pinned host staging
     void *pin = nullptr;
     size_t pin_bytes = 0;
+    // RCCL communicator of the locus-sharded path (pg_comm.cpp); null = single GPU
+    void *comm = nullptr;
+    int comm_size = 1, comm_rank = 0;
 };
 
 int pg_fail(pg_ctx *ctx, int code, const char *fmt, ...);

@@ -64,6 +64,7 @@ extern "C" void pg_destroy(pg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)pg_comm_destroy(ctx);
     for (auto &p : ctx->ev_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : ctx->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (ctx->ws) (void)hipFree(ctx->ws);

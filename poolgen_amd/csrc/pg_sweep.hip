@@ -133,8 +133,160 @@ __device__ __forceinline__ void sweep_chunk(const double *__restrict__ G,
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- the sweep proper ---------------------------------------------------------------------------------------
+// Memory access: every 128-byte line of G is fetched exactly ONCE.  A row (locus) is 8*ld bytes, so consecutive rows start
+// at different offsets inside a line (ld = 200: every other row starts 64 bytes into one) and a per-row grid of 256-byte
+// chunks would touch the lines at both ends of a chunk twice -- measured on the first version of this kernel as 1.14x the
+// algorithmic bytes (18.49 GB moved for 16.24 GB).  Here g = 128 / gcd(8 ld, 128) consecutive rows (1, 2, 4 or 8) form a
+// SUPER-ROW of g*ld doubles that starts and ends on a line boundary; a lane owns one super-row and walks its g loci one
+// after the other, a wave tile is 64 super-rows = one contiguous, line-aligned slab, and the slab is read in aligned
+// 256-byte chunks (16 lanes x 16 bytes each, 4 super-rows per load instruction).  All lanes cross from one locus to the
+// next at the same chunk position, so the pool index -- and with it the W operand -- stays wave-uniform (scalar loads).
+// The loads of chunk c + 1 (or of the next tile's first chunk) are in flight while chunk c is consumed and while the
+// p-value code of a finished locus runs: 16 KB per wave, 8 waves per CU.
+struct SweepGeom {
+    int g;          // loci per super-row
+    int nch;        // 32-double chunks per super-row
+    int64_t sl;     // doubles per super-row = g * ld
+    int64_t total;  // p * ld: loads are clamped to the last pair of the matrix
+};
+
+// The 16 staging registers of a chunk are named variables, not an array: they are live across the consumption loop (the
+// prefetch), and an array that is live around a loop with this much control flow ends up in scratch memory.
+static_assert(SW_NLD == 16, "the staging macros below spell out 16 load instructions per chunk");
+#define SW_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define SW_DECL(r) double2 v##r;
+#define SW_LOAD(r)                                                                                        \
+    {                                                                                                     \
+        int64_t idx_ = ibase_ + (int64_t)(SW_RPI * r) * Q.sl;                                             \
+        idx_ = idx_ < lastpair ? idx_ : lastpair;                                                         \
+        v##r = *reinterpret_cast<const double2 *>(G + idx_);                                              \
+    }
+#define SW_ISSUE(tt, cc)                                                                                  \
+    {                                                                                                     \
+        const int64_t ibase_ = ((tt) * 64 + lr) * Q.sl + (int64_t)(cc) * SW_CH + 2 * piece;              \
+        SW_REP16(SW_LOAD)                                                                                 \
+    }
+#define SW_STAGE(r) *reinterpret_cast<double2 *>(&tile[(SW_RPI * r + lr) * SW_PITCH + 2 * piece]) = v##r;
+
 template <int C>
 __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
+    const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
+    const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
+    double *__restrict__ pval, const SweepDims D, const SweepGeom Q) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double *tile = lds + wave * SW_TILE;
+    const double *row = tile + lane * SW_PITCH;
+    const int lr = lane / SW_LPR, piece = lane % SW_LPR;
+    const int64_t wstride = (int64_t)gridDim.x * SW_WAVES;
+    const int64_t lastpair = Q.total - 2;
+    const int n = D.n, ld = (int)D.ld;
+
+    SW_REP16(SW_DECL)
+    int64_t t = (int64_t)blockIdx.x * SW_WAVES + wave;
+    if (t >= D.ntiles) return;
+    SW_ISSUE(t, 0)
+    for (; t < D.ntiles; t += wstride) {
+        double acc[C];
+        double s2 = 0.0, shift = 0.0;
+        int j = 0, pos = 0; // locus within the super-row, position within its row (pools n..ld-1 are padding)
+        for (int ch = 0; ch < Q.nch; ++ch) {
+            SW_REP16(SW_STAGE)
+            __builtin_amdgcn_wave_barrier();
+            {   // next chunk of this tile, else the first chunk of the wave's next tile (clamped loads: harmless past the end)
+                const bool more = ch + 1 < Q.nch;
+                const int64_t tn = more ? t : t + wstride;
+                const int cn = more ? ch + 1 : 0;
+                SW_ISSUE(tn, cn)
+            }
+            const int64_t left = Q.sl - (int64_t)ch * SW_CH;
+            const int iend = left < SW_CH ? (int)left : SW_CH;
+            int i = 0;
+            while (i < iend) {
+                if (pos >= n) { // padding between n and ld
+                    int skip = ld - pos;
+                    skip = skip < iend - i ? skip : iend - i;
+                    i += skip; pos += skip;
+                    if (pos == ld) { pos = 0; ++j; }
+                    continue;
+                }
+                if (pos == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = 0.0;
+                    s2 = 0.0;
+                    shift = row[i]; // any per-locus constant cancels because Z contains the intercept
+                }
+                int len = n - pos;
+                len = len < iend - i ? len : iend - i;
+                const double *Wp = W + (size_t)pos * C;
+                if (i == 0 && len == SW_CH) {
+#pragma unroll
+                    for (int q = 0; q < SW_CH; q += 2) {
+                        const double2 g2 = *reinterpret_cast<const double2 *>(&row[q]);
+                        const double ga = g2.x - shift;
+                        const double gb = g2.y - shift;
+                        s2 = fma(ga, ga, s2);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = fma(ga, Wp[q * C + c], acc[c]);
+                        s2 = fma(gb, gb, s2);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = fma(gb, Wp[(q + 1) * C + c], acc[c]);
+                    }
+                } else if (((i | len) & 1) == 0) {
+#pragma unroll 4
+                    for (int q = 0; q < len; q += 2) {
+                        const double2 g2 = *reinterpret_cast<const double2 *>(&row[i + q]);
+                        const double ga = g2.x - shift;
+                        const double gb = g2.y - shift;
+                        s2 = fma(ga, ga, s2);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = fma(ga, Wp[q * C + c], acc[c]);
+                        s2 = fma(gb, gb, s2);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = fma(gb, Wp[(q + 1) * C + c], acc[c]);
+                    }
+                } else { // odd pool counts: one value at a time
+                    for (int q = 0; q < len; ++q) {
+                        const double ga = row[i + q] - shift;
+                        s2 = fma(ga, ga, s2);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = fma(ga, Wp[q * C + c], acc[c]);
+                    }
+                }
+                i += len; pos += len;
+                if (pos == n) {
+                    // ---- per-locus closing arithmetic (gwas/ols.rs:102-116, 139-158) ---------------------
+                    const int64_t l = (t * 64 + lane) * Q.g + j;
+                    if (l < D.p) {
+                        double uu = 0.0;
+#pragma unroll
+                        for (int a = 0; a < C; ++a) uu = (a < D.m1) ? fma(acc[a], acc[a], uu) : uu;
+                        const double sgg = s2 - uu;
+                        const bool bad = !(sgg > D.tau * s2);
+                        for (int jt = 0; jt < D.k; ++jt) {
+                            double sgy = 0.0;
+#pragma unroll
+                            for (int a = 0; a < C; ++a) sgy = (a == D.m1 + jt) ? acc[a] : sgy;
+                            double b, vb, pv;
+                            ols_close(sgg, sgy, syy[jt], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
+                            beta[l * D.k + jt] = b;
+                            var[l * D.k + jt] = vb;
+                            pval[l * D.k + jt] = pv;
+                        }
+                    }
+                    if (n == ld) { pos = 0; ++j; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---- round-1 form of the sweep (per-row 256-byte chunk grid, no prefetch), kept for A/B timing: POOLGEN_SWEEP_V1=1
+template <int C>
+__global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep_v1(
     const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
     const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
     double *__restrict__ pval, const SweepDims D) {
@@ -428,16 +580,32 @@ struct SweepArgs {
     const double *G, *W, *syy, *tcoef;
     double *beta, *var, *pval;
     SweepDims D;
+    SweepGeom Q;
 };
 
 template <int C>
 int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
     const size_t shmem = (size_t)SW_WAVES * SW_TILE * sizeof(double);
+    if (std::getenv("POOLGEN_SWEEP_V1")) {
+        SweepDims D1 = A.D;
+        D1.ntiles = (A.D.p + 63) / 64;
+        int64_t blocks = (D1.ntiles + SW_WAVES - 1) / SW_WAVES;
+        const int64_t cap = (int64_t)ctx->cus * 8;
+        const int g1 = (int)(blocks < cap ? blocks : cap);
+        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ols_sweep_v1<C>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        pg_prof_begin(ctx, PG_K_SWEEP);
+        hipLaunchKernelGGL(k_ols_sweep_v1<C>, dim3(g1), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W,
+                           A.syy, A.tcoef, A.beta, A.var, A.pval, D1);
+        pg_prof_end(ctx);
+        PG_HIP(ctx, hipGetLastError());
+        return PG_OK;
+    }
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ols_sweep<C>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     pg_prof_begin(ctx, PG_K_SWEEP);
     hipLaunchKernelGGL(k_ols_sweep<C>, dim3(grid), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W,
-                       A.syy, A.tcoef, A.beta, A.var, A.pval, A.D);
+                       A.syy, A.tcoef, A.beta, A.var, A.pval, A.D, A.Q);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipGetLastError());
     return PG_OK;
@@ -700,7 +868,17 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
     SweepArgs P;
     P.G = G_dev; P.W = ctx->W_dev; P.syy = ctx->syy_dev; P.tcoef = ctx->tcoef_dev;
     P.beta = beta_dev; P.var = var_dev; P.pval = pval_dev;
-    P.D.p = p; P.D.ld = ld; P.D.ntiles = (p + 63) / 64;
+    // super-rows: g consecutive loci whose g * ld doubles start and end on a 128-byte line (see k_ols_sweep)
+    {
+        int64_t bytes = 8 * ld, gc = 128;
+        while (bytes % gc) gc >>= 1; // gcd(8 ld, 128): 8 ld is a multiple of 16
+        P.Q.g = (int)(128 / gc);
+        P.Q.sl = (int64_t)P.Q.g * ld;
+        P.Q.nch = (int)((P.Q.sl + SW_CH - 1) / SW_CH);
+        P.Q.total = p * ld;
+    }
+    const int64_t nsr = (p + P.Q.g - 1) / P.Q.g;
+    P.D.p = p; P.D.ld = ld; P.D.ntiles = (nsr + 63) / 64;
     P.D.n = n; P.D.m1 = ctx->st_m + 1; P.D.k = ctx->st_k;
     P.D.tdf = ctx->tcoef_df; P.D.ntcoef = ctx->tcoef_len;
     P.D.dfe = (double)n - (double)(ctx->st_m + 2);
@@ -717,7 +895,9 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
         return PG_OK;
     }
     int64_t blocks = (P.D.ntiles + SW_WAVES - 1) / SW_WAVES;
-    const int64_t cap = (int64_t)cus * 8;
+    int mult = 8;
+    if (const char *e = std::getenv("POOLGEN_SWEEP_GRID_MULT")) mult = std::max(1, std::atoi(e)); // experiments
+    const int64_t cap = (int64_t)cus * mult;
     const int grid = (int)(blocks < cap ? blocks : cap);
     switch (ctx->st_cols) {
     case 2: return launch_sweep<2>(ctx, P, grid);

@@ -89,6 +89,57 @@ class Engine:
     def synchronize(self):
         self._check(self._lib.pg_synchronize(self._ctx), "pg_synchronize")
 
+    # ---- multi-GPU: RCCL inside the library (pg_comm.cpp) ------------------------------------
+    def comm_unique_id(self) -> bytes:
+        """ncclGetUniqueId through the library; one rank calls it and hands the bytes to the others."""
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.pg_comm_unique_id(buf), "pg_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        """Collective: every rank of the node calls it with the same id (ncclCommInitRank on this engine's GPU)."""
+        assert len(unique_id) == 128
+        self._check(self._lib.pg_comm_init_rank(self._ctx, C.c_char_p(unique_id), int(nranks), int(rank)), "pg_comm_init_rank")
+
+    def comm_destroy(self):
+        self._check(self._lib.pg_comm_destroy(self._ctx), "pg_comm_destroy")
+
+    @property
+    def comm_size(self) -> int:
+        return int(self._lib.pg_comm_size(self._ctx))
+
+    @property
+    def comm_rank(self) -> int:
+        return int(self._lib.pg_comm_rank(self._ctx))
+
+    def comm_version(self) -> int:
+        v = C.c_int()
+        self._check(self._lib.pg_comm_version(C.byref(v)), "pg_comm_version")
+        return v.value
+
+    def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the ranks of this engine's communicator (identity without one), on the engine's stream."""
+        self._check(self._lib.pg_allreduce_sum_dev(self._ctx, self._dev(t, torch.float64), t.numel()), "pg_allreduce_sum_dev")
+        return t
+
+    def ols_with_covariate_sharded(self, G: torch.Tensor, p_total: int, Y, var_explained: float = 0.75, force_m: int = -1,
+                                   n: int | None = None, out=None, want_K: bool = False):
+        """One rank's share of ols_iter_with_kinship in ONE library call (pg_ols_kinship_sharded_dev): partial kinship,
+        RCCL all-reduce, n x n step with p_total, sweep of the own slab.  Returns (m, K or None, beta, var, pval)."""
+        p, ld, n = self._g_dims(G, n)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        if out is None:
+            out = torch.empty((3, p, k), dtype=torch.float64, device=G.device)
+        K = np.empty((n, n)) if want_K else None
+        m = C.c_int()
+        self._check(self._lib.pg_ols_kinship_sharded_dev(self._ctx, self._dev(G, torch.float64), p, int(p_total), n, ld,
+                                                         Yh.ctypes.data, k, float(var_explained), int(force_m), C.byref(m),
+                                                         K.ctypes.data if want_K else None, out[0].data_ptr(),
+                                                         out[1].data_ptr(), out[2].data_ptr()),
+                    "pg_ols_kinship_sharded_dev")
+        return m.value, K, out[0], out[1], out[2]
+
     # ---- kinship path ---------------------------------------------------------------------
     @staticmethod
     def _g_dims(G: torch.Tensor, n: int | None):

@@ -24,28 +24,41 @@ def make(p, n, seed, k=2):
     return G, Y
 
 
-def errs(got, ex):
-    """(max relative error of beta where |beta| is not ~0, max abs error of beta, max rel of var, max abs of p)"""
+def formula_p(oracle, ex, n):
+    """The REFERENCE'S p-value formula, 2 (1 - StudentsT(n-1).cdf(|t|)) in fp64 as statrs evaluates it (gwas/ols.rs:139-153;
+    the oracle's port reproduces statrs' goldens to the last digit), at the binary128 t.  This, not the mathematically exact
+    tail, is what "the reference's p-value" means: for |t| << 1 statrs' h = nu / (nu + t^2) rounds next to 1 and its p is
+    quantised by up to 2.5e-7 (measured in tests/test_exact_arbiter.py); the product mirrors that quantisation on purpose."""
+    t = np.abs(ex["t"]).reshape(-1)
+    out = np.array([1.0 if (x <= 2.220446049250313e-16 or np.isnan(x)) else
+                    2.0 * (1.0 - oracle.lib.orc_students_t_cdf(float(x), float(n - 1))) for x in t])
+    out[np.isnan(ex["beta"]).reshape(-1)] = np.nan
+    return out.reshape(ex["t"].shape)
+
+
+def errs(got, ex, pf):
+    """(max relative error of beta where |beta| is not ~0, max abs error of beta, max rel of var, max abs of p against the
+    reference's formula at the exact t, max abs of p against the exact tail)"""
     b, v, p = got
     big = np.abs(ex["beta"]) > 1e-6 * np.abs(ex["beta"]).max()
     rb = float(np.max(np.abs(b - ex["beta"])[big] / np.abs(ex["beta"])[big]))
     ab = float(np.max(np.abs(b - ex["beta"])))
     rv = float(np.max(np.abs(v - ex["var"]) / np.abs(ex["var"])))
-    dp = float(np.max(np.abs(p - ex["pval"])))
-    return rb, ab, rv, dp
+    return rb, ab, rv, float(np.max(np.abs(p - pf))), float(np.max(np.abs(p - ex["pval"])))
 
 
 def report(tag, gpu, orc):
-    print(f"\n[{tag}] |GPU - exact|: rel beta {gpu[0]:.2e} abs beta {gpu[1]:.2e} rel var {gpu[2]:.2e} abs p {gpu[3]:.2e}   "
-          f"|oracle - exact|: rel beta {orc[0]:.2e} abs beta {orc[1]:.2e} rel var {orc[2]:.2e} abs p {orc[3]:.2e}")
+    f = lambda e: f"rel beta {e[0]:.2e} abs beta {e[1]:.2e} rel var {e[2]:.2e} abs p {e[3]:.2e} (vs the exact tail {e[4]:.2e})"
+    print(f"\n[{tag}]\n    |GPU    - exact|: {f(gpu)}\n    |oracle - exact|: {f(orc)}")
 
 
-def assert_close(got, ex, what):
+def assert_close(got, ex, pf, what):
     b, v, p = got
     assert np.array_equal(np.isnan(b), np.isnan(ex["beta"])), what + " NaN pattern"
     assert np.allclose(b, ex["beta"], rtol=RTOL, atol=1e-10), what + " beta"
     assert np.allclose(v, ex["var"], rtol=RTOL, atol=1e-13), what + " var"
-    assert np.max(np.abs(p - ex["pval"])) <= PTOL, what + " pval"
+    assert np.max(np.abs(p - pf)) <= PTOL, what + " pval"
+    assert np.max(np.abs(p - ex["pval"])) <= 1e-6, what + " pval against the exact tail (statrs' own quantisation)"
 
 
 @pytest.mark.parametrize("n,m,k", [(60, 1, 1), (60, 3, 2), (60, 8, 1), (200, 1, 1), (200, 3, 2), (200, 8, 3)])
@@ -59,12 +72,13 @@ def test_covariate_sweep_against_binary128(engine, oracle, exact, n, m, k, capsy
     got = tuple(x.cpu().numpy() for x in engine.ols_sweep(G, k, n))
     ex = exact.ols_covariate(Gh, Y, C, n=n)
     ref = oracle.ols_with_covariate(Gh, Y, covariate=C, n=n)
+    pf = formula_p(oracle, ex, n)
     with capsys.disabled():
-        report(f"sweep n={n} m={m} k={k}", errs(got, ex), errs((ref["beta"], ref["var"], ref["pval"]), ex))
-    assert_close(got, ex, f"n={n} m={m}")
+        report(f"sweep n={n} m={m} k={k}", errs(got, ex, pf), errs((ref["beta"], ref["var"], ref["pval"]), ex, pf))
+    assert_close(got, ex, pf, f"n={n} m={m}")
 
 
-@pytest.mark.parametrize("n,p,x,force_m", [(60, 4000, 0.99, -1), (60, 4000, 0.995, -1), (200, 6000, 0.75, 3), (120, 5000, 0.75, 8)])
+@pytest.mark.parametrize("n,p,x,force_m", [(60, 4000, 0.99, -1), (60, 4000, 0.985, -1), (200, 6000, 0.75, 3), (120, 5000, 0.75, 8)])
 def test_full_path_against_binary128(engine, oracle, exact, n, p, x, force_m, capsys):
     """kinship -> eig -> n_eigenvecs rule -> covariates -> fits, every stage on the GPU path, against the same chain in
     binary128 end to end (the eigenvectors that become covariates are the product's own here, not handed in)."""
@@ -76,10 +90,11 @@ def test_full_path_against_binary128(engine, oracle, exact, n, p, x, force_m, ca
     assert np.allclose(K, ex["K"], rtol=1e-13, atol=0)
     got = (beta.cpu().numpy(), var.cpu().numpy(), pv.cpu().numpy())
     ref = oracle.ols_with_covariate(Gh, Y, x, force_m=force_m, n=n)
+    pf = formula_p(oracle, ex, n)
     with capsys.disabled():
-        report(f"full path n={n} p={p} m={m}", errs(got, ex), errs((ref["beta"], ref["var"], ref["pval"]), ex))
+        report(f"full path n={n} p={p} x={x} m={m}", errs(got, ex, pf), errs((ref["beta"], ref["var"], ref["pval"]), ex, pf))
     assert ref["m"] == m
-    assert_close(got, ex, f"full path n={n} m={m}")
+    assert_close(got, ex, pf, f"full path n={n} m={m}")
 
 
 @pytest.mark.parametrize("n,p,k,rows", [(24, 3000, 1, None), (60, 5000, 2, "odd"), (200, 2500, 3, "fold")])
@@ -100,7 +115,7 @@ def test_gp_ols_against_binary128(engine, oracle, exact, n, p, k, rows, capsys):
     cond = np.linalg.cond((Xt[:, idx].T @ Xt[:, idx]))
     with capsys.disabled():
         print(f"\n[gp::ols n={n} p={p} rows={len(idx)}] cond(X X^T)={cond:.2e}  max|GPU - exact|/max|b| = {eg:.2e}   max|oracle - exact|/max|b| = {eo:.2e}")
-    assert np.allclose(beta, ex, rtol=RTOL, atol=1e-10 * scale.max())
+    assert np.allclose(beta, ex, rtol=RTOL, atol=1e-12 * scale.max())
 
 
 @pytest.mark.parametrize("n,p,k,alpha", [(60, 3000, 1, 0.0), (40, 2000, 2, 0.0), (50, 1500, 1, 1.0)])
@@ -133,4 +148,4 @@ def test_ridge_path_against_binary128_fits(engine, oracle, exact, n, p, k, alpha
     assert np.allclose(perf, rp, rtol=RTOL, atol=2.6e-8)
     flips = np.abs(perf - rp) > 1e-10
     assert flips.mean() < 0.02
-    assert np.allclose(b, rb, rtol=RTOL, atol=1e-10 * scale)
+    assert np.allclose(b, rb, rtol=RTOL, atol=1e-12 * scale)
