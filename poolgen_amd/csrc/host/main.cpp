@@ -17,6 +17,8 @@
 #include <future>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <exception>
 #include "gp_cv.h"
 #include "operators.h"
 #include <numeric>
@@ -41,6 +43,10 @@ struct Args {
     int k_folds = 10, n_reps = 3; // genomic_prediction_cross_validation (main.rs:104-109)
     uint64_t seed = 42;           // ... and the seed of its folds (an extension: the reference's folds are unrepeatable)
     uint64_t window_size_bp = 100, window_slide_size_bp = 50, min_loci_per_window = 10; // fst / heterozygosity (main.rs:110-118)
+    // multi-GPU (an extension: the reference's parallel axis is --n-threads, one worker per file chunk, sync.rs:913-939):
+    // the input is cut into one contiguous byte range per GPU, each with its own parser threads.  0 = flag absent.
+    int n_gpus = 0;
+    std::vector<int> gpu_ids; // device ordinals of the ranks (default 0, 1, .., n_gpus - 1)
 };
 
 static double parse_valid_freq(const std::string &v, const std::string &flag) { // helpers.rs:93-100
@@ -67,6 +73,10 @@ static const char *USAGE =
     "      --window-size-bp <100>  --window-slide-size-bp <50>  --min-loci-per-window <10>   fst, heterozygosity\n"
     "      --n-threads <1>                 parser / writer threads\n"
     "      --stream-chunk-mb <N>           size of the pieces the input is taken in (0: whole file, kinship path only)\n"
+    "      --n-gpus <N>  [--gpu-ids a,b,..]  chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship: one contiguous part of\n"
+    "                                      the input per GPU (own parser threads: --n-threads is the total); the kinship sums are\n"
+    "                                      all-reduced over the GPUs with RCCL; the kinship path then needs an input sorted by\n"
+    "                                      (chromosome, position)\n"
     "environment: PGH_TIMING=1 prints the phases' wall-clock on stderr\n";
 
 static Args parse_args(int argc, char **argv) {
@@ -108,6 +118,12 @@ static Args parse_args(int argc, char **argv) {
         else if (k == "--output-sig-snps-only") a.sig_only = true;
         else if (k == "--keep-lowercase-reference") a.keep_lowercase_reference = true; // pileup inputs only (pileup.rs:280-299)
         else if (k == "--stream-chunk-mb") a.stream_chunk_mb = std::stol(val());
+        else if (k == "--n-gpus") { a.n_gpus = std::stoi(val()); if (a.n_gpus < 1) throw std::runtime_error("--n-gpus must be at least 1"); }
+        else if (k == "--gpu-ids") {
+            std::stringstream ss(val());
+            std::string t;
+            while (std::getline(ss, t, ',')) a.gpu_ids.push_back(std::stoi(t));
+        }
         else if (k == "--k-folds") a.k_folds = std::stoi(val());
         else if (k == "--n-reps") a.n_reps = std::stoi(val());
         else if (k == "--seed") a.seed = std::stoull(val());
@@ -120,6 +136,10 @@ static Args parse_args(int argc, char **argv) {
     if (pos.size() != 1) throw std::runtime_error("usage: poolgen <analysis> -f <sync> -p <phen.csv> [flags]   (--help lists them)");
     a.analysis = pos[0];
     if (a.fname.empty() || a.phen_fname.empty()) throw std::runtime_error("-f/--fname and -p/--phen-fname are required");
+    if (!a.gpu_ids.empty()) {
+        if (a.n_gpus == 0) a.n_gpus = (int)a.gpu_ids.size();
+        if ((int)a.gpu_ids.size() != a.n_gpus) throw std::runtime_error("--gpu-ids must list exactly --n-gpus devices");
+    }
     return a;
 }
 
@@ -142,9 +162,13 @@ static FILE *create_new(const std::string &path) {
 
 struct Ctx {
     pg_ctx *c = nullptr;
-    Ctx() {
-        if (pg_create(&c, 0, nullptr) != PG_OK) throw std::runtime_error(std::string("GPU: ") + pg_last_error(nullptr));
+    int device = 0;
+    explicit Ctx(int dev = 0) : device(dev) {
+        if (pg_create(&c, dev, nullptr) != PG_OK)
+            throw std::runtime_error("GPU " + std::to_string(dev) + ": " + pg_last_error(nullptr));
     }
+    Ctx(const Ctx &) = delete;
+    Ctx &operator=(const Ctx &) = delete;
     ~Ctx() { pg_destroy(c); }
     void ok(int rc, const char *what) {
         if (rc != PG_OK) throw std::runtime_error(std::string(what) + ": " + pg_last_error(c));
@@ -268,13 +292,98 @@ struct CountsUpload {
     }
 };
 
-static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap, size_t chunk_bytes, bool is_pileup,
-                                const PileupFilter &pf, const pg_filter &flt) {
+// ---- ranks: one GPU, one pg_ctx, one host thread (plus its share of the parser threads) each -------------------------
+// The reference's parallel axis is a worker per contiguous byte range of the input (base/sync.rs:913-939); here a rank
+// is such a worker with a GPU behind it.  Ranks are threads of this process; the kinship sums are all-reduced with RCCL
+// inside libpoolgen_hip (pg_comm_init_rank / pg_allreduce_sum_dev).  PGH_COMM=host is a REHEARSAL mode for boxes with
+// fewer GPUs than ranks (--gpu-ids 0,0: RCCL refuses two ranks on one device): the partial sums are then added on the
+// host in rank order -- same control flow, same byte ranges, same files.
+struct RankSetup {
+    int n_ranks = 1;
+    std::vector<int> devices;   // per rank
+    std::vector<int> threads;   // parser / writer threads per rank
+    bool rccl = false;          // --n-gpus given: a communicator is set up even for one rank
+    bool host_comm = false;     // PGH_COMM=host
+    unsigned char id[PG_COMM_ID_BYTES] = {0};
+};
+
+static RankSetup rank_setup(const Args &a, bool need_comm) {
+    RankSetup r;
+    r.n_ranks = a.n_gpus > 0 ? a.n_gpus : 1;
+    for (int i = 0; i < r.n_ranks; ++i) r.devices.push_back(a.gpu_ids.empty() ? i : a.gpu_ids[i]);
+    const int total = std::max(a.n_threads, 1);
+    for (int i = 0; i < r.n_ranks; ++i) r.threads.push_back(std::max(1, total / r.n_ranks + (i < total % r.n_ranks ? 1 : 0)));
+    const char *e = std::getenv("PGH_COMM");
+    r.host_comm = e && std::string(e) == "host";
+    r.rccl = need_comm && a.n_gpus > 0 && !r.host_comm;
+    if (r.rccl) {
+        std::vector<int> d = r.devices;
+        std::sort(d.begin(), d.end());
+        if (std::adjacent_find(d.begin(), d.end()) != d.end())
+            throw std::runtime_error("--gpu-ids lists a device twice: RCCL needs one GPU per rank (PGH_COMM=host rehearses the rank logic on fewer GPUs)");
+        if (pg_comm_unique_id(r.id) != PG_OK) throw std::runtime_error(std::string("RCCL: ") + pg_last_error(nullptr));
+    }
+    return r;
+}
+
+// contiguous ranges of pieces per rank: rank r takes [first[r], first[r + 1])
+static std::vector<int> deal_pieces(int npieces, int n_ranks) {
+    std::vector<int> first(n_ranks + 1);
+    for (int r = 0; r <= n_ranks; ++r) first[r] = (int)((int64_t)npieces * r / n_ranks);
+    return first;
+}
+
+template <typename F>
+static void run_ranks(int n_ranks, F fn) { // fn(rank) on one thread per rank; the first exception is rethrown
+    std::vector<std::exception_ptr> err(n_ranks);
+    std::vector<std::thread> th;
+    for (int r = 1; r < n_ranks; ++r)
+        th.emplace_back([&, r] { try { fn(r); } catch (...) { err[r] = std::current_exception(); } });
+    try { fn(0); } catch (...) { err[0] = std::current_exception(); }
+    for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+struct KinRank {
+    int rank = 0, device = 0, threads = 1, c0 = 0, c1 = 0;
+    std::unique_ptr<Ctx> own;
+    Ctx *gpu = nullptr;
+    std::vector<double *> Gs;                         // the rank's pieces of the frequency matrix, resident in HBM
+    std::vector<int64_t> ps;
+    std::vector<std::string> chrom_names;             // the rank's dictionary
+    std::vector<int32_t> lab_chr;                     // per column
+    std::vector<uint64_t> lab_pos;
+    std::vector<char> lab_al;
+    std::vector<double> S_total;
+    double *S_dev = nullptr;
+    uint32_t *counts_dev = nullptr;
+    struct Slot { void *p = nullptr; size_t cap = 0; } slot[2];
+    std::string first_chrom, last_chrom;
+    uint64_t first_pos = 0, last_pos = 0;
+    bool have_last = false;
+    int64_t p = 0, col0 = 0;
+    int m = 0;
+    double t_wait = 0, t_host = 0, t_gpu = 0;
+    KinRank() = default;
+    KinRank(const KinRank &) = delete;
+    KinRank &operator=(const KinRank &) = delete;
+    ~KinRank() { // an exception on the way (unsorted input, out of memory) must not leave the pieces behind: the caller may fall back to the whole-file path
+        for (double *g : Gs) (void)hipFree(g);
+        if (S_dev) (void)hipFree(S_dev);
+        if (counts_dev) (void)hipFree(counts_dev);
+        for (auto &sl : slot) if (sl.p) (void)hipHostFree(sl.p);
+    }
+};
+
+static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &lap, size_t chunk_bytes, bool is_pileup,
+                                const PileupFilter &pf, const pg_filter &flt, const RankSetup &rs) {
     auto hip_ok = [](hipError_t e, const char *what) {
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
     };
     const MappedFile mf(a.fname);
-    const std::vector<size_t> cuts = mf.cuts((mf.size() + chunk_bytes - 1) / chunk_bytes);
+    const int R = rs.n_ranks;
+    const size_t want_pieces = std::max<size_t>((size_t)R, (mf.size() + chunk_bytes - 1) / chunk_bytes);
+    const std::vector<size_t> cuts = mf.cuts(want_pieces);
     const int nchunks = (int)cuts.size() - 1;
     const int n = ph.n, k = ph.k;
     const std::vector<int> keep = complete_pools(ph); // remove_missing (ols.rs:287)
@@ -283,148 +392,195 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
     const int64_t ld = n2 + (n2 & 1);
     std::vector<int32_t> pool_map(n, -1);
     for (int i = 0; i < n2; ++i) pool_map[keep[i]] = i;
-    // two pinned buffers that grow on demand and are handed out in turn
-    struct Slot { void *p = nullptr; size_t cap = 0; } slot[2];
-    auto alloc_for = [&](int i) {
-        SyncAlloc al;
-        al.alloc = [&slot, i](size_t bytes) -> void * {
-            if (bytes > slot[i].cap) {
-                if (slot[i].p) (void)hipHostFree(slot[i].p);
-                slot[i].p = nullptr; slot[i].cap = 0;
-                const size_t want = bytes + bytes / 8;
-                if (hipHostMalloc(&slot[i].p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
-                slot[i].cap = want;
-            }
-            return slot[i].p;
-        };
-        al.release = [](void *) {};
-        return al;
-    };
-    auto parse_piece = [&](int c) {
-        const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
-        return is_pileup ? parse_pileup_buffer(b, e, a.n_threads, pf, alloc_for(c & 1))
-                         : parse_sync_buffer(b, e, a.n_threads, n, alloc_for(c & 1), true);
-    };
-    std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, 0);
-    std::vector<double *> Gs;
-    std::vector<int64_t> ps;
-    std::vector<std::string> chrom_names;             // global dictionary
-    std::vector<int32_t> lab_chr;                     // per column
-    std::vector<uint64_t> lab_pos;
-    std::vector<char> lab_al;
-    std::vector<double> S_total((size_t)n2 * n2, 0.0), S_piece((size_t)n2 * n2);
-    double *S_dev = nullptr;
-    hip_ok(hipMalloc((void **)&S_dev, sizeof(double) * n2 * n2), "device memory");
-    uint32_t *counts_dev = nullptr;
-    size_t counts_cap = 0;
-    CountsUpload upload;
-    std::string last_chrom;
-    uint64_t last_pos = 0;
-    bool have_last = false;
-    double t_wait = 0, t_host = 0, t_gpu = 0; // PGH_TIMING: waiting for the parser | host bookkeeping | copy + device work
-    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (int c = 0; c < nchunks; ++c) {
-        double t0 = clk();
-        SyncBatch sb = next.get();
-        if (c + 1 < nchunks) next = std::async(std::launch::async, parse_piece, c + 1);
-        t_wait += clk() - t0; t0 = clk();
-        if (sb.L == 0) continue;
-        if (sb.n != n) throw std::runtime_error("the number of pools in the input and in the phenotype file differ");
-        for (int64_t l = 0; l < sb.L; ++l) { // sortedness, within and across pieces
-            const std::string &ch = sb.chrom(l);
-            if (have_last) {
-                const int cmp = last_chrom.compare(ch);
-                if (cmp > 0 || (cmp == 0 && last_pos > sb.pos[l]))
-                    throw UnsortedInput("streamed ols_iter_with_kinship needs the input sorted by chromosome and position (line of " +
-                                        ch + ":" + std::to_string(sb.pos[l]) + "); use --stream-chunk-mb 0 to load the whole file");
-                if (cmp != 0) last_chrom = ch;
-            } else { last_chrom = ch; have_last = true; }
-            last_pos = sb.pos[l];
-        }
-        t_host += clk() - t0; t0 = clk();
-        const size_t bytes32 = sizeof(uint32_t) * (size_t)sb.L * n * 6;
-        if (bytes32 > counts_cap) {
-            if (counts_dev) hip_ok(hipFree(counts_dev), "free");
-            counts_cap = bytes32 + bytes32 / 8;
-            hip_ok(hipMalloc((void **)&counts_dev, counts_cap), "device memory for the counts");
-        }
-        upload(gpu, sb, counts_dev);
-        int64_t pc = 0;
-        gpu.ok(pg_load_plan_dev(gpu.c, counts_dev, sb.L, n, ph.pool_sizes.data(), &flt, a.keep_p_minus_1 ? 1 : 0, nullptr, &pc), "load");
-        if (pc == 0) continue;
-        double *G = nullptr;
-        int64_t *col_locus_dev = nullptr;
-        int32_t *col_allele_dev = nullptr;
-        hip_ok(hipMalloc((void **)&G, sizeof(double) * (size_t)pc * ld), "device memory for the genotype matrix");
-        hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * pc), "device memory");
-        hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * pc), "device memory");
-        gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G, ld, col_locus_dev, col_allele_dev), "load");
-        std::vector<int64_t> col_locus(pc);
-        std::vector<int32_t> col_allele(pc);
-        hip_ok(hipMemcpy(col_locus.data(), col_locus_dev, sizeof(int64_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
-        hip_ok(hipMemcpy(col_allele.data(), col_allele_dev, sizeof(int32_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
-        (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
-        t_gpu += clk() - t0; t0 = clk();
-        std::vector<int32_t> remap(sb.chrom_names.size());
-        for (size_t i = 0; i < sb.chrom_names.size(); ++i) {
-            int g = -1;
-            for (size_t j = 0; j < chrom_names.size(); ++j) if (chrom_names[j] == sb.chrom_names[i]) { g = (int)j; break; }
-            if (g < 0) { chrom_names.push_back(sb.chrom_names[i]); g = (int)chrom_names.size() - 1; }
-            remap[i] = g;
-        }
-        for (int64_t q = 0; q < pc; ++q) {
-            lab_chr.push_back(remap[sb.chrom_id[col_locus[q]]]);
-            lab_pos.push_back(sb.pos[col_locus[q]]);
-            lab_al.push_back(ALLELES[col_allele[q]]);
-        }
-        t_host += clk() - t0; t0 = clk();
-        gpu.ok(pg_kinship_partial_dev(gpu.c, G, pc, n2, ld, S_dev), "kinship");
-        hip_ok(hipMemcpy(S_piece.data(), S_dev, sizeof(double) * n2 * n2, hipMemcpyDeviceToHost), "D2H kinship");
-        for (size_t i = 0; i < S_total.size(); ++i) S_total[i] += S_piece[i];
-        Gs.push_back(G);
-        ps.push_back(pc);
-        t_gpu += clk() - t0;
+    const std::vector<int> first = deal_pieces(nchunks, R);
+    std::vector<KinRank> ranks(R);
+    for (int r = 0; r < R; ++r) {
+        ranks[r].rank = r; ranks[r].device = rs.devices[r]; ranks[r].threads = rs.threads[r];
+        ranks[r].c0 = first[r]; ranks[r].c1 = first[r + 1];
     }
+    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+    // ---- phase A, per rank: parse piece c + 1 || H2D + loader + partial kinship of piece c -----------------------
+    run_ranks(R, [&](int r) {
+        KinRank &K = ranks[r];
+        hip_ok(hipSetDevice(K.device), "hipSetDevice");
+        if (r == 0 && gpu0.device == K.device) K.gpu = &gpu0;
+        else { K.own.reset(new Ctx(K.device)); K.gpu = K.own.get(); }
+        Ctx &gpu = *K.gpu;
+        if (rs.rccl) gpu.ok(pg_comm_init_rank(gpu.c, rs.id, R, r), "RCCL communicator"); // collective over the rank threads
+        K.S_total.assign((size_t)n2 * n2, 0.0);
+        hip_ok(hipMalloc((void **)&K.S_dev, sizeof(double) * n2 * n2), "device memory");
+        if (K.c0 >= K.c1) return;
+        auto alloc_for = [&K](int i) { // two pinned buffers that grow on demand and are handed out in turn
+            SyncAlloc al;
+            al.alloc = [&K, i](size_t bytes) -> void * {
+                if (bytes > K.slot[i].cap) {
+                    if (K.slot[i].p) (void)hipHostFree(K.slot[i].p);
+                    K.slot[i].p = nullptr; K.slot[i].cap = 0;
+                    const size_t want = bytes + bytes / 8;
+                    if (hipHostMalloc(&K.slot[i].p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+                    K.slot[i].cap = want;
+                }
+                return K.slot[i].p;
+            };
+            al.release = [](void *) {};
+            return al;
+        };
+        auto parse_piece = [&](int c) {
+            (void)hipSetDevice(K.device); // the pinned allocator runs on the parser's thread
+            const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
+            return is_pileup ? parse_pileup_buffer(b, e, K.threads, pf, alloc_for(c & 1))
+                             : parse_sync_buffer(b, e, K.threads, n, alloc_for(c & 1), true);
+        };
+        std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, K.c0);
+        std::vector<double> S_piece((size_t)n2 * n2);
+        size_t counts_cap = 0;
+        CountsUpload upload;
+        for (int c = K.c0; c < K.c1; ++c) {
+            double t0 = clk();
+            SyncBatch sb = next.get();
+            if (c + 1 < K.c1) next = std::async(std::launch::async, parse_piece, c + 1);
+            K.t_wait += clk() - t0; t0 = clk();
+            if (sb.L == 0) continue;
+            if (sb.n != n) throw std::runtime_error("the number of pools in the input and in the phenotype file differ");
+            for (int64_t l = 0; l < sb.L; ++l) { // sortedness, within and across the rank's pieces
+                const std::string &ch = sb.chrom(l);
+                if (K.have_last) {
+                    const int cmp = K.last_chrom.compare(ch);
+                    if (cmp > 0 || (cmp == 0 && K.last_pos > sb.pos[l]))
+                        throw UnsortedInput("streamed ols_iter_with_kinship needs the input sorted by chromosome and position (line of " +
+                                            ch + ":" + std::to_string(sb.pos[l]) + "); use --stream-chunk-mb 0 to load the whole file");
+                    if (cmp != 0) K.last_chrom = ch;
+                } else { K.last_chrom = ch; K.have_last = true; K.first_chrom = ch; K.first_pos = sb.pos[l]; }
+                K.last_pos = sb.pos[l];
+            }
+            K.t_host += clk() - t0; t0 = clk();
+            const size_t bytes32 = sizeof(uint32_t) * (size_t)sb.L * n * 6;
+            if (bytes32 > counts_cap) {
+                if (K.counts_dev) hip_ok(hipFree(K.counts_dev), "free");
+                K.counts_dev = nullptr;
+                counts_cap = bytes32 + bytes32 / 8;
+                hip_ok(hipMalloc((void **)&K.counts_dev, counts_cap), "device memory for the counts");
+            }
+            upload(gpu, sb, K.counts_dev);
+            int64_t pc = 0;
+            gpu.ok(pg_load_plan_dev(gpu.c, K.counts_dev, sb.L, n, ph.pool_sizes.data(), &flt, a.keep_p_minus_1 ? 1 : 0, nullptr, &pc), "load");
+            if (pc == 0) continue;
+            double *G = nullptr;
+            int64_t *col_locus_dev = nullptr;
+            int32_t *col_allele_dev = nullptr;
+            hip_ok(hipMalloc((void **)&G, sizeof(double) * (size_t)pc * ld), "device memory for the genotype matrix");
+            K.Gs.push_back(G);
+            K.ps.push_back(pc);
+            hip_ok(hipMalloc((void **)&col_locus_dev, sizeof(int64_t) * pc), "device memory");
+            hip_ok(hipMalloc((void **)&col_allele_dev, sizeof(int32_t) * pc), "device memory");
+            gpu.ok(pg_load_emit_dev(gpu.c, pool_map.data(), n2, G, ld, col_locus_dev, col_allele_dev), "load");
+            std::vector<int64_t> col_locus(pc);
+            std::vector<int32_t> col_allele(pc);
+            hip_ok(hipMemcpy(col_locus.data(), col_locus_dev, sizeof(int64_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
+            hip_ok(hipMemcpy(col_allele.data(), col_allele_dev, sizeof(int32_t) * pc, hipMemcpyDeviceToHost), "D2H labels");
+            (void)hipFree(col_locus_dev); (void)hipFree(col_allele_dev);
+            K.t_gpu += clk() - t0; t0 = clk();
+            std::vector<int32_t> remap(sb.chrom_names.size());
+            for (size_t i = 0; i < sb.chrom_names.size(); ++i) {
+                int g = -1;
+                for (size_t j = 0; j < K.chrom_names.size(); ++j) if (K.chrom_names[j] == sb.chrom_names[i]) { g = (int)j; break; }
+                if (g < 0) { K.chrom_names.push_back(sb.chrom_names[i]); g = (int)K.chrom_names.size() - 1; }
+                remap[i] = g;
+            }
+            for (int64_t q = 0; q < pc; ++q) {
+                K.lab_chr.push_back(remap[sb.chrom_id[col_locus[q]]]);
+                K.lab_pos.push_back(sb.pos[col_locus[q]]);
+                K.lab_al.push_back(ALLELES[col_allele[q]]);
+            }
+            K.t_host += clk() - t0; t0 = clk();
+            gpu.ok(pg_kinship_partial_dev(gpu.c, G, pc, n2, ld, K.S_dev), "kinship");
+            hip_ok(hipMemcpy(S_piece.data(), K.S_dev, sizeof(double) * n2 * n2, hipMemcpyDeviceToHost), "D2H kinship");
+            for (size_t i = 0; i < K.S_total.size(); ++i) K.S_total[i] += S_piece[i];
+            K.p += pc;
+            K.t_gpu += clk() - t0;
+        }
+        if (K.counts_dev) { (void)hipFree(K.counts_dev); K.counts_dev = nullptr; }
+        for (auto &sl : K.slot) if (sl.p) { (void)hipHostFree(sl.p); sl.p = nullptr; sl.cap = 0; }
+    });
     if (std::getenv("PGH_TIMING"))
-        std::fprintf(stderr, "poolgen: pieces: waited for the parser %.3f s, host bookkeeping %.3f s, copies + device %.3f s\n", t_wait, t_host, t_gpu);
-    if (counts_dev) (void)hipFree(counts_dev);
-    for (auto &sl : slot) if (sl.p) (void)hipHostFree(sl.p);
+        for (const KinRank &K : ranks)
+            std::fprintf(stderr, "poolgen: rank %d (GPU %d, pieces %d..%d, %d parser threads): waited for the parser %.3f s, host bookkeeping %.3f s, copies + device %.3f s\n",
+                         K.rank, K.device, K.c0, K.c1, K.threads, K.t_wait, K.t_host, K.t_gpu);
     lap("pieces: parse | H2D + loader + partial kinship");
+    // ---- between the phases: the order across ranks, the global column offsets ------------------------------------
     int64_t p = 0;
-    for (int64_t x : ps) p += x;
+    const KinRank *prev = nullptr;
+    for (KinRank &K : ranks) {
+        K.col0 = p;
+        p += K.p;
+        if (!K.have_last) continue;
+        if (prev) {
+            const int cmp = prev->last_chrom.compare(K.first_chrom);
+            if (cmp > 0 || (cmp == 0 && prev->last_pos > K.first_pos))
+                throw UnsortedInput("streamed ols_iter_with_kinship needs the input sorted by chromosome and position (line of " +
+                                    K.first_chrom + ":" + std::to_string(K.first_pos) + "); use --stream-chunk-mb 0 to load the whole file");
+        }
+        prev = &K;
+    }
     if (p <= 0) throw std::runtime_error("no loci passed the filters");
     std::vector<double> Y;
     for (int i : keep) for (int j = 0; j < k; ++j) Y.push_back(ph.phen[(size_t)i * k + j]);
     if (!a.output.empty()) { FILE *t = create_new(a.output); fclose(t); ::unlink(a.output.c_str()); } // ols.rs:285
-    hip_ok(hipMemcpy(S_dev, S_total.data(), sizeof(double) * n2 * n2, hipMemcpyHostToDevice), "H2D kinship");
-    int m = 0;
-    gpu.ok(pg_kinship_set(gpu.c, S_dev, p, n2, Y.data(), k, a.xxt, -1, &m, nullptr, nullptr), "ols_iter_with_kinship");
-    std::vector<double> beta((size_t)p * k), pval((size_t)p * k);
-    int64_t off = 0;
-    for (size_t c = 0; c < Gs.size(); ++c) {
-        double *out_dev = nullptr;
-        const size_t cnt = (size_t)ps[c] * k;
-        hip_ok(hipMalloc((void **)&out_dev, sizeof(double) * 3 * cnt), "device memory for the results");
-        gpu.ok(pg_ols_sweep_dev(gpu.c, Gs[c], ps[c], n2, ld, out_dev, out_dev + cnt, out_dev + 2 * cnt), "ols_iter_with_kinship");
-        gpu.ok(pg_synchronize(gpu.c), "ols_iter_with_kinship");
-        hip_ok(hipMemcpy(beta.data() + (size_t)off * k, out_dev, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H results");
-        hip_ok(hipMemcpy(pval.data() + (size_t)off * k, out_dev + 2 * cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H results");
-        (void)hipFree(out_dev);
-        (void)hipFree(Gs[c]);
-        off += ps[c];
+    std::vector<double> S_host; // PGH_COMM=host, or no communicator at all: the ranks' sums added in rank order
+    if (!rs.rccl) {
+        S_host.assign((size_t)n2 * n2, 0.0);
+        for (const KinRank &K : ranks)
+            for (size_t i = 0; i < S_host.size(); ++i) S_host[i] += K.S_total[i];
     }
-    (void)hipFree(S_dev);
-    lap("eigen rule + fits + D2H");
+    // ---- phase B, per rank: all-reduce of the kinship sums, the n x n step (replicated), the rank's sweeps ---------
+    std::vector<double> beta((size_t)p * k), pval((size_t)p * k);
+    run_ranks(R, [&](int r) {
+        KinRank &K = ranks[r];
+        Ctx &gpu = *K.gpu;
+        hip_ok(hipSetDevice(K.device), "hipSetDevice");
+        hip_ok(hipMemcpy(K.S_dev, rs.rccl ? K.S_total.data() : S_host.data(), sizeof(double) * n2 * n2, hipMemcpyHostToDevice), "H2D kinship");
+        if (rs.rccl) gpu.ok(pg_allreduce_sum_dev(gpu.c, K.S_dev, (int64_t)n2 * n2), "RCCL all-reduce of the kinship sums");
+        gpu.ok(pg_kinship_set(gpu.c, K.S_dev, p, n2, Y.data(), k, a.xxt, -1, &K.m, nullptr, nullptr), "ols_iter_with_kinship");
+        int64_t off = K.col0;
+        for (size_t c = 0; c < K.Gs.size(); ++c) {
+            double *out_dev = nullptr;
+            const size_t cnt = (size_t)K.ps[c] * k;
+            hip_ok(hipMalloc((void **)&out_dev, sizeof(double) * 3 * cnt), "device memory for the results");
+            gpu.ok(pg_ols_sweep_dev(gpu.c, K.Gs[c], K.ps[c], n2, ld, out_dev, out_dev + cnt, out_dev + 2 * cnt), "ols_iter_with_kinship");
+            gpu.ok(pg_synchronize(gpu.c), "ols_iter_with_kinship");
+            hip_ok(hipMemcpy(beta.data() + (size_t)off * k, out_dev, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H results");
+            hip_ok(hipMemcpy(pval.data() + (size_t)off * k, out_dev + 2 * cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H results");
+            (void)hipFree(out_dev);
+            (void)hipFree(K.Gs[c]);
+            K.Gs[c] = nullptr;
+            off += K.ps[c];
+        }
+        K.Gs.clear();
+    });
+    const int m = ranks[0].m;
+    for (const KinRank &K : ranks)
+        if (K.m != m) throw std::runtime_error("internal error: the ranks disagree on n_eigenvecs");
+    lap("all-reduce + eigen rule + fits + D2H");
     std::string out = a.output;
     if (out.empty()) // ols.rs:393-398
         out = basename_no_ext(a.fname) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";
+    // label of global column q: the rank whose range holds it
+    std::vector<int64_t> starts;
+    for (const KinRank &K : ranks) starts.push_back(K.col0);
+    auto label = [&](int64_t q, std::string &text) {
+        const int r = (int)(std::upper_bound(starts.begin(), starts.end(), q) - starts.begin()) - 1;
+        const KinRank &K = ranks[r];
+        const int64_t i = q - K.col0;
+        text += K.chrom_names[K.lab_chr[i]]; text += ","; text += std::to_string(K.lab_pos[i]); text += ","; text.push_back(K.lab_al[i]);
+    };
     FILE *fo = create_new(out);
     fputs("#chr,pos,alleles,phenotype,statistic,pvalue\n", fo); // ols.rs:409
     write_rows_parallel(fo, (int64_t)k * p, a.n_threads, [&](int64_t r, std::string &text) {
         const int64_t j = r / p, i = r - j * p; // rows are trait-major (ols.rs:411-433)
         // coefficient i carries label i of the (1+p)-long vectors whose entry 0 is "intercept" (ols.rs:421-425)
         if (i == 0) text += "intercept,0,intercept";
-        else { text += chrom_names[lab_chr[i - 1]]; text += ","; text += std::to_string(lab_pos[i - 1]); text += ","; text.push_back(lab_al[i - 1]); }
+        else label(i - 1, text);
         text += ",Pheno_"; text += std::to_string(j); text.push_back(',');
         append_rust_display(text, beta[(size_t)i * k + j]); text.push_back(',');
         append_rust_display(text, pval[(size_t)i * k + j]); text.push_back('\n');
@@ -439,14 +595,16 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &la
 // the file is taken in pieces whatever its size -- the worker threads parse piece c + 1 into one of two pinned buffers
 // (16-bit counts when they fit) while the GPU takes piece c and its rows are formatted and appended, in file order
 // (sync.rs:927-946).  Nothing of the size of the input is ever allocated, pinned or copied in one go.
-static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap, int mode, size_t chunk_bytes, bool is_pileup,
-                              const PileupFilter &pf, const pg_filter &flt) {
+static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &lap, int mode, size_t chunk_bytes, bool is_pileup,
+                              const PileupFilter &pf, const pg_filter &flt, const RankSetup &rs) {
     auto hip_ok = [](hipError_t e, const char *what) {
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
     };
     const MappedFile mf(a.fname);
-    const std::vector<size_t> cuts = mf.cuts(std::max<size_t>(1, (mf.size() + chunk_bytes - 1) / chunk_bytes));
+    const int R = rs.n_ranks;
+    const std::vector<size_t> cuts = mf.cuts(std::max<size_t>((size_t)R, (mf.size() + chunk_bytes - 1) / chunk_bytes));
     const int nchunks = (int)cuts.size() - 1;
+    const std::vector<int> first = deal_pieces(nchunks, R);
     const int n = ph.n, k = ph.k;
     std::string out = a.output;
     if (out.empty()) out = basename_no_ext(a.fname) + "-" + unix_time_string() + "-" + a.analysis + ".csv"; // sync.rs:903
@@ -466,91 +624,132 @@ static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu, Lap &lap,
     }
     const int n2 = (int)keep.size();
     const bool subset = n2 != n;
-    struct Slot { void *p = nullptr; size_t cap = 0; } slot[2];
-    auto alloc_for = [&](int i) {
-        SyncAlloc al;
-        al.alloc = [&slot, i](size_t bytes) -> void * {
-            if (bytes > slot[i].cap) {
-                if (slot[i].p) (void)hipHostFree(slot[i].p);
-                slot[i].p = nullptr; slot[i].cap = 0;
-                const size_t want = bytes + bytes / 8;
-                if (hipHostMalloc(&slot[i].p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
-                slot[i].cap = want;
-            }
-            return slot[i].p;
+    const char *header = mode == 0 ? "#chr,pos,alleles,statistic,pvalue\n"                 // sync.rs:766
+                                   : "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n"; // sync.rs:950
+    // One rank = one contiguous range of pieces, one GPU, its own pinned buffers and parser threads, and -- when there are
+    // several -- its own part file, like the reference's one `.tmp` file per worker thread (sync.rs:794-870), concatenated in
+    // rank order afterwards (sync.rs:951-968).  No exchange between the ranks: a locus needs nothing beyond its own line.
+    std::vector<int64_t> totals(R, 0);
+    std::vector<std::string> part(R);
+    for (int r = 0; r < R; ++r) part[r] = R == 1 ? out : out + ".rank" + std::to_string(r) + ".tmp";
+    auto cleanup_parts = [&] { if (R > 1) for (auto &f : part) ::unlink(f.c_str()); };
+    try {
+    run_ranks(R, [&](int r) {
+        const int device = rs.devices[r], threads = rs.threads[r];
+        hip_ok(hipSetDevice(device), "hipSetDevice");
+        std::unique_ptr<Ctx> own;
+        Ctx *gp = &gpu0;
+        if (!(r == 0 && gpu0.device == device)) { own.reset(new Ctx(device)); gp = own.get(); }
+        Ctx &gpu = *gp;
+        struct Slot { void *p = nullptr; size_t cap = 0; } slot[2];
+        auto alloc_for = [&](int i) {
+            SyncAlloc al;
+            al.alloc = [&slot, i](size_t bytes) -> void * {
+                if (bytes > slot[i].cap) {
+                    if (slot[i].p) (void)hipHostFree(slot[i].p);
+                    slot[i].p = nullptr; slot[i].cap = 0;
+                    const size_t want = bytes + bytes / 8;
+                    if (hipHostMalloc(&slot[i].p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+                    slot[i].cap = want;
+                }
+                return slot[i].p;
+            };
+            al.release = [](void *) {};
+            return al;
         };
-        al.release = [](void *) {};
-        return al;
-    };
-    auto parse_piece = [&](int c) {
-        const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
-        return is_pileup ? parse_pileup_buffer(b, e, a.n_threads, pf, alloc_for(c & 1))
-                         : parse_sync_buffer(b, e, a.n_threads, 0, alloc_for(c & 1), !subset);
-    };
-    std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, 0);
-    FILE *fo = nullptr;
-    uint32_t *counts_dev = nullptr;
-    int32_t *n_out_dev = nullptr, *ids_dev = nullptr;
-    double *mf_dev = nullptr, *stat_dev = nullptr, *pv_dev = nullptr;
-    int64_t cap_loci = 0;
-    CountsUpload upload;
-    std::vector<uint32_t> counts2;
-    std::vector<int32_t> n_out, ids;
-    std::vector<double> mfq, stat, pv;
-    const size_t per_stat = mode == 0 ? 1 : (size_t)PG_MAX_OUT * k;
+        auto parse_piece = [&](int c) {
+            (void)hipSetDevice(device);
+            const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
+            return is_pileup ? parse_pileup_buffer(b, e, threads, pf, alloc_for(c & 1))
+                             : parse_sync_buffer(b, e, threads, 0, alloc_for(c & 1), !subset);
+        };
+        const int c0 = first[r], c1 = first[r + 1];
+        if (c0 >= c1) return;
+        std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, c0);
+        FILE *fo = nullptr;
+        uint32_t *counts_dev = nullptr;
+        int32_t *n_out_dev = nullptr, *ids_dev = nullptr;
+        double *mf_dev = nullptr, *stat_dev = nullptr, *pv_dev = nullptr;
+        int64_t cap_loci = 0;
+        CountsUpload upload;
+        std::vector<uint32_t> counts2;
+        std::vector<int32_t> n_out, ids;
+        std::vector<double> mfq, stat, pv;
+        const size_t per_stat = mode == 0 ? 1 : (size_t)PG_MAX_OUT * k;
+        for (int c = c0; c < c1; ++c) {
+            SyncBatch sb = next.get();
+            if (c + 1 < c1) next = std::async(std::launch::async, parse_piece, c + 1);
+            if (sb.L == 0) continue;
+            if (sb.n != n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
+            const int64_t L = sb.L;
+            totals[r] += L;
+            if (L > cap_loci) {
+                for (void *q : {(void *)counts_dev, (void *)n_out_dev, (void *)ids_dev, (void *)mf_dev, (void *)stat_dev, (void *)pv_dev})
+                    if (q) (void)hipFree(q);
+                cap_loci = L + L / 8;
+                hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * (size_t)cap_loci * n * 6), "device memory for the counts");
+                hip_ok(hipMalloc((void **)&n_out_dev, sizeof(int32_t) * cap_loci), "device memory");
+                hip_ok(hipMalloc((void **)&ids_dev, sizeof(int32_t) * cap_loci * PG_MAX_OUT), "device memory");
+                hip_ok(hipMalloc((void **)&mf_dev, sizeof(double) * cap_loci * PG_MAX_OUT), "device memory");
+                hip_ok(hipMalloc((void **)&stat_dev, sizeof(double) * cap_loci * per_stat), "device memory");
+                hip_ok(hipMalloc((void **)&pv_dev, sizeof(double) * cap_loci * per_stat), "device memory");
+            }
+            if (subset) { // rare: drop the pools without phenotype on the host (32-bit counts), then one copy
+                counts2.resize((size_t)L * n2 * 6);
+                for (int64_t l = 0; l < L; ++l)
+                    for (int i = 0; i < n2; ++i) std::memcpy(&counts2[((size_t)l * n2 + i) * 6], &sb.counts[((size_t)l * n + keep[i]) * 6], 24);
+                hip_ok(hipMemcpy(counts_dev, counts2.data(), sizeof(uint32_t) * counts2.size(), hipMemcpyHostToDevice), "H2D counts");
+            } else
+                upload(gpu, sb, counts_dev);
+            if (mode == 0)
+                gpu.ok(pg_chisq_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, n_out_dev, ids_dev, stat_dev, pv_dev), "chisq_test");
+            else if (mode == 1)
+                gpu.ok(pg_pearson_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, Y.data(), k, n_out_dev, ids_dev, mf_dev, stat_dev, pv_dev),
+                       "pearson_corr");
+            else
+                gpu.ok(pg_ols_iter_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, Y.data(), k, n_out_dev, ids_dev, mf_dev, stat_dev, pv_dev),
+                       "ols_iter");
+            n_out.resize(L); ids.resize((size_t)L * PG_MAX_OUT); mfq.resize((size_t)L * PG_MAX_OUT);
+            stat.resize((size_t)L * per_stat); pv.resize((size_t)L * per_stat);
+            hip_ok(hipMemcpy(n_out.data(), n_out_dev, sizeof(int32_t) * L, hipMemcpyDeviceToHost), "D2H results");
+            hip_ok(hipMemcpy(ids.data(), ids_dev, sizeof(int32_t) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
+            if (mode != 0) hip_ok(hipMemcpy(mfq.data(), mf_dev, sizeof(double) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
+            hip_ok(hipMemcpy(stat.data(), stat_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
+            hip_ok(hipMemcpy(pv.data(), pv_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
+            if (!fo) {
+                fo = create_new(part[r]);
+                if (R == 1) fputs(header, fo);
+            }
+            write_rows_parallel(fo, L, threads, [&](int64_t l, std::string &line) {
+                format_locus_rows(mode, sb.chrom(l), sb.pos[l], n_out[l], &ids[(size_t)l * PG_MAX_OUT], &mfq[(size_t)l * PG_MAX_OUT],
+                                  &stat[(size_t)l * per_stat], &pv[(size_t)l * per_stat], k, line);
+            });
+        }
+        if (fo) fclose(fo);
+        for (void *q : {(void *)counts_dev, (void *)n_out_dev, (void *)ids_dev, (void *)mf_dev, (void *)stat_dev, (void *)pv_dev})
+            if (q) (void)hipFree(q);
+        for (auto &sl : slot) if (sl.p) (void)hipHostFree(sl.p);
+    });
+    } catch (...) { cleanup_parts(); throw; }
     int64_t total = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        SyncBatch sb = next.get();
-        if (c + 1 < nchunks) next = std::async(std::launch::async, parse_piece, c + 1);
-        if (sb.L == 0) continue;
-        if (sb.n != n) throw std::runtime_error("the number of pools in the sync file and in the phenotype file differ");
-        const int64_t L = sb.L;
-        total += L;
-        if (L > cap_loci) {
-            for (void *q : {(void *)counts_dev, (void *)n_out_dev, (void *)ids_dev, (void *)mf_dev, (void *)stat_dev, (void *)pv_dev})
-                if (q) (void)hipFree(q);
-            cap_loci = L + L / 8;
-            hip_ok(hipMalloc((void **)&counts_dev, sizeof(uint32_t) * (size_t)cap_loci * n * 6), "device memory for the counts");
-            hip_ok(hipMalloc((void **)&n_out_dev, sizeof(int32_t) * cap_loci), "device memory");
-            hip_ok(hipMalloc((void **)&ids_dev, sizeof(int32_t) * cap_loci * PG_MAX_OUT), "device memory");
-            hip_ok(hipMalloc((void **)&mf_dev, sizeof(double) * cap_loci * PG_MAX_OUT), "device memory");
-            hip_ok(hipMalloc((void **)&stat_dev, sizeof(double) * cap_loci * per_stat), "device memory");
-            hip_ok(hipMalloc((void **)&pv_dev, sizeof(double) * cap_loci * per_stat), "device memory");
+    for (int64_t t : totals) total += t;
+    if (total == 0) { cleanup_parts(); throw std::runtime_error("no loci in " + a.fname); }
+    if (R > 1) { // header + the ranks' parts in rank order = file order
+        FILE *fo = create_new(out);
+        fputs(header, fo);
+        std::vector<char> buf(8 << 20);
+        for (int r = 0; r < R; ++r) {
+            if (totals[r] == 0) continue;
+            FILE *fi = std::fopen(part[r].c_str(), "rb");
+            if (!fi) { fclose(fo); cleanup_parts(); throw std::runtime_error("cannot reopen " + part[r]); }
+            size_t got;
+            while ((got = std::fread(buf.data(), 1, buf.size(), fi)) > 0)
+                if (std::fwrite(buf.data(), 1, got, fo) != got) { fclose(fi); fclose(fo); cleanup_parts(); throw std::runtime_error("write failed (disk full?)"); }
+            fclose(fi);
         }
-        if (subset) { // rare: drop the pools without phenotype on the host (32-bit counts), then one copy
-            counts2.resize((size_t)L * n2 * 6);
-            for (int64_t l = 0; l < L; ++l)
-                for (int i = 0; i < n2; ++i) std::memcpy(&counts2[((size_t)l * n2 + i) * 6], &sb.counts[((size_t)l * n + keep[i]) * 6], 24);
-            hip_ok(hipMemcpy(counts_dev, counts2.data(), sizeof(uint32_t) * counts2.size(), hipMemcpyHostToDevice), "H2D counts");
-        } else
-            upload(gpu, sb, counts_dev);
-        if (mode == 0)
-            gpu.ok(pg_chisq_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, n_out_dev, ids_dev, stat_dev, pv_dev), "chisq_test");
-        else if (mode == 1)
-            gpu.ok(pg_pearson_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, Y.data(), k, n_out_dev, ids_dev, mf_dev, stat_dev, pv_dev),
-                   "pearson_corr");
-        else
-            gpu.ok(pg_ols_iter_batch_dev(gpu.c, counts_dev, L, n2, ps.data(), &flt, Y.data(), k, n_out_dev, ids_dev, mf_dev, stat_dev, pv_dev),
-                   "ols_iter");
-        n_out.resize(L); ids.resize((size_t)L * PG_MAX_OUT); mfq.resize((size_t)L * PG_MAX_OUT);
-        stat.resize((size_t)L * per_stat); pv.resize((size_t)L * per_stat);
-        hip_ok(hipMemcpy(n_out.data(), n_out_dev, sizeof(int32_t) * L, hipMemcpyDeviceToHost), "D2H results");
-        hip_ok(hipMemcpy(ids.data(), ids_dev, sizeof(int32_t) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
-        if (mode != 0) hip_ok(hipMemcpy(mfq.data(), mf_dev, sizeof(double) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
-        hip_ok(hipMemcpy(stat.data(), stat_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
-        hip_ok(hipMemcpy(pv.data(), pv_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
-        if (!fo) {
-            fo = create_new(out);
-            fputs(mode == 0 ? "#chr,pos,alleles,statistic,pvalue\n"                 // sync.rs:766
-                            : "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n", fo); // sync.rs:950
-        }
-        write_rows_parallel(fo, L, a.n_threads, [&](int64_t l, std::string &line) {
-            format_locus_rows(mode, sb.chrom(l), sb.pos[l], n_out[l], &ids[(size_t)l * PG_MAX_OUT], &mfq[(size_t)l * PG_MAX_OUT],
-                              &stat[(size_t)l * per_stat], &pv[(size_t)l * per_stat], k, line);
-        });
+        fclose(fo);
+        cleanup_parts();
     }
-    if (total == 0) throw std::runtime_error("no loci in " + a.fname);
-    fclose(fo);
     lap("pieces: parse | H2D + operator + D2H + format + write");
     std::cout << out << "\n"; // main.rs:507
     return done_ok();
@@ -815,7 +1014,10 @@ static int run(int argc, char **argv) {
         std::cout << out << "\n"; // main.rs:507
         return done_ok();
     }
-    Ctx gpu; // first: the pinned allocator below needs a HIP context
+    if (a.n_gpus > 0 && known.at(a.analysis) > 3)
+        throw std::runtime_error("--n-gpus applies to chisq_test, pearson_corr, ols_iter and ols_iter_with_kinship; `" + a.analysis + "` runs on one GPU");
+    const RankSetup ranks = rank_setup(a, a.analysis == "ols_iter_with_kinship");
+    Ctx gpu(ranks.devices[0]); // first: the pinned allocator below needs a HIP context
     lap("start-up");
     // A pileup input (*.pileup / *.mpileup) is converted in memory -- the counts pileup2sync would write and the
     // sync reader would read back, without the text in between (an extension: the reference needs the sync file).
@@ -848,11 +1050,12 @@ static int run(int argc, char **argv) {
         if (mb < 0) mb = fsize > ((size_t)1 << 30) ? 256 : (fsize > ((size_t)256 << 20) ? 128 : 0); // no whole-file pinned buffer beyond 256 MiB
         size_t piece = (size_t)(mb > 0 ? mb : 0) << 20;
         if (const char *e = std::getenv("PGH_STREAM_CHUNK_BYTES")) piece = (size_t)std::strtoull(e, nullptr, 10); // tests: small pieces
-        if (piece > 0 && fsize > piece) {
+        if (a.n_gpus > 0 && piece == 0) piece = std::max<size_t>(1, (fsize + ranks.n_ranks - 1) / ranks.n_ranks); // one piece per rank at least
+        if (piece > 0 && (fsize > piece || a.n_gpus > 0)) {
             try {
-                return run_kinship_streamed(a, ph, gpu, lap, piece, is_pileup, pf, flt);
+                return run_kinship_streamed(a, ph, gpu, lap, piece, is_pileup, pf, flt, ranks);
             } catch (const UnsortedInput &e) {
-                if (!automatic) throw;
+                if (!automatic || a.n_gpus > 0) throw;
                 std::cerr << "note: input is not sorted by (chromosome, position); loading the whole file instead\n";
             }
         }
@@ -860,7 +1063,7 @@ static int run(int argc, char **argv) {
     if (known.at(a.analysis) <= 2) {
         size_t piece = (size_t)(a.stream_chunk_mb > 0 ? a.stream_chunk_mb : 128) << 20;
         if (const char *e = std::getenv("PGH_STREAM_CHUNK_BYTES")) piece = (size_t)std::strtoull(e, nullptr, 10); // tests: small pieces
-        return run_batch_streamed(a, ph, gpu, lap, known.at(a.analysis), piece, is_pileup, pf, flt);
+        return run_batch_streamed(a, ph, gpu, lap, known.at(a.analysis), piece, is_pileup, pf, flt, ranks);
     }
     SyncBatch sb;
     if (is_pileup) {

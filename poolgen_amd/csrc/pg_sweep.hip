@@ -149,6 +149,7 @@ struct SweepGeom {
     int nch;        // 32-double chunks per super-row
     int64_t sl;     // doubles per super-row = g * ld
     int64_t total;  // p * ld: loads are clamped to the last pair of the matrix
+    int prefetch;   // experiments: 0 = the loads of a chunk are issued when the chunk is needed
 };
 
 // The 16 staging registers of a chunk are named variables, not an array: they are live across the consumption loop (the
@@ -164,7 +165,9 @@ static_assert(SW_NLD == 16, "the staging macros below spell out 16 load instruct
     }
 #define SW_ISSUE(tt, cc)                                                                                  \
     {                                                                                                     \
-        const int64_t ibase_ = ((tt) * 64 + lr) * Q.sl + (int64_t)(cc) * SW_CH + 2 * piece;              \
+        int64_t q_ = (int64_t)(cc) * SW_CH + 2 * piece; /* lanes past the super-row's end re-read its last pair: */ \
+        q_ = q_ < Q.sl - 2 ? q_ : Q.sl - 2;             /* the lines behind it belong to the next super-row      */ \
+        const int64_t ibase_ = ((tt) * 64 + lr) * Q.sl + q_;                                              \
         SW_REP16(SW_LOAD)                                                                                 \
     }
 #define SW_STAGE(r) *reinterpret_cast<double2 *>(&tile[(SW_RPI * r + lr) * SW_PITCH + 2 * piece]) = v##r;
@@ -187,15 +190,16 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
     SW_REP16(SW_DECL)
     int64_t t = (int64_t)blockIdx.x * SW_WAVES + wave;
     if (t >= D.ntiles) return;
-    SW_ISSUE(t, 0)
+    if (Q.prefetch & 1) SW_ISSUE(t, 0)
     for (; t < D.ntiles; t += wstride) {
         double acc[C];
         double s2 = 0.0, shift = 0.0;
         int j = 0, pos = 0; // locus within the super-row, position within its row (pools n..ld-1 are padding)
         for (int ch = 0; ch < Q.nch; ++ch) {
+            if (!(Q.prefetch & 1)) SW_ISSUE(t, ch)
             SW_REP16(SW_STAGE)
             __builtin_amdgcn_wave_barrier();
-            {   // next chunk of this tile, else the first chunk of the wave's next tile (clamped loads: harmless past the end)
+            if ((Q.prefetch & 3) == 1) {   // next chunk of this tile, else the first chunk of the wave's next tile (clamped loads: harmless past the end)
                 const bool more = ch + 1 < Q.nch;
                 const int64_t tn = more ? t : t + wstride;
                 const int cn = more ? ch + 1 : 0;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
             }
             const int64_t left = Q.sl - (int64_t)ch * SW_CH;
             const int iend = left < SW_CH ? (int)left : SW_CH;
-            int i = 0;
+            int i = (Q.prefetch & 4) ? iend : 0; // (timing experiments, POOLGEN_SWEEP_MODE: bit 1 = no loads after the first, bit 2 = no arithmetic)
             while (i < iend) {
                 if (pos >= n) { // padding between n and ld
                     int skip = ld - pos;
@@ -876,6 +880,8 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
         P.Q.sl = (int64_t)P.Q.g * ld;
         P.Q.nch = (int)((P.Q.sl + SW_CH - 1) / SW_CH);
         P.Q.total = p * ld;
+        P.Q.prefetch = std::getenv("POOLGEN_SWEEP_NOPF") ? 0 : 1;
+        if (const char *e = std::getenv("POOLGEN_SWEEP_MODE")) P.Q.prefetch = std::atoi(e); // 3: compute only, 5: memory only (wrong results)
     }
     const int64_t nsr = (p + P.Q.g - 1) / P.Q.g;
     P.D.p = p; P.D.ld = ld; P.D.ntiles = (nsr + 63) / 64;
@@ -937,38 +943,95 @@ extern "C" int pg_ols_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
     return pg_ols_sweep_dev(ctx, G_dev, p, n, ld, beta_dev, var_dev, pval_dev);
 }
 
+namespace {
+__global__ void k_accumulate(double *__restrict__ acc, const double *__restrict__ x, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) acc[i] += x[i];
+}
+struct HostPathRes { // whatever pg_ols_kinship holds while it runs; released on every exit path
+    double *Gd = nullptr, *out = nullptr, *S_acc = nullptr, *S_slab = nullptr;
+    hipStream_t copy = nullptr;
+    std::vector<hipEvent_t> ev;
+    ~HostPathRes() {
+        if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        (void)hipFree(Gd); (void)hipFree(out); (void)hipFree(S_acc); (void)hipFree(S_slab);
+    }
+};
+} // namespace
+
+// Host-buffer form of ols_iter_with_kinship (what main.rs:285-291 hands over: the whole matrix in host memory).
+// The link, not the GPU, sets its pace (16 GB at ~55 GB/s = 0.3 s against 10 ms of kernels), so the one thing worth
+// doing is never to leave the link idle:
+//   phase 1  G crosses the bus in SLABS on a copy stream (a pinned caller buffer is used as is; pageable pages are
+//            pinned in place by the runtime, which reaches the link rate on this platform -- no second host copy is made
+//            here) while the partial kinship of the slab that has already landed runs on the context's stream; the sums
+//            are accumulated on the device in slab order; G stays resident in HBM (288 GB hold config 3 eighteen times);
+//   n x n    eigen rule and basis on the accumulated sum (pg_kinship_set);
+//   phase 2  the sweep runs slab by slab over the resident matrix and the results of slab s return over the bus while
+//            slab s + 1 is swept.
+// POOLGEN_HOST_SLAB_MB sets the slab size (default 256).
 extern "C" int pg_ols_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld,
                               const double *Y, int k, double var_explained, int force_m, int *m_out,
                               double *K_out, double *beta, double *var, double *pval) {
     if (!ctx) return PG_ERR_INVALID;
-    PG_CHECK(ctx, G && beta && var && pval && p > 0, "ols_kinship: bad arguments");
+    PG_CHECK(ctx, G && Y && beta && var && pval && p > 0 && n >= 2 && k >= 1, "ols_kinship: bad arguments");
+    PG_CHECK(ctx, ld >= n && (ld % 2) == 0, "ols_kinship: ld (%lld) must be even and >= n (%d)", (long long)ld, n);
     PG_HIP(ctx, hipSetDevice(ctx->device));
-    // Simple resident form: G is copied once and stays in HBM for both passes (288 GB HBM3E
-    // holds the 16 GB of the 200 x 10M case many times over).
-    double *Gd = nullptr, *out = nullptr;
+    long slab_mb = 256;
+    if (const char *e = std::getenv("POOLGEN_HOST_SLAB_MB")) slab_mb = std::max(1L, std::atol(e));
+    int64_t slab_loci = ((int64_t)slab_mb << 20) / (ld * 8);
+    slab_loci = std::max<int64_t>(1024, slab_loci / 1024 * 1024); // a multiple of the sweep's super-row tiles
+    const int nslab = (int)((p + slab_loci - 1) / slab_loci);
+    HostPathRes R;
     const size_t gbytes = (size_t)p * ld * sizeof(double);
-    const size_t obytes = (size_t)p * k * sizeof(double);
-    PG_HIP(ctx, hipMalloc((void **)&Gd, gbytes));
-    if (hipMalloc((void **)&out, 3 * obytes) != hipSuccess) {
-        (void)hipFree(Gd);
-        return pg_fail(ctx, PG_ERR_HIP, "ols_kinship: out of device memory");
+    const size_t ocnt = (size_t)p * k;
+    if (hipMalloc((void **)&R.Gd, gbytes) != hipSuccess || hipMalloc((void **)&R.out, 3 * ocnt * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&R.S_acc, sizeof(double) * n * n) != hipSuccess || hipMalloc((void **)&R.S_slab, sizeof(double) * n * n) != hipSuccess)
+        return pg_fail(ctx, PG_ERR_HIP, "ols_kinship: out of device memory (%.1f GB for the matrix)", gbytes / 1e9);
+    PG_HIP(ctx, hipStreamCreateWithFlags(&R.copy, hipStreamNonBlocking));
+    R.ev.resize((size_t)2 * nslab + 1, nullptr);
+    for (auto &e : R.ev) PG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    PG_HIP(ctx, hipMemsetAsync(R.S_acc, 0, sizeof(double) * n * n, ctx->stream));
+    int rc = pg_set_phenotypes(ctx, 0, nullptr, 0); // the fused intercept-only sums belong to the resident path
+    if (rc) return rc;
+    // ---- phase 1: H2D of slab s + 1 || partial kinship of slab s ------------------------------------------------
+    auto h2d = [&](int sidx) -> hipError_t {
+        const int64_t lo = (int64_t)sidx * slab_loci, cnt = std::min(slab_loci, p - lo);
+        hipError_t e = hipMemcpyAsync(R.Gd + lo * ld, G + lo * ld, (size_t)cnt * ld * sizeof(double), hipMemcpyHostToDevice, R.copy);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(R.ev[sidx], R.copy);
+    };
+    PG_HIP(ctx, h2d(0));
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+        const int64_t lo = (int64_t)sidx * slab_loci, cnt = std::min(slab_loci, p - lo);
+        PG_HIP(ctx, hipStreamWaitEvent(ctx->stream, R.ev[sidx], 0));
+        rc = pg_launch_kinship(ctx, R.Gd + lo * ld, cnt, n, ld, R.S_slab, false, PG_K_KINSHIP, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_accumulate, dim3((n * n + 255) / 256), dim3(256), 0, ctx->stream, R.S_acc, R.S_slab, n * n);
+        PG_HIP(ctx, hipGetLastError());
+        if (sidx + 1 < nslab) PG_HIP(ctx, h2d(sidx + 1)); // queued behind nothing but the previous slab's copy
     }
-    int rc = PG_OK;
-    if (hipMemcpyAsync(Gd, G, gbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        rc = pg_fail(ctx, PG_ERR_HIP, "ols_kinship: H2D copy failed");
-    if (!rc)
-        rc = pg_ols_kinship_dev(ctx, Gd, p, n, ld, Y, k, var_explained, force_m, m_out, K_out, out,
-                                out + (size_t)p * k, out + 2 * (size_t)p * k);
-    if (!rc) {
-        if (hipMemcpyAsync(beta, out, obytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(var, out + (size_t)p * k, obytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(pval, out + 2 * (size_t)p * k, obytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-            rc = pg_fail(ctx, PG_ERR_HIP, "ols_kinship: D2H copy failed");
+    // ---- the n x n step ---------------------------------------------------------------------------------------------
+    rc = pg_kinship_set(ctx, R.S_acc, p, n, Y, k, var_explained, force_m, m_out, K_out, nullptr);
+    if (rc) return rc;
+    // ---- phase 2: sweep of slab s + 1 || D2H of the results of slab s -------------------------------------------
+    double *ob = R.out, *ov = R.out + ocnt, *op = R.out + 2 * ocnt;
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+        const int64_t lo = (int64_t)sidx * slab_loci, cnt = std::min(slab_loci, p - lo);
+        rc = pg_ols_sweep_dev(ctx, R.Gd + lo * ld, cnt, n, ld, ob + lo * k, ov + lo * k, op + lo * k);
+        if (rc) return rc;
+        hipEvent_t done = R.ev[(size_t)nslab + sidx];
+        PG_HIP(ctx, hipEventRecord(done, ctx->stream));
+        PG_HIP(ctx, hipStreamWaitEvent(R.copy, done, 0));
+        const size_t bytes = (size_t)cnt * k * sizeof(double);
+        PG_HIP(ctx, hipMemcpyAsync(beta + lo * k, ob + lo * k, bytes, hipMemcpyDeviceToHost, R.copy));
+        PG_HIP(ctx, hipMemcpyAsync(var + lo * k, ov + lo * k, bytes, hipMemcpyDeviceToHost, R.copy));
+        PG_HIP(ctx, hipMemcpyAsync(pval + lo * k, op + lo * k, bytes, hipMemcpyDeviceToHost, R.copy));
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(Gd);
-    (void)hipFree(out);
-    return rc;
+    PG_HIP(ctx, hipStreamSynchronize(R.copy));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -233,3 +233,75 @@ def test_operator_interface_reference_unit_tests():
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "apitest: all checks passed" in r.stdout and "FAIL" not in r.stdout
+
+
+def _sorted_fixture(tmp_path):
+    lines = [l for l in (GOLD / "test.sync").read_text().splitlines() if not l.startswith("#")]
+    lines.sort(key=lambda l: (l.split("\t")[0].encode(), int(l.split("\t")[1])))
+    srt = tmp_path / "sorted.sync"
+    srt.write_text("\n".join(lines) + "\n")
+    return srt
+
+
+@pytest.mark.parametrize("thr", ["0.5", "0.8"])
+def test_multi_gpu_kinship_ranks(tmp_path, thr):
+    """`--n-gpus`: the input is cut into one contiguous byte range per rank (own GPU context, own parser threads), the
+    partial kinship sums are all-reduced, every rank sweeps its own pieces, the CSV is assembled in rank order.
+    On the 1-GPU pool: (a) `--n-gpus 1` runs the REAL RCCL path (pg_comm_init_rank + pg_allreduce_sum_dev, one rank) and
+    must reproduce the flag-less run byte for byte; (b) two and three ranks sharing GPU 0 (PGH_COMM=host: the rehearsal mode,
+    sums added on the host in rank order because RCCL refuses two ranks per device) must give the same labels and, up to the
+    summation order of the kinship (m = 0: nothing at all), the same numbers."""
+    import os
+    srt = _sorted_fixture(tmp_path)
+    base = [str(CLI), "ols_iter_with_kinship", "-f", str(srt), "-p", str(GOLD / "test.csv"), "--phen-value-col", "2,3", "--n-threads", "4",
+            "-x", thr]
+    env = dict(os.environ, PGH_STREAM_CHUNK_BYTES="40000", PGH_TIMING="1")
+    one, rccl1 = tmp_path / "one.csv", tmp_path / "rccl1.csv"
+    r = subprocess.run(base + ["-o", str(one)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base + ["-o", str(rccl1), "--n-gpus", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "rank 0 (GPU 0" in r.stderr
+    assert one.read_bytes() == rccl1.read_bytes() and one.stat().st_size > 100000
+    la, va = _read_kinship_csv(one)
+    for ranks, ids in ((2, "0,0"), (3, "0,0,0")):
+        out = tmp_path / f"r{ranks}.csv"
+        r = subprocess.run(base + ["-o", str(out), "--n-gpus", str(ranks), "--gpu-ids", ids], capture_output=True, text=True,
+                           env=dict(env, PGH_COMM="host"))
+        assert r.returncode == 0, r.stderr
+        assert f"rank {ranks - 1} (GPU 0" in r.stderr
+        lb, vb = _read_kinship_csv(out)
+        assert la == lb
+        assert np.allclose(va, vb, rtol=1e-10, atol=1e-11, equal_nan=True)
+        if np.array_equal(va, vb, equal_nan=True):
+            assert one.read_bytes() == out.read_bytes()
+    # RCCL itself needs one GPU per rank; asking for two ranks on one device is refused with a clear message
+    r = subprocess.run(base + ["-o", str(tmp_path / "x.csv"), "--n-gpus", "2", "--gpu-ids", "0,0"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "one GPU per rank" in r.stderr
+    # an unsorted input cannot be split over ranks
+    r = subprocess.run([a if a != str(srt) else str(GOLD / "test.sync") for a in base] + ["-o", str(tmp_path / "y.csv"), "--n-gpus", "2",
+                       "--gpu-ids", "0,0"], capture_output=True, text=True, env=dict(env, PGH_COMM="host"))
+    assert r.returncode != 0 and "sorted by chromosome and position" in r.stderr
+
+
+@pytest.mark.parametrize("analysis,extra", [("ols_iter", ["--phen-value-col", "2,3"]), ("pearson_corr", ["--phen-value-col", "2"]),
+                                            ("chisq_test", [])])
+def test_multi_gpu_batch_operators(tmp_path, analysis, extra):
+    """The per-locus operators over several ranks: no exchange, one part file per rank concatenated in rank order (the
+    reference's one .tmp file per worker, sync.rs:794-870, :951-968) -- byte-identical to the single-rank file."""
+    import os
+    base = [str(CLI), analysis, "-f", str(GOLD / "test.sync"), "-p", str(GOLD / "test.csv"), "--n-threads", "4", *extra]
+    env = dict(os.environ, PGH_STREAM_CHUNK_BYTES="50000")
+    one = tmp_path / "one.csv"
+    r = subprocess.run(base + ["-o", str(one)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    for ranks, ids in ((1, "0"), (2, "0,0"), (5, "0,0,0,0,0")):
+        out = tmp_path / f"r{ranks}.csv"
+        r = subprocess.run(base + ["-o", str(out), "--n-gpus", str(ranks), "--gpu-ids", ids], capture_output=True, text=True,
+                           env=dict(env, PGH_COMM="host"))
+        assert r.returncode == 0, r.stderr
+        assert one.read_bytes() == out.read_bytes() and one.stat().st_size > 10000
+        assert not list(tmp_path.glob("*.tmp"))
+    r = subprocess.run([str(CLI), "fst", "-f", str(GOLD / "test.sync"), "-p", str(GOLD / "test.csv"), "--n-gpus", "2", "-o", str(tmp_path / "f.csv")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "runs on one GPU" in r.stderr

@@ -1,0 +1,138 @@
+"""The HOST-BUFFER entry points of the C ABI -- what INTEGRATION.md tells a poolgen maintainer to call first -- through ctypes
+with plain numpy buffers (no torch, no device pointers on the caller's side), against the oracle:
+  pg_ols_kinship                 (gwas/ols.rs:278-436 numeric core; main.rs:285-291)
+  pg_ols_iter_batch / pg_pearson_batch / pg_chisq_batch   (gwas/ols.rs:201-276, correlation_test.rs:73-129, chisq_test.rs:5-47)"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(native):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    c = C.c_void_p()
+    assert native.pg_create(C.byref(c), 0, None) == 0, native.pg_last_error(None)
+    yield c
+    native.pg_destroy(c)
+
+
+def host_G(p, n, seed, ld=None):
+    from poolgen_amd import synth
+    G = synth.genotype_matrix(p, n, "cuda", seed=seed, ld=ld)
+    Y = synth.phenotypes(G, n, k=2, seed=seed)
+    return np.ascontiguousarray(G.cpu().numpy()), Y
+
+
+@pytest.mark.parametrize("p,n,k,x,force_m,slab_mb", [(30011, 200, 1, 0.75, -1, 1), (30011, 200, 2, 0.75, 3, 1), (5000, 60, 2, 0.99, -1, 1),
+                                                      (777, 100, 1, 0.75, -1, 256), (70001, 37, 1, 0.75, 2, 2)])
+def test_ols_kinship_host_buffers(native, ctx, oracle, exact, p, n, k, x, force_m, slab_mb):
+    """G in (pageable) host memory, results in host memory; slabs of 1-2 MB so that the slab pipeline (H2D of slab s + 1 ||
+    partial kinship of slab s; sweep of slab s + 1 || D2H of slab s) really runs over many slabs, ragged last slab included."""
+    from test_gpu_exact import assert_close, formula_p
+    G, Y = host_G(p, n, 61)
+    Y = np.ascontiguousarray(Y[:, :k])
+    ld = G.shape[1]
+    beta, var, pv = (np.full((p, k), -7.0) for _ in range(3))
+    K = np.empty((n, n)); m = C.c_int(-1)
+    os.environ["POOLGEN_HOST_SLAB_MB"] = str(slab_mb)
+    try:
+        rc = native.pg_ols_kinship(ctx, G.ctypes.data, p, n, ld, Y.ctypes.data, k, x, force_m, C.byref(m), K.ctypes.data,
+                                   beta.ctypes.data, var.ctypes.data, pv.ctypes.data)
+    finally:
+        del os.environ["POOLGEN_HOST_SLAB_MB"]
+    assert rc == 0, native.pg_last_error(ctx)
+    ref = oracle.ols_with_covariate(G, Y, x, force_m=force_m, n=n)
+    assert m.value == ref["m"]
+    assert np.allclose(K, ref["K"], rtol=1e-11, atol=0)
+    if m.value == 0:
+        ok = np.isfinite(ref["beta"])
+        assert np.array_equal(np.isnan(beta), ~ok)
+        assert np.allclose(beta[ok], ref["beta"][ok], rtol=1e-10, atol=1e-10)
+        assert np.allclose(var[ok], ref["var"][ok], rtol=1e-10, atol=1e-13)
+        assert np.max(np.abs(pv[ok] - ref["pval"][ok])) <= 1e-10
+    else:   # covariate fits: the reference point is the binary128 chain (tests/test_gpu_exact.py)
+        ex = exact.ols_with_covariate(G, Y, x, force_m=force_m, n=n)
+        assert ex["m"] == m.value
+        assert_close((beta, var, pv), ex, formula_p(oracle, ex, n), f"host path p={p} n={n} m={m.value}")
+
+
+def test_ols_kinship_host_rejects_bad_arguments(native, ctx):
+    G, Y = host_G(128, 10, 3)
+    b = np.empty((128, 1))
+    assert native.pg_ols_kinship(ctx, G.ctypes.data, 128, 10, 9, Y.ctypes.data, 1, 0.75, -1, None, None, b.ctypes.data, b.ctypes.data,
+                                 b.ctypes.data) == -1                      # ld < n
+    assert b"ld" in native.pg_last_error(ctx)
+    assert native.pg_ols_kinship(ctx, None, 128, 10, 10, Y.ctypes.data, 1, 0.75, -1, None, None, b.ctypes.data, b.ctypes.data,
+                                 b.ctypes.data) == -1
+
+
+def _counts(L, n, seed):
+    rng = np.random.default_rng(seed)
+    c = np.zeros((L, n, 6), dtype=np.uint32)
+    depth = rng.poisson(40, size=(L, n)) + 3
+    f = np.clip(rng.beta(0.6, 0.6, size=(L, 1)) + 0.1 * rng.normal(size=(L, n)), 0, 1)
+    alt = rng.binomial(depth, f)
+    third = rng.binomial(depth - alt, 0.05 * (rng.random((L, 1)) < 0.3))
+    c[:, :, 0] = depth - alt - third; c[:, :, 1] = alt; c[:, :, 2] = third
+    c[rng.random(L) < 0.05] = 0                                      # uncovered loci
+    c[:, :, 4] = rng.binomial(2, 0.1, size=(L, n))                   # some Ns
+    return c
+
+
+@pytest.mark.parametrize("op", ["ols_iter", "pearson", "chisq"])
+def test_batch_operators_host_buffers(native, ctx, oracle, op):
+    from poolgen_amd._native import PgFilter
+    L, n, k = 700, 24, 2
+    counts = _counts(L, n, 5)
+    rng = np.random.default_rng(6)
+    Y = np.ascontiguousarray(rng.normal(size=(n, k)))
+    ps = np.full(n, 1.0 / n)
+    f = PgFilter(1, 0, 5, 0.01, 0.0)
+    fo = oracle.filt(True, 5, 0.01, 0.0)
+    n_out = np.full(L, -1, dtype=np.int32); ids = np.full((L, 5), -1, dtype=np.int32)
+    mf = np.full((L, 5), np.nan); stat = np.full((L, 5, k), np.nan); pv = np.full((L, 5, k), np.nan)
+    if op == "chisq":
+        chi2 = np.full(L, np.nan); p1 = np.full(L, np.nan)
+        rc = native.pg_chisq_batch(ctx, counts.ctypes.data, L, n, ps.ctypes.data, C.byref(f), n_out.ctypes.data, ids.ctypes.data,
+                                   chi2.ctypes.data, p1.ctypes.data)
+    else:
+        fn = native.pg_ols_iter_batch if op == "ols_iter" else native.pg_pearson_batch
+        rc = fn(ctx, counts.ctypes.data, L, n, ps.ctypes.data, C.byref(f), Y.ctypes.data, k, n_out.ctypes.data, ids.ctypes.data,
+                mf.ctypes.data, stat.ctypes.data, pv.ctypes.data)
+    assert rc == 0, native.pg_last_error(ctx)
+    emitted = 0
+    for l in range(L):
+        c64 = counts[l].astype(np.uint64)
+        if op == "chisq":
+            a, rid, rchi, rp = oracle.chisq_locus(c64, ps, fo)
+            assert n_out[l] == a, l
+            if a:
+                assert list(ids[l, :a]) == list(rid)
+                assert (np.isnan(chi2[l]) and np.isnan(rchi)) or abs(chi2[l] - rchi) <= 1e-10 * max(1.0, abs(rchi))
+                assert (np.isnan(p1[l]) and np.isnan(rp)) or abs(p1[l] - rp) <= 1e-10
+                emitted += 1
+            continue
+        ref = (oracle.ols_iterate_locus if op == "ols_iter" else oracle.correlation_locus)(c64, Y, ps, fo)
+        na = max(ref[0], 0)
+        assert n_out[l] == na, (l, n_out[l], na)
+        if na == 0:
+            continue
+        emitted += 1
+        assert list(ids[l, :na]) == list(ref[1])
+        assert np.array_equal(mf[l, :na], np.array(ref[2]))                 # mean frequencies: bit-exact
+        X = None
+        if op == "ols_iter":   # rank-deficient designs print noise in the reference: emission pattern only (counted below)
+            idf, fc = oracle.filter_locus(c64, ps, fo)
+            fr, _ = oracle.sort_by_allele_freq(oracle.to_frequencies(fc), idf, True)
+            X = np.ones_like(fr); X[:, 1:] = fr[:, 1:]
+            if np.linalg.cond(X) > 1e7:
+                continue
+        assert np.allclose(stat[l, :na], ref[3], rtol=1e-10, atol=1e-10, equal_nan=True), l
+        assert np.allclose(pv[l, :na], ref[4], rtol=0, atol=1e-10, equal_nan=True), l
+    assert emitted > L // 3

@@ -30,6 +30,13 @@ def test_python_binding_covers_the_header():
     assert sorted(SIGNATURES) == header_functions()
 
 
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md's `extern "C"` block is the reference-side binding: it must declare every function of the header."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    missing = [n for n in header_functions() if f"fn {n}(" not in text]
+    assert not missing, missing
+
+
 def test_no_product_code_touches_the_oracle():
     """The product (poolgen_amd/, include/) must never include, link, import or call oracle/."""
     bad = re.compile(r"poolgen_oracle\.h|liboracle|\borc_[a-z_]+\s*\(|oracle_lib|import\s+oracle|from\s+oracle|oracle/")

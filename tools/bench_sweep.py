@@ -23,16 +23,20 @@ for m in (0, 8):
     ref = None
     for rnd in range(2):
         for v in variants:
-            for key in ("POOLGEN_SWEEP_V1", "POOLGEN_SWEEP_GRID_MULT"):
+            for key in ("POOLGEN_SWEEP_V1", "POOLGEN_SWEEP_GRID_MULT", "POOLGEN_SWEEP_NOPF", "POOLGEN_SWEEP_MODE"):
                 os.environ.pop(key, None)
             if v == "v1":
                 os.environ["POOLGEN_SWEEP_V1"] = "1"
+            elif v.startswith("v2mode"):
+                os.environ["POOLGEN_SWEEP_MODE"] = v[6:]
+            elif v == "v2nopf":
+                os.environ["POOLGEN_SWEEP_NOPF"] = "1"
             elif v.startswith("v2g"):
                 os.environ["POOLGEN_SWEEP_GRID_MULT"] = v[3:]
             eng.ols_sweep(G, 1, n, out); torch.cuda.synchronize()
             if ref is None:
                 ref = out.clone()
-            else:
+            elif "mode" not in v:
                 d = float((out[0] - ref[0]).abs().max()); dp = float((out[2] - ref[2]).abs().max())
                 assert d < 1e-9 and dp < 1e-9, (v, d, dp)
             eng.profile(True); eng.profile_reset()
