@@ -361,6 +361,7 @@ std::vector<double> pg_tdist_coef(int df) {
             c.push_back(v);
         }
     }
+    while (c.size() % 8) c.push_back(0.0); // the device evaluates the series in blocks of 8 coefficients (pg_stats_device.h)
     return c;
 }
 
@@ -476,8 +477,14 @@ extern "C" double pg_host_t_two_sided_p(double t_abs, int df) {
     const double nu = (double)df;
     const double c2 = nu / (nu + t_abs * t_abs);
     const double s = std::sqrt(1.0 - c2);
-    double poly = 0.0;
-    for (int j = (int)coef.size() - 1; j >= 0; --j) poly = std::fma(poly, c2, coef[j]);
+    // the device's evaluation order (pg_stats_device.h): four interleaved Horner chains in c2^4
+    const double x2 = c2 * c2, y = x2 * x2;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    for (int b = (int)coef.size() - 8; b >= 0; b -= 8) {
+        p0 = std::fma(p0, y, coef[b + 4]); p1 = std::fma(p1, y, coef[b + 5]); p2 = std::fma(p2, y, coef[b + 6]); p3 = std::fma(p3, y, coef[b + 7]);
+        p0 = std::fma(p0, y, coef[b]); p1 = std::fma(p1, y, coef[b + 1]); p2 = std::fma(p2, y, coef[b + 2]); p3 = std::fma(p3, y, coef[b + 3]);
+    }
+    const double poly = std::fma(std::fma(std::fma(p3, c2, p2), c2, p1), c2, p0);
     double A;
     if (df & 1) {
         const double c = std::sqrt(c2);

@@ -172,7 +172,9 @@ static_assert(SW_NLD == 16, "the staging macros below spell out 16 load instruct
     }
 #define SW_STAGE(r) *reinterpret_cast<double2 *>(&tile[(SW_RPI * r + lr) * SW_PITCH + 2 * piece]) = v##r;
 
-template <int C>
+// EXP: timing experiments only (wrong results): bit 0 = W operands are constants (no scalar loads), bit 1 = g is a constant
+// (no LDS reads), bit 2 = no LDS staging writes
+template <int C, int EXP = 0>
 __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
     const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
     const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
@@ -194,10 +196,18 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
     for (; t < D.ntiles; t += wstride) {
         double acc[C];
         double s2 = 0.0, shift = 0.0;
+        double stash_b = 0.0, stash_v = 0.0, stash_p = 0.0; // g == 2, one trait: the results of the super-row's first locus wait for
+                          // the second, so that the pair leaves as one 16-byte store per lane (two half-filled lines per store
+                          // otherwise: WRITE_SIZE 2x)
         int j = 0, pos = 0; // locus within the super-row, position within its row (pools n..ld-1 are padding)
         for (int ch = 0; ch < Q.nch; ++ch) {
             if (!(Q.prefetch & 1)) SW_ISSUE(t, ch)
-            SW_REP16(SW_STAGE)
+            if (EXP & 4) {
+#define SW_TOUCH(r) s2 += v##r.x + v##r.y;
+                SW_REP16(SW_TOUCH)
+            } else {
+                SW_REP16(SW_STAGE)
+            }
             __builtin_amdgcn_wave_barrier();
             if ((Q.prefetch & 3) == 1) {   // next chunk of this tile, else the first chunk of the wave's next tile (clamped loads: harmless past the end)
                 const bool more = ch + 1 < Q.nch;
@@ -228,19 +238,39 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
                 if (i == 0 && len == SW_CH) {
 #pragma unroll
                     for (int q = 0; q < SW_CH; q += 2) {
-                        const double2 g2 = *reinterpret_cast<const double2 *>(&row[q]);
+                        const double2 g2 = (EXP & 2) ? double2{shift + 1e-3 * q, shift - 1e-3} : *reinterpret_cast<const double2 *>(&row[q]);
                         const double ga = g2.x - shift;
                         const double gb = g2.y - shift;
                         s2 = fma(ga, ga, s2);
 #pragma unroll
-                        for (int c = 0; c < C; ++c) acc[c] = fma(ga, Wp[q * C + c], acc[c]);
+                        for (int c = 0; c < C; ++c) acc[c] = fma(ga, (EXP & 1) ? 0.25 + c : Wp[q * C + c], acc[c]);
                         s2 = fma(gb, gb, s2);
 #pragma unroll
-                        for (int c = 0; c < C; ++c) acc[c] = fma(gb, Wp[(q + 1) * C + c], acc[c]);
+                        for (int c = 0; c < C; ++c) acc[c] = fma(gb, (EXP & 1) ? 0.5 - c : Wp[(q + 1) * C + c], acc[c]);
                     }
                 } else if (((i | len) & 1) == 0) {
-#pragma unroll 4
-                    for (int q = 0; q < len; q += 2) {
+                    // a run that is not a whole chunk (the chunk holds the end of one locus and the start of the next): blocks of
+                    // 8 pools with their W operands fetched up front (one or two wide scalar loads per block instead of a
+                    // wait per pair), then what is left pair by pair
+                    int q = 0;
+                    for (; C <= 4 && q + 8 <= len; q += 8) { // (more columns than that and the block's W operands overflow the scalar registers)
+                        double2 g2[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) g2[u] = *reinterpret_cast<const double2 *>(&row[i + q + 2 * u]);
+                        const double *wq = Wp + (size_t)q * C;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double ga = g2[u].x - shift;
+                            const double gb = g2[u].y - shift;
+                            s2 = fma(ga, ga, s2);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[c] = fma(ga, wq[(2 * u) * C + c], acc[c]);
+                            s2 = fma(gb, gb, s2);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[c] = fma(gb, wq[(2 * u + 1) * C + c], acc[c]);
+                        }
+                    }
+                    for (; q < len; q += 2) {
                         const double2 g2 = *reinterpret_cast<const double2 *>(&row[i + q]);
                         const double ga = g2.x - shift;
                         const double gb = g2.y - shift;
@@ -263,6 +293,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
                 if (pos == n) {
                     // ---- per-locus closing arithmetic (gwas/ols.rs:102-116, 139-158) ---------------------
                     const int64_t l = (t * 64 + lane) * Q.g + j;
+                    const bool pairs = Q.g == 2 && D.k == 1;
                     if (l < D.p) {
                         double uu = 0.0;
 #pragma unroll
@@ -275,9 +306,17 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
                             for (int a = 0; a < C; ++a) sgy = (a == D.m1 + jt) ? acc[a] : sgy;
                             double b, vb, pv;
                             ols_close(sgg, sgy, syy[jt], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
-                            beta[l * D.k + jt] = b;
-                            var[l * D.k + jt] = vb;
-                            pval[l * D.k + jt] = pv;
+                            if (!pairs || (j == 0 && l + 1 >= D.p)) { // (or the matrix ends inside this super-row)
+                                beta[l * D.k + jt] = b;
+                                var[l * D.k + jt] = vb;
+                                pval[l * D.k + jt] = pv;
+                            } else if (j == 0) {
+                                stash_b = b; stash_v = vb; stash_p = pv;
+                            } else {
+                                *reinterpret_cast<double2 *>(&beta[l - 1]) = double2{stash_b, b};
+                                *reinterpret_cast<double2 *>(&var[l - 1]) = double2{stash_v, vb};
+                                *reinterpret_cast<double2 *>(&pval[l - 1]) = double2{stash_p, pv};
+                            }
                         }
                     }
                     if (n == ld) { pos = 0; ++j; }
@@ -288,9 +327,14 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
     }
 }
 
-// ---- round-1 form of the sweep (per-row 256-byte chunk grid, no prefetch), kept for A/B timing: POOLGEN_SWEEP_V1=1
+// ---- the sweep on a per-ROW chunk grid (round 1's form: no super-rows, no prefetch; rows that start 64 bytes into a line make
+// it touch 1.14x the algorithmic bytes).  It stays in the product for WIDE designs: measured on 200 pools x 10 M loci with m = 8
+// covariates (12 columns) 3.15 ms against 3.85 ms for the super-row kernel above (whose staging registers, prefetch and
+// mid-chunk locus boundaries cost more than the over-fetch once 14 fp64 operations per pool keep the vector unit busy), while
+// for the narrow designs (m = 0: 2 columns) the super-row kernel is ahead and moves exactly the algorithmic bytes.
+// launch_sweep picks by column count; POOLGEN_SWEEP_V1=1 / POOLGEN_SWEEP_V2=1 force one of them (A/B timing).
 template <int C>
-__global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep_v1(
+__global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep_rows(
     const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
     const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
     double *__restrict__ pval, const SweepDims D) {
@@ -590,16 +634,17 @@ struct SweepArgs {
 template <int C>
 int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
     const size_t shmem = (size_t)SW_WAVES * SW_TILE * sizeof(double);
-    if (std::getenv("POOLGEN_SWEEP_V1")) {
+    const bool rows_kernel = std::getenv("POOLGEN_SWEEP_V1") || (C >= 6 && !std::getenv("POOLGEN_SWEEP_V2"));
+    if (rows_kernel) {
         SweepDims D1 = A.D;
         D1.ntiles = (A.D.p + 63) / 64;
         int64_t blocks = (D1.ntiles + SW_WAVES - 1) / SW_WAVES;
         const int64_t cap = (int64_t)ctx->cus * 8;
         const int g1 = (int)(blocks < cap ? blocks : cap);
-        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ols_sweep_v1<C>),
+        PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ols_sweep_rows<C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         pg_prof_begin(ctx, PG_K_SWEEP);
-        hipLaunchKernelGGL(k_ols_sweep_v1<C>, dim3(g1), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W,
+        hipLaunchKernelGGL(k_ols_sweep_rows<C>, dim3(g1), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W,
                            A.syy, A.tcoef, A.beta, A.var, A.pval, D1);
         pg_prof_end(ctx);
         PG_HIP(ctx, hipGetLastError());
@@ -607,6 +652,28 @@ int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
     }
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ols_sweep<C>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if constexpr (C == 2) {
+        if (const char *e = std::getenv("POOLGEN_SWEEP_EXP")) {
+            const int x = std::atoi(e);
+            auto go = [&](auto kern) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                pg_prof_begin(ctx, PG_K_SWEEP);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W, A.syy, A.tcoef, A.beta, A.var,
+                                   A.pval, A.D, A.Q);
+                pg_prof_end(ctx);
+            };
+            switch (x) {
+            case 1: go(k_ols_sweep<2, 1>); break;
+            case 2: go(k_ols_sweep<2, 2>); break;
+            case 3: go(k_ols_sweep<2, 3>); break;
+            case 4: go(k_ols_sweep<2, 4>); break;
+            case 6: go(k_ols_sweep<2, 6>); break;
+            default: go(k_ols_sweep<2, 7>); break;
+            }
+            PG_HIP(ctx, hipGetLastError());
+            return PG_OK;
+        }
+    }
     pg_prof_begin(ctx, PG_K_SWEEP);
     hipLaunchKernelGGL(k_ols_sweep<C>, dim3(grid), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W,
                        A.syy, A.tcoef, A.beta, A.var, A.pval, A.D, A.Q);

@@ -17,16 +17,20 @@ Y = synth.phenotypes(G[:100000], n, k=1)
 out = torch.empty((3, p, 1), dtype=torch.float64, device="cuda")
 rng = np.random.default_rng(1)
 res = {}
-for m in (0, 8):
+for m in [int(x) for x in os.environ.get('SWEEP_MS', '0,8').split(',')]:
     C = None if m == 0 else np.linalg.qr(rng.normal(size=(n, m)))[0]
     eng.covariates_set(n, C, Y)
     ref = None
     for rnd in range(2):
         for v in variants:
-            for key in ("POOLGEN_SWEEP_V1", "POOLGEN_SWEEP_GRID_MULT", "POOLGEN_SWEEP_NOPF", "POOLGEN_SWEEP_MODE"):
+            for key in ("POOLGEN_SWEEP_V1", "POOLGEN_SWEEP_V2", "POOLGEN_SWEEP_GRID_MULT", "POOLGEN_SWEEP_NOPF", "POOLGEN_SWEEP_MODE", "POOLGEN_SWEEP_EXP"):
                 os.environ.pop(key, None)
             if v == "v1":
                 os.environ["POOLGEN_SWEEP_V1"] = "1"
+            elif v == "v2":
+                os.environ["POOLGEN_SWEEP_V2"] = "1"
+            elif v.startswith("v2exp"):
+                os.environ["POOLGEN_SWEEP_EXP"] = v[5:]
             elif v.startswith("v2mode"):
                 os.environ["POOLGEN_SWEEP_MODE"] = v[6:]
             elif v == "v2nopf":
@@ -36,7 +40,7 @@ for m in (0, 8):
             eng.ols_sweep(G, 1, n, out); torch.cuda.synchronize()
             if ref is None:
                 ref = out.clone()
-            elif "mode" not in v:
+            elif "mode" not in v and "exp" not in v:
                 d = float((out[0] - ref[0]).abs().max()); dp = float((out[2] - ref[2]).abs().max())
                 assert d < 1e-9 and dp < 1e-9, (v, d, dp)
             eng.profile(True); eng.profile_reset()
