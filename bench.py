@@ -225,7 +225,7 @@ def main():
                 "achieved": per_s(kin_exec_flops, kin_avg), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_s(kin_exec_flops, kin_avg) / FP64_MFMA_PEAK_TFLOPS,
                 "what": "EXECUTED fp64 MFMA flop/s (matrix-pipe utilisation); the peak is AMD's datasheet 78.6 TFLOP/s, confirmed at "
-                        "78.0 by tools/microbench.hip (profiles/r02_microbench.log)",
+                        "77.4 (4 waves/SIMD) by tools/microbench.hip on the box (profiles/r02_microbench.log)",
                 "useful_tflops": per_s(kin_useful_flops, kin_avg),
                 "useful_frac": per_s(kin_useful_flops, kin_avg) / FP64_MFMA_PEAK_TFLOPS,
                 "algorithmic_tflops": kin_tflops,

@@ -1,6 +1,8 @@
 // host_util.cpp -- see host_util.h.  Compiled with -ffp-contract=off: the filter arithmetic must
 // round exactly like the reference (multiply, then add).
 #include "host_util.h"
+#include <cctype>
+#include <climits>
 #include <algorithm>
 #include <charconv>
 #include <chrono>
@@ -83,6 +85,62 @@ static std::vector<std::string> split(const std::string &s, const std::string &d
     return out;
 }
 
+bool parse_f64_strict(const std::string &s, double &out) {
+    size_t i = 0;
+    const size_t n = s.size();
+    if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+    auto lower_eq = [&](const char *w) {
+        size_t k = 0;
+        for (; w[k]; ++k)
+            if (i + k >= n || std::tolower((unsigned char)s[i + k]) != w[k]) return false;
+        return i + k == n;
+    };
+    if (lower_eq("inf") || lower_eq("infinity") || lower_eq("nan")) {
+        out = std::strtod(s.c_str(), nullptr);
+        return true;
+    }
+    size_t digits = 0;
+    while (i < n && std::isdigit((unsigned char)s[i])) { ++i; ++digits; }
+    if (i < n && s[i] == '.') {
+        ++i;
+        while (i < n && std::isdigit((unsigned char)s[i])) { ++i; ++digits; }
+    }
+    if (digits == 0) return false;
+    if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+        ++i;
+        if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+        size_t ed = 0;
+        while (i < n && std::isdigit((unsigned char)s[i])) { ++i; ++ed; }
+        if (ed == 0) return false;
+    }
+    if (i != n) return false;
+    out = std::strtod(s.c_str(), nullptr);
+    return true;
+}
+
+bool parse_u64_strict(const std::string &s, uint64_t &out) {
+    size_t i = (!s.empty() && s[0] == '+') ? 1 : 0;
+    if (i >= s.size()) return false;
+    uint64_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (!std::isdigit((unsigned char)s[i])) return false;
+        const uint64_t d = (uint64_t)(s[i] - '0');
+        if (v > (UINT64_MAX - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    out = v;
+    return true;
+}
+
+bool parse_i64_strict(const std::string &s, int64_t &out) {
+    const bool neg = !s.empty() && s[0] == '-';
+    uint64_t v = 0;
+    if (!parse_u64_strict(neg ? s.substr(1) : s, v) || (neg && !s.empty() && s.size() > 1 && s[1] == '+')) return false;
+    if (v > (uint64_t)INT64_MAX + (neg ? 1 : 0)) return false;
+    out = neg ? (int64_t)(0 - v) : (int64_t)v;
+    return true;
+}
+
 Phen parse_phen(const std::string &fname, const std::string &delim, int name_col, int size_col,
                 const std::vector<int> &value_cols) {
     std::ifstream in(fname);
@@ -99,9 +157,8 @@ Phen parse_phen(const std::string &fname, const std::string &delim, int name_col
         const int need = std::max({name_col, size_col, ph.k ? *std::max_element(value_cols.begin(), value_cols.end()) : 0});
         if ((int)v.size() <= need) throw std::runtime_error("phenotype file: too few columns in line: " + line);
         ph.pool_names.push_back(v[name_col]);
-        char *end = nullptr;
-        const double sz = std::strtod(v[size_col].c_str(), &end);
-        if (v[size_col].empty() || *end != 0)
+        double sz = 0.0;
+        if (!parse_f64_strict(v[size_col], sz))
             throw std::runtime_error("T_T Pool sizes column (column index: " + std::to_string(size_col) +
                                      ") is not a valid number. Line: " + line + ".");
         ph.pool_sizes.push_back(sz);
@@ -110,8 +167,8 @@ Phen parse_phen(const std::string &fname, const std::string &delim, int name_col
             if (t == "" || t == "NA" || t == "NAN" || t == "NaN" || t == "na" || t == "nan") {
                 ph.phen.push_back(NAN); // phen.rs:68-75
             } else {
-                const double y = std::strtod(t.c_str(), &end);
-                if (*end != 0)
+                double y = 0.0;
+                if (!parse_f64_strict(t, y))
                     throw std::runtime_error("T_T Error parsing the phenotype file. The trait values specified cannot be casted into float64.");
                 ph.phen.push_back(y);
             }

@@ -17,6 +17,14 @@ double sensible_round(double x, int n_digits);           // helpers.rs:103-108
 std::string roundup_own(double x, int n_digits);         // helpers.rs:111-117
 void append_roundup_own(std::string &out, double x, int n_digits); // the same, appended in place
 
+// ---- numbers as Rust's `str::parse` reads them (main.rs flag values, base/phen.rs:60-78) ------------------------
+// f64: [+-] digits [. digits] [e [+-] digits] | [+-] inf | infinity | nan (any case); no hex floats, no surrounding blanks,
+// nothing after the number.  u64 / i64: [+] digits (i64 also -), in range, nothing else -- "2x", "-1" for an unsigned flag
+// or "1e3" for an integer are errors there and here (strtod / stoi would have accepted them).
+bool parse_f64_strict(const std::string &s, double &out);
+bool parse_u64_strict(const std::string &s, uint64_t &out);
+bool parse_i64_strict(const std::string &s, int64_t &out);
+
 // ---- phenotypes ---------------------------------------------------------------------------------
 struct Phen {
     std::vector<std::string> pool_names;

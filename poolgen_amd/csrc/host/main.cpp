@@ -16,6 +16,7 @@
 #include <fstream>
 #include <future>
 #include <iostream>
+#include <climits>
 #include <map>
 #include <memory>
 #include <exception>
@@ -50,11 +51,23 @@ struct Args {
 };
 
 static double parse_valid_freq(const std::string &v, const std::string &flag) { // helpers.rs:93-100
-    char *end = nullptr;
-    const double x = std::strtod(v.c_str(), &end);
-    if (v.empty() || *end != 0) throw std::runtime_error("`" + v + "` isn't a valid number (" + flag + ")");
+    double x = 0.0;
+    if (!parse_f64_strict(v, x)) throw std::runtime_error("`" + v + "` isn't a valid number (" + flag + ")");
     if (x < 0.0 || x > 1.0) throw std::runtime_error("Value must be between 0.0 and 1.0, got `" + rust_display(x) + "` (" + flag + ")");
     return x;
+}
+
+// integer flag values as clap's `parse::<usize / u64>()` reads them: digits only, nothing after them, no sign for the unsigned
+static uint64_t flag_u64(const std::string &v, const std::string &flag) {
+    uint64_t x = 0;
+    if (!parse_u64_strict(v, x)) throw std::runtime_error("invalid value `" + v + "` for " + flag + ": a non-negative integer is expected");
+    return x;
+}
+static int flag_int(const std::string &v, const std::string &flag, int64_t lo = 0) {
+    int64_t x = 0;
+    if (!parse_i64_strict(v, x) || x < lo || x > INT32_MAX)
+        throw std::runtime_error("invalid value `" + v + "` for " + flag + ": an integer >= " + std::to_string(lo) + " is expected");
+    return (int)x;
 }
 
 static const char *USAGE =
@@ -98,17 +111,17 @@ static Args parse_args(int argc, char **argv) {
         else if (k == "-o" || k == "--output") a.output = val();
         else if (k == "-p" || k == "--phen-fname") a.phen_fname = val();
         else if (k == "--phen-delim") a.phen_delim = val();
-        else if (k == "--phen-name-col") a.phen_name_col = std::stoi(val());
-        else if (k == "--phen-pool-size-col") a.phen_pool_size_col = std::stoi(val());
+        else if (k == "--phen-name-col") a.phen_name_col = flag_int(val(), k);
+        else if (k == "--phen-pool-size-col") a.phen_pool_size_col = flag_int(val(), k);
         else if (k == "--phen-value-col") {
             a.phen_value_col.clear();
             std::stringstream ss(val());
             std::string t;
-            while (std::getline(ss, t, ',')) a.phen_value_col.push_back(std::stoi(t));
-        } else if (k == "--n-threads") a.n_threads = std::stoi(val());
+            while (std::getline(ss, t, ',')) a.phen_value_col.push_back(flag_int(t, k));
+        } else if (k == "--n-threads") a.n_threads = flag_int(val(), k, 1);
         else if (k == "--max-base-error-rate") a.max_base_error_rate = parse_valid_freq(val(), k);
         else if (k == "--min-coverage-breadth") a.min_coverage_breadth = parse_valid_freq(val(), k);
-        else if (k == "--min-coverage-depth") a.min_coverage_depth = std::stoull(val());
+        else if (k == "--min-coverage-depth") a.min_coverage_depth = flag_u64(val(), k);
         else if (k == "--min-allele-frequency") a.min_allele_frequency = parse_valid_freq(val(), k);
         else if (k == "--max-missingness-rate") a.max_missingness_rate = parse_valid_freq(val(), k);
         else if (k == "-x" || k == "--xxt-eigen-variance-explained") a.xxt = parse_valid_freq(val(), k);
@@ -117,19 +130,19 @@ static Args parse_args(int argc, char **argv) {
         else if (k == "--generate-plots") a.generate_plots = true;
         else if (k == "--output-sig-snps-only") a.sig_only = true;
         else if (k == "--keep-lowercase-reference") a.keep_lowercase_reference = true; // pileup inputs only (pileup.rs:280-299)
-        else if (k == "--stream-chunk-mb") a.stream_chunk_mb = std::stol(val());
-        else if (k == "--n-gpus") { a.n_gpus = std::stoi(val()); if (a.n_gpus < 1) throw std::runtime_error("--n-gpus must be at least 1"); }
+        else if (k == "--stream-chunk-mb") a.stream_chunk_mb = flag_int(val(), k);
+        else if (k == "--n-gpus") a.n_gpus = flag_int(val(), k, 1);
         else if (k == "--gpu-ids") {
             std::stringstream ss(val());
             std::string t;
-            while (std::getline(ss, t, ',')) a.gpu_ids.push_back(std::stoi(t));
+            while (std::getline(ss, t, ',')) a.gpu_ids.push_back(flag_int(t, k));
         }
-        else if (k == "--k-folds") a.k_folds = std::stoi(val());
-        else if (k == "--n-reps") a.n_reps = std::stoi(val());
-        else if (k == "--seed") a.seed = std::stoull(val());
-        else if (k == "--window-size-bp") a.window_size_bp = std::stoull(val());
-        else if (k == "--window-slide-size-bp") a.window_slide_size_bp = std::stoull(val());
-        else if (k == "--min-loci-per-window") a.min_loci_per_window = std::stoull(val());
+        else if (k == "--k-folds") a.k_folds = flag_int(val(), k, 1);
+        else if (k == "--n-reps") a.n_reps = flag_int(val(), k, 1);
+        else if (k == "--seed") a.seed = flag_u64(val(), k);
+        else if (k == "--window-size-bp") a.window_size_bp = flag_u64(val(), k);
+        else if (k == "--window-slide-size-bp") a.window_slide_size_bp = flag_u64(val(), k);
+        else if (k == "--min-loci-per-window") a.min_loci_per_window = flag_u64(val(), k);
         else if (k.rfind("-", 0) == 0) throw std::runtime_error("unknown flag " + k);
         else pos.push_back(k);
     }

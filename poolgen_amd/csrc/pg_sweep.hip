@@ -699,6 +699,11 @@ extern "C" int pg_covariates_set(pg_ctx *ctx, int n, const double *Cmat, int m, 
     if (!ctx) return PG_ERR_INVALID;
     PG_CHECK(ctx, n >= 2 && k >= 1 && m >= 0 && Y, "covariates: bad shape n=%d m=%d k=%d", n, m, k);
     PG_CHECK(ctx, m == 0 || Cmat, "covariates: C is null with m=%d", m);
+    // every route to a fit passes here (pg_kinship_set's fast exits included): n - P residual degrees of freedom (gwas/ols.rs:103)
+    if (m + 2 >= n)
+        return pg_fail(ctx, PG_ERR_UNSUPPORTED,
+                       "n_eigenvecs = %d leaves no residual degrees of freedom with n = %d pools (reference regime n - P <= 0, "
+                       "gwas/ols.rs:103); lower --xxt-eigen-variance-explained or add pools", m, n);
     for (int i = 0; i < n * k; ++i)
         PG_CHECK(ctx, !std::isnan(Y[i]), "covariates: phenotype matrix contains NaN; remove pools "
                                            "with missing phenotypes first (gwas/ols.rs:287)");
