@@ -23,7 +23,13 @@ int main(int argc, char **argv) {
     try {
         if (argc < 2) return 2;
         const std::string mode = argv[1];
-        if (mode == "fmt") {
+        if (mode == "num") { // hostcheck num <f64|u64|i64> <text>: the strict parsers of the flag values and the phenotype file
+            const std::string kind = argv[2], text = argc > 3 ? argv[3] : "";
+            double d; uint64_t u; int64_t i;
+            if (kind == "f64") { if (parse_f64_strict(text, d)) std::cout << "ok " << rust_display(d) << "\n"; else std::cout << "reject\n"; }
+            else if (kind == "u64") { if (parse_u64_strict(text, u)) std::cout << "ok " << u << "\n"; else std::cout << "reject\n"; }
+            else { if (parse_i64_strict(text, i)) std::cout << "ok " << i << "\n"; else std::cout << "reject\n"; }
+        } else if (mode == "fmt") {
             std::string line;
             while (std::getline(std::cin, line)) {
                 char *end; const double x = std::strtod(line.c_str(), &end); const int nd = std::atoi(end);

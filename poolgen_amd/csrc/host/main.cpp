@@ -74,7 +74,10 @@ static const char *USAGE =
     "poolgen <analysis> -f <input> -p <phenotypes.csv> [flags]      (MI355X build of the per-locus regression path)\n"
     "analyses: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship,\n"
     "          genomic_prediction_cross_validation, fst, heterozygosity\n"
-    "  -f, --fname <file>                 *.sync, or *.pileup / *.mpileup (converted in memory)\n"
+    "  -f, --fname <file>                 *.sync, or *.pileup / *.mpileup (converted in memory: exactly what pileup2sync followed by the\n"
+    "                                     analysis on its sync file gives -- including the reference's column quirk: pileup2sync\n"
+    "                                     writes A:T:C:G:DEL:N, the sync reader labels the columns A,T,C,G,N,DEL, so on pileup-derived\n"
+    "                                     counts the default N removal drops the DELETION column and --keep-ns keeps it)\n"
     "  -p, --phen-fname <file>            delimited file: pool name, pool size, trait value(s)\n"
     "  -o, --output <file>                must not exist; default: derived from the input name and the time\n"
     "      --phen-delim <,>  --phen-name-col <0>  --phen-pool-size-col <1>  --phen-value-col <2[,3..]>\n"

@@ -31,7 +31,9 @@ def fixture(oracle):
     return rows, Y
 
 
-def compare_csv(got, want, float_cols, max_noise_rows):
+def compare_csv(got, want, float_cols, max_noise_rows, exempt=None):
+    """exempt: set of (chromosome, position) whose rows may differ numerically (their text fields must still agree): the
+    loci the caller has shown to be rank-deficient, where the reference prints rounding noise.  Every other row must agree."""
     g, w = got.splitlines(), want.splitlines()
     assert len(g) == len(w), (len(g), len(w))
     assert g[0] == w[0]
@@ -51,6 +53,8 @@ def compare_csv(got, want, float_cols, max_noise_rows):
                     same = False
             else:
                 assert x == y, (a, b)
+        if not same and exempt is not None and (fa[0], int(fa[1])) not in exempt:
+            raise AssertionError(f"row of a full-rank locus differs: {a} | {b}")
         noisy += 0 if same else 1
         if not same:
             print("DIFF", a, "|", b)
@@ -58,18 +62,44 @@ def compare_csv(got, want, float_cols, max_noise_rows):
     return noisy
 
 
-@pytest.mark.parametrize("extra", [[], ["--min-coverage-depth", "10", "--min-allele-frequency", "0.01"]])
-def test_cli_ols_iter(oracle, tmp_path, extra):
+def rank_deficient_loci(oracle, rows, f):
+    """(chromosome, position) of the loci whose ols_iter design [1 | sorted frequencies without the major allele] is numerically
+    rank deficient (cond > 1e7, i.e. cond(X'X) > 1e14: duplicated pools / alleles at n = 5): there, and only there, the
+    reference's LU prints rounding noise and only the emission pattern can be compared."""
+    bad = set()
+    for c, p, cnt in rows:
+        res = oracle.filter_locus(cnt, PS, f)
+        if res is None:
+            continue
+        ids, fc = res
+        fr, ids = oracle.sort_by_allele_freq(oracle.to_frequencies(fc), ids, True)
+        X = np.ones_like(fr); X[:, 1:] = fr[:, 1:]
+        if not np.all(np.isfinite(X)) or np.linalg.cond(X) > 1e7:
+            bad.add((c, int(p)))
+    return bad
+
+
+@pytest.mark.parametrize("extra,pieces", [([], None), (["--min-coverage-depth", "10", "--min-allele-frequency", "0.01"], None),
+                                          ([], "30000")])
+def test_cli_ols_iter(oracle, tmp_path, extra, pieces):
+    import os
     rows, Y = fixture(oracle)
     out = tmp_path / "o.csv"
-    r = run_cli("ols_iter", "-f", GOLD / "test.sync", "-p", GOLD / "test.csv", "--phen-delim", ",", "--phen-name-col", 0,
-                "--phen-value-col", "2,3", "--n-threads", 2, "-o", out, *extra)
+    env = dict(os.environ, PGH_STREAM_CHUNK_BYTES=pieces) if pieces else None   # small pieces: boundaries under the same zero budget
+    r = subprocess.run([str(CLI), "ols_iter", "-f", str(GOLD / "test.sync"), "-p", str(GOLD / "test.csv"), "--phen-delim", ",",
+                        "--phen-name-col", "0", "--phen-value-col", "2,3", "--n-threads", "2", "-o", str(out), *extra],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
     assert r.stdout.strip().endswith(str(out))
     f = oracle.filt(True, 10, 0.01, 0.0) if extra else oracle.filt()
     want = "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n" + "".join(
         oracle.ols_iterate_csv(c, p, cnt, Y, PS, f) or "" for c, p, cnt in rows)
-    # rank-deficient loci print rounding noise in the reference (tests/test_gpu_locus_ops.py): <1 % of rows
-    compare_csv(out.read_text(), want, {3: 1.0000001e-8, 5: 1.0000001e-6, 6: 1e-10}, max_noise_rows=want.count("\n") // 100)
+    # rows may differ numerically ONLY at loci the oracle's own design matrix shows to be rank deficient; everywhere else: zero
+    exempt = rank_deficient_loci(oracle, rows, f)
+    noisy = compare_csv(out.read_text(), want, {3: 1.0000001e-8, 5: 1.0000001e-6, 6: 1e-10}, max_noise_rows=len(want.splitlines()),
+                        exempt=exempt)
+    print(f"ols_iter CSV: {noisy} rows differ numerically, all at the {len(exempt)} rank-deficient loci of {len(rows)}")
+    assert len(exempt) < len(rows) // 20
     run_cli("ols_iter", "-f", GOLD / "test.sync", "-p", GOLD / "test.csv", "--phen-value-col", "2,3", "-o", out, ok=False)  # create_new
 
 
@@ -154,6 +184,11 @@ def test_cli_default_output_name_and_errors(tmp_path):
     assert name.startswith(str(tmp_path / "my.data-")) and name.endswith("-chisq_test.csv") and Path(name).exists()
     assert run_cli("ridge_iter", "-f", GOLD / "test.sync", "-p", GOLD / "test.csv", ok=False).stderr.count("Invalid analysis")
     assert run_cli("chisq_test", "-f", GOLD / "test.sync", "-p", GOLD / "test.csv", "--min-allele-frequency", "1.5", ok=False).returncode == 1
+    # flag values are read like Rust's parse::<usize / f64>(): no trailing garbage, no negative unsigned, no hex floats
+    for flag, val in (("--n-threads", "2x"), ("--min-coverage-depth", "-1"), ("--min-allele-frequency", "0x0.1"), ("--phen-value-col", "2,three"),
+                      ("--n-threads", "0")):
+        r = run_cli("chisq_test", "-f", GOLD / "test.sync", "-p", GOLD / "test.csv", flag, val, "-o", tmp_path / "bad.csv", ok=False)
+        assert r.returncode == 1 and val in r.stderr and not (tmp_path / "bad.csv").exists(), (flag, val, r.stderr)
 
 
 def test_pileup_input_equals_pileup2sync_then_analysis(tmp_path):
@@ -172,9 +207,14 @@ def test_pileup_input_equals_pileup2sync_then_analysis(tmp_path):
     subprocess.run([str(exe), "pileup2sync", "-f", str(pile), "-p", str(phen), "-o", str(sync), "--n-threads", "3"], check=True,
                    capture_output=True)
     assert sync.read_text().count("\n") > 300
-    for analysis, extra in (("ols_iter", ["--phen-value-col", "2,3"]), ("chisq_test", []),
+    # --keep-ns included: pileup2sync writes its six counts in the order A:T:C:G:D:N (pileup.rs:184) and the sync reader labels
+    # columns A,T,C,G,N,D (sync.rs:134), so on a converted file "remove Ns" drops the DELETION counts and keeps the Ns -- the
+    # reference's two-step behaviour, which the in-memory path must reproduce with and without the flag
+    for analysis, extra in (("ols_iter", ["--phen-value-col", "2,3"]), ("chisq_test", []), ("chisq_test", ["--keep-ns"]),
+                            ("ols_iter", ["--phen-value-col", "2", "--keep-ns"]),
                             ("ols_iter_with_kinship", ["--phen-value-col", "2", "-x", "0.5"])):
-        a, b = tmp_path / f"{analysis}_sync.csv", tmp_path / f"{analysis}_pileup.csv"
+        tag = analysis + ("_ns" if "--keep-ns" in extra else "")
+        a, b = tmp_path / f"{tag}_sync.csv", tmp_path / f"{tag}_pileup.csv"
         for src, dst in ((sync, a), (pile, b)):
             r = subprocess.run([str(exe), analysis, "-f", str(src), "-p", str(phen), "-o", str(dst), "--n-threads", "2", *extra],
                                capture_output=True, text=True)

@@ -118,3 +118,20 @@ def test_sync_parser_16_bit_counts(tmp_path):
         a = run("parse", p, threads).splitlines()
         b = run("parse", p, threads, 16).splitlines()
         assert b[0] == a[0] + " 32" and b[1:] == a[1:]
+
+
+def test_numbers_are_read_like_rust_parse():
+    """Flag values and phenotype numbers: what Rust's `str::parse::<f64 / usize>()` accepts (main.rs flag types, phen.rs:60-78)
+    and nothing else -- strtod / stoi took hex floats, trailing garbage ("2x" -> 2) and wrapped negatives."""
+    run("fmt", stdin="")
+    ok = {("f64", "1.5"): "1.5", ("f64", "-2"): "-2", ("f64", "1e3"): "1000", ("f64", ".5"): "0.5", ("f64", "5."): "5",
+          ("f64", "+0.25"): "0.25", ("f64", "inf"): "inf", ("f64", "-Infinity"): "-inf", ("f64", "NaN"): "NaN", ("f64", "1E-2"): "0.01",
+          ("u64", "0"): "0", ("u64", "+17"): "17", ("u64", "18446744073709551615"): "18446744073709551615",
+          ("i64", "-5"): "-5", ("i64", "42"): "42"}
+    for (kind, text), want in ok.items():
+        assert run("num", kind, text).strip() == "ok " + want, (kind, text)
+    bad = [("f64", ""), ("f64", "0x10"), ("f64", "0x1p3"), ("f64", "1.5x"), ("f64", " 1"), ("f64", "1 "), ("f64", "e5"), ("f64", "."),
+           ("f64", "1e"), ("f64", "--1"), ("f64", "infin"), ("u64", "-1"), ("u64", "2x"), ("u64", "1e3"), ("u64", ""), ("u64", "1.0"),
+           ("u64", "18446744073709551616"), ("i64", "9223372036854775808"), ("i64", "-+1"), ("i64", "3 ")]
+    for kind, text in bad:
+        assert run("num", kind, text).strip() == "reject", (kind, text)
