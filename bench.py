@@ -216,9 +216,14 @@ def main():
         traffic_note = ("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command "
                         "(counters cannot be read from inside the process); file profiles/pmc_traffic.json, see its 'source'")
         tiles = (n + 15) // 16
-        # MFMA work the kernel EXECUTES: 16x16x4 tiles of the upper triangle (n <= 208) incl. padding to a multiple of 16
-        # and the lower halves of the diagonal tiles; USEFUL = the n (n + 1) / 2 distinct products of the triangle
-        kin_exec_flops = (tiles * (tiles + 1) // 2 if tiles <= 13 else tiles * tiles) * 512.0 * p_local
+        # MFMA work the kernel EXECUTES (upper triangle, padding and the redundant parts of the diagonal tiles included);
+        # USEFUL = the n (n + 1) / 2 distinct products of the triangle
+        if tiles == 13:
+            # the 13-tile kernel: 66 (n <= 200) or 78 full off-diagonal 16x16x4 tiles + 13 diagonal tiles as 3 instructions of four
+            # 4x4x4 blocks + (n <= 200) 12 last-column tiles as 2 such instructions; 512 / 128 flop per locus per 16x16 tile / 4-block instruction
+            kin_exec_flops = ((66 if n <= 200 else 78) * 512.0 + 13 * 3 * 128.0 + (12 * 2 * 128.0 if n <= 200 else 0.0)) * p_local
+        else:
+            kin_exec_flops = (tiles * (tiles + 1) // 2 if tiles <= 13 else tiles * tiles) * 512.0 * p_local
         kin_useful_flops = float(n) * (n + 1) * p_local
         per_s = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = {"kernel": "k_kinship_syrk", "bound": "mfma",

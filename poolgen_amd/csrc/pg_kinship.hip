@@ -49,6 +49,15 @@ __device__ __forceinline__ double dpp_add(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
     return v + __hiloint2double(hi, lo);
 }
+// value of lane ((l & 15) + N) % 16 of the same 16-lane row (row_ror:(16 - N) moves data towards higher lanes by 16 - N)
+template <int N>
+__device__ __forceinline__ double row_from_plus(double v) {
+    static_assert(N >= 1 && N <= 15, "row rotation");
+    constexpr int CTRL = 0x120 + (16 - N); // row_ror:(16 - N)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 // ---- compile-time helpers ------------------------------------------------------------------------
 template <int... I, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
@@ -82,10 +91,12 @@ constexpr int KIN13_T[16][6][2] = {
     {{6, 9}, {6, 10}, {6, 11}, {7, 9}, {7, 10}, {7, 11}},
     {{2, 4}, {2, 11}, {2, 12}, {4, 12}, {11, 12}, {12, 12}},
     {{2, 5}, {2, 6}, {2, 7}, {5, 6}, {5, 7}, {-1, -1}},
-    {{1, 12}, {5, 8}, {5, 11}, {8, 11}, {8, 12}, {-1, -1}},
+    // (rows 12, 13, 15 in this order so that the four waves of a SIMD -- w, w + 4, w + 8, w + 12 -- carry nearly equal matrix time
+    //  once the narrow tiles run on 4 x 4 x 4 blocks: 1339 / 1369 / 1357 / 1334 cycles per 4 loci)
     {{0, 12}, {2, 3}, {3, 12}, {6, 12}, {7, 12}, {-1, -1}},
-    {{2, 8}, {2, 9}, {2, 10}, {8, 9}, {8, 10}, {-1, -1}},
     {{5, 9}, {5, 10}, {5, 12}, {9, 12}, {10, 12}, {-1, -1}},
+    {{2, 8}, {2, 9}, {2, 10}, {8, 9}, {8, 10}, {-1, -1}},
+    {{1, 12}, {5, 8}, {5, 11}, {8, 11}, {8, 12}, {-1, -1}},
 };
 constexpr int kin13_ntiles(int w) { int c = 0; for (int u = 0; u < 6; ++u) c += KIN13_T[w][u][0] >= 0; return c; }
 // distinct tile columns of wave w, in order of first use; kin13_col(w, i) = -1 past the end
@@ -104,6 +115,8 @@ constexpr int kin13_col(int w, int idx) {
 constexpr int kin13_ncols(int w) { int c = 0; while (c < 12 && kin13_col(w, c) >= 0) ++c; return c; }
 constexpr int kin13_slot(int w, int col) { int i = 0; while (kin13_col(w, i) != col) ++i; return i; } // fragment register of a column
 constexpr int KIN13_MAXC = 6;
+constexpr int kin13_ndiag(int w) { int c = 0; for (int u = 0; u < 6; ++u) c += (KIN13_T[w][u][0] >= 0 && KIN13_T[w][u][0] == KIN13_T[w][u][1]); return c; }
+constexpr int kin13_diag_index(int w, int u) { int c = 0; for (int v = 0; v < u; ++v) c += (KIN13_T[w][v][0] >= 0 && KIN13_T[w][v][0] == KIN13_T[w][v][1]); return c; }
 
 struct KinParams {
     const double *G;
@@ -123,7 +136,18 @@ struct KinParams {
     int k;
 };
 
-template <bool FUSE, bool SPEC13>
+// SMALL (13-tile shape only): the tiles that are not full 16 x 16 blocks of useful products run on v_mfma_f64_4x4x4_4b_f64
+// (four independent 4 x 4 x 4 blocks per instruction, a quarter of the matrix-pipe time of a 16 x 16 x 4):
+//   * the 13 diagonal tiles need their upper triangle only: 3 instructions (the block diagonals d = 0, 1, 2 of the 4 x 4 grid of
+//     4 x 4 blocks; the wrapped block of d = 1 is the transpose of the one block d = 3 would add) instead of 4 instructions' worth;
+//   * with n <= 200 pools tile column 12 holds at most 8 pools: 2 instructions (4 row blocks x one 4-pool column block each)
+//     per tile instead of 4.
+// Lane layout of the instruction (probed on the device, tools/probe_mfma4.hip): A[blk][i][k] in lane 16 k + 4 blk + i,
+// B[blk][k][j] in lane 16 k + 4 blk + j, D[blk][i][j] in lane 16 i + 4 blk + j -- so the 16 x 16 fragment of tile column c
+// (lane: pool = lane & 15, locus = lane >> 4) IS the A operand whose four blocks are the four 4-pool groups of that column,
+// a B operand "column group (blk + d) % 4" is the same register rotated by 4 d lanes inside its 16-lane row (DPP, no LDS), and
+// only the 8-pool strip needs reads of its own.  200 pools: 5 200 instead of 5 824 matrix cycles per 4 loci.
+template <bool FUSE, bool SPEC13, int SMALL = 0> // SMALL bits: 1 = diagonal tiles on 4 x 4 blocks, 2 = 8-pool last column (n <= 200) on 4 x 4 blocks
 __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -366,19 +390,55 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
             static_assert(NC <= KIN13_MAXC && KS % 2 == 0, "fragment sets alternate with the k-step parity");
             double fr[2][KIN13_MAXC];
             const double *lb = lds + kq * ldsld + fi;
+            // which of this wave's tiles are strip tiles (r, 12), r < 12
+            constexpr bool has_strip = [] { bool h = false; for (int u = 0; u < 6; ++u) h = h || (KIN13_T[W][u][0] >= 0 && KIN13_T[W][u][0] < 12 && KIN13_T[W][u][1] == 12); return h; }();
+            double bs[2][2];                          // strip B operands: pools 192 + 4 c + (lane & 3), c = 0, 1
+            const double *lbs = lds + kq * ldsld + 192 + (lane & 3);
+            // diagonal tiles: the B operands of the block diagonals d = 1, 2 = the tile's fragment rotated by 4 d lanes inside its
+            // 16-lane row.  Read from LDS at the rotated address (a DPP rotation is VALU work on the port the MFMAs issue from:
+            // measured, it ate the saving)
+            constexpr int ND = (SMALL & 1) ? kin13_ndiag(W) : 0;
+            double bd[2][ND > 0 ? ND : 1][2];
+            const double *lbr1 = lds + kq * ldsld + ((fi + 4) & 15), *lbr2 = lds + kq * ldsld + ((fi + 8) & 15);
             auto load_set = [&](const double *bufbase, auto sc, auto pc) __attribute__((always_inline)) {
                 constexpr int s2 = decltype(sc)::value, par = decltype(pc)::value;
                 static_for<NC>([&](auto cc) __attribute__((always_inline)) {
                     constexpr int ci = decltype(cc)::value;
                     fr[par][ci] = bufbase[4 * s2 * 208 + 16 * kin13_col(W, ci)];
                 });
+                if constexpr ((SMALL & 2) != 0 && has_strip) {
+                    const double *bb = lbs + (bufbase - lb);
+                    bs[par][0] = bb[4 * s2 * 208];
+                    bs[par][1] = bb[4 * s2 * 208 + 4];
+                }
+                if constexpr (ND > 0) {
+                    static_for<NT>([&](auto uc) __attribute__((always_inline)) {
+                        constexpr int u = decltype(uc)::value;
+                        if constexpr (KIN13_T[W][u][0] == KIN13_T[W][u][1]) {
+                            constexpr int di = kin13_diag_index(W, u);
+                            bd[par][di][0] = (lbr1 + (bufbase - lb))[4 * s2 * 208 + 16 * KIN13_T[W][u][0]];
+                            bd[par][di][1] = (lbr2 + (bufbase - lb))[4 * s2 * 208 + 16 * KIN13_T[W][u][0]];
+                        }
+                    });
+                }
             };
             auto mfma_set = [&](auto pc) __attribute__((always_inline)) {
                 constexpr int par = decltype(pc)::value;
                 static_for<NT>([&](auto uc) __attribute__((always_inline)) {
                     constexpr int u = decltype(uc)::value;
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[par][kin13_slot(W, KIN13_T[W][u][0])],
-                                                                   fr[par][kin13_slot(W, KIN13_T[W][u][1])], acc[u], 0, 0, 0);
+                    constexpr int ti = KIN13_T[W][u][0], tj = KIN13_T[W][u][1];
+                    const double fa = fr[par][kin13_slot(W, ti)];
+                    if constexpr ((SMALL & 1) != 0 && ti == tj) {
+                        // diagonal tile: block diagonals d = 0, 1, 2 of its 4 x 4 grid of 4 x 4 blocks
+                        acc[u][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, fa, acc[u][0], 0, 0, 0);
+                        acc[u][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, bd[par][kin13_diag_index(W, u)][0], acc[u][1], 0, 0, 0);
+                        acc[u][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, bd[par][kin13_diag_index(W, u)][1], acc[u][2], 0, 0, 0);
+                    } else if constexpr ((SMALL & 2) != 0 && tj == 12 && ti != tj) {
+                        acc[u][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, bs[par][0], acc[u][0], 0, 0, 0);
+                        acc[u][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa, bs[par][1], acc[u][1], 0, 0, 0);
+                    } else {
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fr[par][kin13_slot(W, tj)], acc[u], 0, 0, 0);
+                    }
                 });
             };
             if (nstages > 0) load_set(lb, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -405,9 +465,23 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
             double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
             static_for<NT>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
-                constexpr int r0 = 16 * KIN13_T[W][u][0], c0 = 16 * KIN13_T[W][u][1];
+                constexpr int ti = KIN13_T[W][u][0], tj = KIN13_T[W][u][1];
+                constexpr int r0 = 16 * ti, c0 = 16 * tj;
+                // 4 x 4 blocks: this lane holds D[blk][i][j] with i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3
+                const int bi = lane >> 4, bb = (lane >> 2) & 3, bj = lane & 3;
+                if constexpr ((SMALL & 1) != 0 && ti == tj) {
+                    // d = 0: block (bb, bb); d = 1: (bb, bb + 1), the wrapped (3, 0) stored as its transpose (0, 3); d = 2: (0, 2), (1, 3)
+                    slab[(size_t)(r0 + 4 * bb + bi) * P.npad + c0 + 4 * bb + bj] = acc[u][0];
+                    if (bb < 3) slab[(size_t)(r0 + 4 * bb + bi) * P.npad + c0 + 4 * (bb + 1) + bj] = acc[u][1];
+                    else slab[(size_t)(r0 + bj) * P.npad + c0 + 12 + bi] = acc[u][1];
+                    if (bb < 2) slab[(size_t)(r0 + 4 * bb + bi) * P.npad + c0 + 4 * (bb + 2) + bj] = acc[u][2];
+                } else if constexpr ((SMALL & 2) != 0 && tj == 12 && ti != tj) {
+                    slab[(size_t)(r0 + 4 * bb + bi) * P.npad + c0 + bj] = acc[u][0];
+                    slab[(size_t)(r0 + 4 * bb + bi) * P.npad + c0 + 4 + bj] = acc[u][1];
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(size_t)(r0 + kq + 4 * r) * P.npad + c0 + fi] = acc[u][r];
+                    for (int r = 0; r < 4; ++r) slab[(size_t)(r0 + kq + 4 * r) * P.npad + c0 + fi] = acc[u][r];
+                }
             });
             return;
         }
@@ -627,8 +701,26 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     };
     pg_prof_begin(ctx, kid);
     hipError_t le;
-    if (fuse) le = spec13 ? launch(k_kinship_syrk<true, true>) : launch(k_kinship_syrk<true, false>);
-    else le = spec13 ? launch(k_kinship_syrk<false, true>) : launch(k_kinship_syrk<false, false>);
+    // 4 x 4 x 4 blocks for the narrow tiles of the 13-tile shape (see k_kinship_syrk): the diagonal tiles (bit 1) and the last
+    // column when it holds <= 8 pools (bit 2).  Measured at 200 pools x 10 M loci (tools/bench_kin_ab.py, one box, ms):
+    //   bits          0      1      2      3
+    //   fused sums   7.62   7.59   7.31   7.23     (bit 1 costs the fused kernel 19 spilled registers and still pays)
+    //   plain        6.84   6.80   6.41   6.30
+    // POOLGEN_KIN_SMALL=<bits> overrides (A/B timing).
+    int sm = !spec13 ? 0 : ((n <= 200 ? 2 : 0) | 1);
+    if (const char *e = std::getenv("POOLGEN_KIN_SMALL")) sm = spec13 ? (std::atoi(e) & (n <= 200 ? 3 : 1)) : 0;
+    if (std::getenv("POOLGEN_KIN_NO_SMALL")) sm = 0;
+    auto pick = [&](auto fz) -> hipError_t {
+        constexpr bool FZ = decltype(fz)::value;
+        if (!spec13) return launch(k_kinship_syrk<FZ, false>);
+        switch (sm) {
+        case 1: return launch(k_kinship_syrk<FZ, true, 1>);
+        case 2: return launch(k_kinship_syrk<FZ, true, 2>);
+        case 3: return launch(k_kinship_syrk<FZ, true, 3>);
+        default: return launch(k_kinship_syrk<FZ, true, 0>);
+        }
+    };
+    le = fuse ? pick(std::true_type{}) : pick(std::false_type{});
     PG_HIP(ctx, le);
     pg_prof_end(ctx);
     if (fuse) {
