@@ -329,9 +329,10 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep(
 
 // ---- the sweep on a per-ROW chunk grid (round 1's form: no super-rows, no prefetch; rows that start 64 bytes into a line make
 // it touch 1.14x the algorithmic bytes).  It stays in the product for WIDE designs: measured on 200 pools x 10 M loci with m = 8
-// covariates (12 columns) 3.15 ms against 3.85 ms for the super-row kernel above (whose staging registers, prefetch and
+// covariates (12 columns) 3.15 ms against 3.6-3.9 ms for the super-row kernel above (whose staging registers, prefetch and
 // mid-chunk locus boundaries cost more than the over-fetch once 14 fp64 operations per pool keep the vector unit busy), while
-// for the narrow designs (m = 0: 2 columns) the super-row kernel is ahead and moves exactly the algorithmic bytes.
+// up to 8 columns (m = 0, 2, 4, 6 with one trait: 2.70 / 2.88 / 2.93 / 2.93 ms against 2.72 / 2.95 / 2.95 / 2.97) the super-row
+// kernel is ahead and moves exactly the algorithmic bytes.
 // launch_sweep picks by column count; POOLGEN_SWEEP_V1=1 / POOLGEN_SWEEP_V2=1 force one of them (A/B timing).
 template <int C>
 __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep_rows(
@@ -634,7 +635,7 @@ struct SweepArgs {
 template <int C>
 int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
     const size_t shmem = (size_t)SW_WAVES * SW_TILE * sizeof(double);
-    const bool rows_kernel = std::getenv("POOLGEN_SWEEP_V1") || (C >= 6 && !std::getenv("POOLGEN_SWEEP_V2"));
+    const bool rows_kernel = std::getenv("POOLGEN_SWEEP_V1") || (C >= 12 && !std::getenv("POOLGEN_SWEEP_V2"));
     if (rows_kernel) {
         SweepDims D1 = A.D;
         D1.ntiles = (A.D.p + 63) / 64;
