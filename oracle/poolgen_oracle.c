@@ -769,7 +769,38 @@ int orc_n_eigenvecs_rule(const double *ev, int n, double threshold) {
     return m;
 }
 
-/* kinship = G G^T / p (ols.rs:291-295).  G locus-major (p x n, ld). */
+/* kinship = G G^T / p (ols.rs:291-295).  G locus-major (p x n, ld).
+ * The reference hands this product to BLAS (ndarray `dot` -> MKL dgemm), so the restatement should not be a scalar loop when it
+ * serves as the CPU baseline: loci are taken in blocks of 8 (one rank-8 update of the upper triangle per block: every K row is
+ * loaded and stored once per 8 loci instead of once per locus), the inner loop over j is vectorised (omp simd; AVX2 / AVX-512
+ * clones chosen at load time), threads own disjoint locus ranges and their partial sums are added in thread order.  Each entry is
+ * still a plain sum of products over the loci -- only the association order differs from a sequential loop (1e-16 relative). */
+#if defined(__GNUC__) && defined(__x86_64__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+static void kinship_block8(const double *G, int64_t l0, int64_t l1, int n, int64_t ld, double *kp) {
+    int64_t l = l0;
+    for (; l + 8 <= l1; l += 8) {
+        const double *g0 = G + l * ld, *g1 = g0 + ld, *g2 = g1 + ld, *g3 = g2 + ld, *g4 = g3 + ld, *g5 = g4 + ld, *g6 = g5 + ld, *g7 = g6 + ld;
+        for (int i = 0; i < n; i++) {
+            const double a0 = g0[i], a1 = g1[i], a2 = g2[i], a3 = g3[i], a4 = g4[i], a5 = g5[i], a6 = g6[i], a7 = g7[i];
+            double *row = kp + (size_t)i * n;
+#pragma omp simd
+            for (int j = i; j < n; j++)
+                row[j] += ((a0 * g0[j] + a1 * g1[j]) + (a2 * g2[j] + a3 * g3[j])) + ((a4 * g4[j] + a5 * g5[j]) + (a6 * g6[j] + a7 * g7[j]));
+        }
+    }
+    for (; l < l1; l++) {
+        const double *g = G + l * ld;
+        for (int i = 0; i < n; i++) {
+            const double gi = g[i];
+            double *row = kp + (size_t)i * n;
+#pragma omp simd
+            for (int j = i; j < n; j++) row[j] += gi * g[j];
+        }
+    }
+}
+
 void orc_kinship(const double *G, int64_t p, int n, int64_t ld, double *K, int n_threads) {
     int nt = 1;
 #ifdef _OPENMP
@@ -779,26 +810,21 @@ void orc_kinship(const double *G, int64_t p, int n, int64_t ld, double *K, int n
     double *part = (double *)calloc((size_t)nt * n * n, sizeof(double));
 #pragma omp parallel num_threads(nt)
     {
-        int tid = 0;
+        int tid = 0, nth = 1;
 #ifdef _OPENMP
         tid = omp_get_thread_num();
+        nth = omp_get_num_threads();
 #endif
-        double *kp = part + (size_t)tid * n * n;
-#pragma omp for schedule(static)
-        for (int64_t l = 0; l < p; l++) {
-            const double *g = G + l * ld;
-            for (int i = 0; i < n; i++) {
-                double gi = g[i];
-                double *row = kp + (size_t)i * n;
-                for (int j = 0; j < n; j++) row[j] += gi * g[j];
-            }
+        const int64_t l0 = p * tid / nth, l1 = p * (tid + 1) / nth;
+        kinship_block8(G, l0, l1, n, ld, part + (size_t)tid * n * n);
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) {
+            double s = 0.0;
+            for (int t = 0; t < nt; t++) s += part[(size_t)t * n * n + (size_t)i * n + j];
+            K[(size_t)i * n + j] = s / (double)p;
+            K[(size_t)j * n + i] = s / (double)p;
         }
-    }
-    for (int i = 0; i < n * n; i++) {
-        double s = 0.0;
-        for (int t = 0; t < nt; t++) s += part[(size_t)t * n * n + i];
-        K[i] = s / (double)p;
-    }
     free(part);
 }
 

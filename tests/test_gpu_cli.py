@@ -161,6 +161,11 @@ def test_cli_ols_iter_with_kinship(oracle, exact, tmp_path, thr, keep1):
         assert ex["m"] == ref["m"]
         nanpat = np.isnan(ref["beta"])
         ref = dict(m=ex["m"], beta=np.where(nanpat, np.nan, ex["beta"]), pval=np.where(nanpat, np.nan, formula_p(oracle, ex, G.shape[1])))
+    # Rows may differ ONLY for columns that are (numerically) constant over the 5 pools: there the reference's LU happens to hit an
+    # exact zero pivot (NaN) or not (rounding noise) depending on the residue, while the product flags s_gg <= 1e-12 g'g as NaN
+    # always.  The exemption is computed from the column itself; every other row must agree.
+    gc = G - G.mean(axis=1, keepdims=True)
+    flat = (gc * gc).sum(axis=1) <= 1e-10 * (G * G).sum(axis=1)
     bad = 0
     for j in range(2):
         for i in range(len(cols)):
@@ -170,10 +175,12 @@ def test_cli_ols_iter_with_kinship(oracle, exact, tmp_path, thr, keep1):
             rb, rp = ref["beta"][i, j], ref["pval"][i, j]
             okb = (np.isnan(b) and np.isnan(rb)) or abs(b - rb) <= tol * max(1.0, abs(rb))
             okp = (np.isnan(p) and np.isnan(rp)) or abs(p - rp) <= tol
-            bad += 0 if (okb and okp) else 1
-    # n = 5 pools: columns constant over pools are exactly singular in the reference only when the
-    # rounding residue happens to vanish; the product flags all of them as NaN
-    assert bad <= len(cols) // 50, bad
+            if not (okb and okp):
+                assert flat[i], f"row of a non-constant column differs: {lines[1 + j * len(cols) + i]} | oracle {rb} {rp}"
+                assert np.isnan(b) and np.isnan(p)          # ... and on a constant column the product's answer is NaN, never noise
+                bad += 1
+    print(f"kinship CSV: {bad} rows NaN here / noise in the reference, all on the {int(flat.sum())} constant columns of {len(cols)}")
+    assert flat.sum() < len(cols) // 10
 
 
 def test_cli_default_output_name_and_errors(tmp_path):
