@@ -119,6 +119,17 @@ int pg_ols_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, c
                    int k, double var_explained, int force_m, int *m_out, double *K_out,
                    double *beta, double *var, double *pval);
 
+/* mle_iter_with_kinship == gwas::mle_with_covariate (gwas/mle.rs:307-463): the same kinship preamble (:317-343), then per
+ * (column, trait) a Nelder-Mead maximum-likelihood fit of y ~ [1 | C | g] on (logit-bounded sigma^2, b) (mle.rs:13-30, :84-115;
+ * argmin 0.8, start simplex of base/helpers.rs:132-146, <= 1000 iterations), ve = sigma^2, v_b = ve [(X'X)^-1]_last,
+ * t = b / v_b as written (:175), p = 2 (1 - T_{n-1}(|t|)).  PARITY UNPINNED: the reference has no test of this path and the
+ * solver's source is not in its tree; the published algorithm is restated (here and, literally, in the oracle) and the two
+ * agree at the solver's resolution (~1e-6), not at 1e-10.  At most 2 kinship covariates (4 design columns), k <= 4 traits.
+ * beta/var/pval: p x k on the device. */
+int pg_mle_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y, int k,
+                       double var_explained, int force_m, int *m_out, double *K_out, double *beta_dev, double *var_dev,
+                       double *pval_dev);
+
 /* ---------------------------------------------------------------------------------------
  * Multi-GPU: loci shard over the GPUs of a node in contiguous slabs, one pg_ctx (= one GPU, one host thread or
  * process) per rank.  The reference's parallel axis is the same one -- a worker per file chunk (base/sync.rs:913-939)

@@ -889,6 +889,164 @@ int orc_ols_with_covariate(const double *G, int64_t p, int n, int64_t ld, const 
 }
 
 /* ======================================================================================
+ * gwas/mle.rs -- PARITY UNPINNED twice over: the reference has no test of it (`fn test_mle() {}`, mle.rs:470) and its numbers are
+ * wherever argmin 0.8's Nelder-Mead simplex stands after <= 1000 iterations -- a crate whose source is not under /root/reference
+ * (Cargo.toml:13 `argmin = "0.8.1"`, no lockfile).  What follows restates the PUBLISHED algorithm of that solver (Nelder & Mead 1965
+ * as argmin 0.8 words it: alpha 1, gamma 2, rho 0.5, sigma 0.5, termination when the sample standard deviation of the vertex costs
+ * drops below f64::EPSILON) around the reference's own cost function, start simplex and closing arithmetic, which ARE on disk.
+ * ====================================================================================== */
+/* bound_parameters_with_logit (base/helpers.rs:120-130) */
+static double mle_bound(double x, double lo, double hi) { return lo + ((hi - lo) / (1.00 + exp(-x))); }
+
+/* negative_likelihood_normal_distribution_sigma_and_beta (mle.rs:13-30), as written (note 1 / sigma2, not 1 / (2 sigma2)) */
+static double mle_cost(const double *par, const double *X, const double *y, int n, int P) {
+    const double sigma2 = mle_bound(par[0], ORC_EPS, 1e9);
+    double ss = 0.0;
+    for (int i = 0; i < n; i++) {
+        double xb = 0.0;
+        for (int c = 0; c < P; c++) xb = xb + X[i * P + c] * par[1 + c];
+        const double e = y[i] - xb;
+        ss = ss + e * e;
+    }
+    return ((double)n / 2.00) * log(2.00 * M_PI * sigma2) + (1.00 / sigma2) * ss;
+}
+
+/* Nelder-Mead on D parameters from the simplex of prepare_solver_neldermead(p = D, h = 1) (helpers.rs:132-146): D + 1 vertices,
+ * all ones, 1.5 on the diagonal.  best: the parameters of the lowest vertex when the run ends.  Returns the iterations done. */
+static int mle_nelder_mead(const double *X, const double *y, int n, int P, double *best) {
+    const int D = P + 1, V = D + 1;
+    double *sx = (double *)malloc(sizeof(double) * V * D), *cost = (double *)malloc(sizeof(double) * V);
+    double *x0 = (double *)malloc(sizeof(double) * D * 4), *xr = x0 + D, *xe = xr + D, *tmp = xe + D;
+    for (int i = 0; i < V; i++)
+        for (int j = 0; j < D; j++) sx[i * D + j] = (i == j) ? 1.5 : 1.0;
+    for (int i = 0; i < V; i++) cost[i] = mle_cost(&sx[i * D], X, y, n, P);
+#define NM_SORT()                                                                                               \
+    for (int a = 1; a < V; a++) { /* stable insertion sort by cost */                                           \
+        const double ca = cost[a];                                                                              \
+        memcpy(tmp, &sx[a * D], sizeof(double) * D);                                                            \
+        int b = a - 1;                                                                                          \
+        while (b >= 0 && cost[b] > ca) { cost[b + 1] = cost[b]; memcpy(&sx[(b + 1) * D], &sx[b * D], sizeof(double) * D); b--; } \
+        cost[b + 1] = ca;                                                                                       \
+        memcpy(&sx[(b + 1) * D], tmp, sizeof(double) * D);                                                      \
+    }
+    NM_SORT();
+    int it = 0;
+    for (; it < 1000; it++) { /* .configure(|state| state.max_iters(1_000)), mle.rs:98 */
+        double mean = 0.0, sd = 0.0;
+        for (int i = 0; i < V; i++) mean += cost[i];
+        mean /= (double)V;
+        for (int i = 0; i < V; i++) sd += (cost[i] - mean) * (cost[i] - mean);
+        sd = sqrt(sd / ((double)V - 1.0));
+        if (sd < ORC_EPS) break; /* sd_tolerance = EPSILON */
+        for (int j = 0; j < D; j++) { /* centroid of all vertices but the worst */
+            double c = sx[j];
+            for (int i = 1; i < V - 1; i++) c += sx[i * D + j];
+            x0[j] = c * (1.0 / ((double)V - 1.0));
+        }
+        const double *xw = &sx[(V - 1) * D];
+        for (int j = 0; j < D; j++) xr[j] = x0[j] + (x0[j] - xw[j]) * 1.0;
+        const double cr = mle_cost(xr, X, y, n, P);
+        if (cr < cost[V - 2] && cr >= cost[0]) {
+            memcpy(&sx[(V - 1) * D], xr, sizeof(double) * D); cost[V - 1] = cr;
+        } else if (cr < cost[0]) {
+            for (int j = 0; j < D; j++) xe[j] = x0[j] + (xr[j] - x0[j]) * 2.0;
+            const double ce = mle_cost(xe, X, y, n, P);
+            if (ce < cr) { memcpy(&sx[(V - 1) * D], xe, sizeof(double) * D); cost[V - 1] = ce; }
+            else { memcpy(&sx[(V - 1) * D], xr, sizeof(double) * D); cost[V - 1] = cr; }
+        } else {
+            for (int j = 0; j < D; j++) xe[j] = x0[j] + (xw[j] - x0[j]) * 0.5;
+            const double cc = mle_cost(xe, X, y, n, P);
+            if (cc < cost[V - 1]) { memcpy(&sx[(V - 1) * D], xe, sizeof(double) * D); cost[V - 1] = cc; }
+            else {
+                for (int i = 1; i < V; i++) {
+                    for (int j = 0; j < D; j++) sx[i * D + j] = sx[j] + (sx[i * D + j] - sx[j]) * 0.5;
+                    cost[i] = mle_cost(&sx[i * D], X, y, n, P);
+                }
+            }
+        }
+        NM_SORT();
+    }
+#undef NM_SORT
+    memcpy(best, sx, sizeof(double) * D);
+    free(sx); free(cost); free(x0);
+    return it;
+}
+
+/* estimate_effects / estimate_variances / estimate_significance of UnivariateMaximumLikelihoodEstimation (mle.rs:84-192), n >= p */
+int orc_mle_fit(const double *X, const double *y, int n, int P, double *b, double *v_b, double *t, double *pval) {
+    double *par = (double *)malloc(sizeof(double) * (P + 1));
+    mle_nelder_mead(X, y, n, P, par);
+    const double ve = mle_bound(par[0], ORC_EPS, 1e9); /* mle.rs:112 */
+    for (int c = 0; c < P; c++) b[c] = par[1 + c];
+    free(par);
+    double *xtx = (double *)malloc(sizeof(double) * P * P), *inv = (double *)malloc(sizeof(double) * P * P);
+    for (int r = 0; r < P; r++)
+        for (int c = 0; c < P; c++) {
+            double s = 0.0;
+            for (int i = 0; i < n; i++) s = s + X[i * P + r] * X[i * P + c];
+            xtx[r * P + c] = s;
+        }
+    int rc = 0;
+    if (orc_lu_inverse(xtx, P, inv) != 0 || orc_lu_det(inv, P) == 0.0) rc = -1; /* mle.rs:140-147 */
+    if (!rc)
+        for (int i = 0; i < P; i++) {
+            v_b[i] = ve * inv[i * P + i];
+            t[i] = b[i] / v_b[i]; /* as written (mle.rs:175): the variance, not its square root */
+            if (isinf(t[i])) pval[i] = 0.0;
+            else if (isnan(t[i])) pval[i] = 1.0;
+            else pval[i] = 2.00 * (1.00 - orc_students_t_cdf(fabs(t[i]), (double)n - 1.0));
+        }
+    free(xtx); free(inv);
+    return rc;
+}
+
+/* mle_with_covariate numeric core (mle.rs:307-400): the kinship preamble of ols_with_covariate, then one Nelder-Mead fit per cell */
+int orc_mle_with_covariate(const double *G, int64_t p, int n, int64_t ld, const double *Y, int k, double var_explained, int force_m,
+                           const double *covariate_in, double *beta, double *var, double *pval, int n_threads) {
+    int m;
+    double *C = NULL;
+    if (covariate_in && force_m >= 0) {
+        m = force_m;
+        C = (double *)malloc(sizeof(double) * n * (m > 0 ? m : 1));
+        memcpy(C, covariate_in, sizeof(double) * n * m);
+    } else {
+        double *K = (double *)malloc(sizeof(double) * n * n), *ev = (double *)malloc(sizeof(double) * n), *V = (double *)malloc(sizeof(double) * n * n);
+        orc_kinship(G, p, n, ld, K, n_threads);
+        orc_sym_eig(K, n, ev, V);
+        m = force_m >= 0 ? force_m : orc_n_eigenvecs_rule(ev, n, var_explained);
+        C = (double *)malloc(sizeof(double) * n * (m > 0 ? m : 1));
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < m; j++) C[i * m + j] = V[i * n + j];
+        free(K); free(ev); free(V);
+    }
+    const int P = m + 2;
+    int nt = 1;
+#ifdef _OPENMP
+    nt = n_threads > 0 ? n_threads : (omp_get_max_threads() < 8 ? omp_get_max_threads() : 8);
+#endif
+#pragma omp parallel num_threads(nt)
+    {
+        double *X = (double *)malloc(sizeof(double) * n * P), *y = (double *)malloc(sizeof(double) * n), *r = (double *)malloc(sizeof(double) * P * 4);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t i = 0; i < p; i++)
+            for (int j = 0; j < k; j++) {
+                for (int i_ = 0; i_ < n; i_++) {
+                    X[i_ * P] = 1.0;
+                    for (int j_ = 1; j_ < m + 1; j_++) X[i_ * P + j_] = C[i_ * m + j_ - 1];
+                    X[i_ * P + m + 1] = G[i * ld + i_];
+                    y[i_] = Y[i_ * k + j];
+                }
+                if (orc_mle_fit(X, y, n, P, r, r + P, r + 2 * P, r + 3 * P) == 0) {
+                    beta[i * k + j] = r[m + 1]; var[i * k + j] = r[P + m + 1]; pval[i * k + j] = r[3 * P + m + 1];
+                } else { beta[i * k + j] = NAN; var[i * k + j] = NAN; pval[i * k + j] = NAN; }
+            }
+        free(X); free(y); free(r);
+    }
+    free(C);
+    return m;
+}
+
+/* ======================================================================================
  * gwas/correlation_test.rs
  * ====================================================================================== */
 /* pearsons_correlation (correlation_test.rs:7-71), method = "sensible_corr" */

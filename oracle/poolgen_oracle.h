@@ -169,6 +169,11 @@ int orc_penalised_lambda_path(const double *Xt, int64_t P, int n, int64_t ld, co
                               int nfolds, double alpha, double lambda_step, double *beta,
                               double *lambdas_out, double *perf, int n_threads);
 
+/* gwas/mle.rs (parity unpinned: see the banner in poolgen_oracle.c) */
+int orc_mle_fit(const double *X, const double *y, int n, int P, double *b, double *v_b, double *t, double *pval);
+int orc_mle_with_covariate(const double *G, int64_t p, int n, int64_t ld, const double *Y, int k, double var_explained, int force_m,
+                           const double *covariate_in, double *beta, double *var, double *pval, int n_threads);
+
 /* the fits inside the penalised path: NULL = orc_gp_ols; the exact arbiter's tests install exq_gp_ols (poolgen_exact.c) */
 void orc_set_gp_ols_hook(void *fn);
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "pg_ols_sweep_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "pg_ols_kinship_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _d, _i, _pi, _vp, _vp, _vp, _vp]),
     "pg_ols_kinship": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _d, _i, _pi, _vp, _vp, _vp, _vp]),
+    "pg_mle_kinship_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _i, _d, _i, _pi, _vp, _vp, _vp, _vp]),
     "pg_comm_unique_id": (_i, [_vp]),
     "pg_comm_init_rank": (_i, [_vp, _vp, _i, _i]),
     "pg_comm_destroy": (_i, [_vp]),

@@ -72,7 +72,7 @@ static int flag_int(const std::string &v, const std::string &flag, int64_t lo = 
 
 static const char *USAGE =
     "poolgen <analysis> -f <input> -p <phenotypes.csv> [flags]      (MI355X build of the per-locus regression path)\n"
-    "analyses: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship,\n"
+    "analyses: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship, mle_iter_with_kinship,\n"
     "          genomic_prediction_cross_validation, fst, heterozygosity\n"
     "  -f, --fname <file>                 *.sync, or *.pileup / *.mpileup (converted in memory: exactly what pileup2sync followed by the\n"
     "                                     analysis on its sync file gives -- including the reference's column quirk: pileup2sync\n"
@@ -955,8 +955,12 @@ static GenotypesAndPhenotypes into_genotypes_and_phenotypes(Ctx &gpu, const Sync
 
 // gwas::ols_with_covariate (gwas/ols.rs:278-436): kinship, eigen rule, one fit per (column, trait), the CSV; returns the
 // name of the file it wrote.
+// ... and gwas::mle_with_covariate (gwas/mle.rs:307-463) when `mle`: same preamble, Nelder-Mead fits, same writer with its own file name
+// (the reference also prints its index arrays, the covariates, y, g, beta and pval to stdout, mle.rs:364-368, :402-405: debug output,
+// not reproduced).
 static std::string ols_with_covariate(Ctx &gpu, GenotypesAndPhenotypes &g, double xxt_eigen_variance_explained,
-                                      const std::string &fname_input, const std::string &fname_output, int n_threads, Lap &lap) {
+                                      const std::string &fname_input, const std::string &fname_output, int n_threads, Lap &lap,
+                                      bool mle = false) {
     auto hip_ok = [](hipError_t e, const char *what) {
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
     };
@@ -967,6 +971,10 @@ static std::string ols_with_covariate(Ctx &gpu, GenotypesAndPhenotypes &g, doubl
     int m = 0;
     double *out_dev = nullptr;
     hip_ok(hipMalloc((void **)&out_dev, sizeof(double) * 3 * (size_t)p * k), "device memory for the results");
+    if (mle)
+        gpu.ok(pg_mle_kinship_dev(gpu.c, g.intercept_and_allele_frequencies, p, g.n, g.ld, g.phenotypes.data(), k, xxt_eigen_variance_explained, -1,
+                                  &m, nullptr, out_dev, out_dev + (size_t)p * k, out_dev + 2 * (size_t)p * k), "mle_iter_with_kinship");
+    else
     gpu.ok(pg_ols_kinship_dev(gpu.c, g.intercept_and_allele_frequencies, p, g.n, g.ld, g.phenotypes.data(), k, xxt_eigen_variance_explained, -1,
                               &m, nullptr, out_dev, out_dev + (size_t)p * k, out_dev + 2 * (size_t)p * k), "ols_iter_with_kinship");
     gpu.ok(pg_synchronize(gpu.c), "ols_iter_with_kinship");
@@ -976,7 +984,8 @@ static std::string ols_with_covariate(Ctx &gpu, GenotypesAndPhenotypes &g, doubl
     lap("kinship + fits + D2H");
     std::string out = fname_output;
     if (out.empty()) // ols.rs:393-398
-        out = basename_no_ext(fname_input) + "-ols_iterative_xxt_" + std::to_string(m + 1) + "_eigens-" + unix_time_string() + ".csv";
+        out = basename_no_ext(fname_input) + (mle ? "-mle_iterative_xxt_" : "-ols_iterative_xxt_") + std::to_string(m + 1) + "_eigens-" +
+              unix_time_string() + ".csv"; // ols.rs:393-398, mle.rs:423-427
     FILE *fo = create_new(out);
     fputs("#chr,pos,alleles,phenotype,statistic,pvalue\n", fo); // ols.rs:409
     write_rows_parallel(fo, (int64_t)k * p, n_threads, [&](int64_t r, std::string &text) {
@@ -998,11 +1007,12 @@ static int run(int argc, char **argv) {
     Lap lap;
     const std::map<std::string, int> known{{"chisq_test", 0}, {"pearson_corr", 1}, {"ols_iter", 2},
                                            {"ols_iter_with_kinship", 3}, {"pileup2sync", 4},
-                                           {"genomic_prediction_cross_validation", 5}, {"fst", 6}, {"heterozygosity", 7}};
+                                           {"genomic_prediction_cross_validation", 5}, {"fst", 6}, {"heterozygosity", 7},
+                                           {"mle_iter_with_kinship", 8}};
     if (!known.count(a.analysis))
         throw std::runtime_error("Invalid analysis utility for this build: `" + a.analysis +
                                  "` (available: pileup2sync, chisq_test, pearson_corr, ols_iter, ols_iter_with_kinship, "
-                                 "genomic_prediction_cross_validation, fst, heterozygosity)");
+                                 "mle_iter_with_kinship, genomic_prediction_cross_validation, fst, heterozygosity)");
     if (a.generate_plots || a.sig_only)
         throw std::runtime_error("--generate-plots / --output-sig-snps-only call the reference's python scripts and are out of scope here");
     Phen ph = parse_phen(a.phen_fname, a.phen_delim, a.phen_name_col, a.phen_pool_size_col, a.phen_value_col);
@@ -1099,9 +1109,9 @@ static int run(int argc, char **argv) {
     // ---------------- the analyses on the loaded matrix (main.rs:280-298, :397-455) ---------------------------
     const bool kpm1 = mode == 7 ? false : a.keep_p_minus_1; // heterozygosity: "we need all alleles in each locus" (main.rs:445)
     GenotypesAndPhenotypes genotypes_and_phenotypes =
-        into_genotypes_and_phenotypes(gpu, sb, ph, flt, kpm1, /*remove_missing=*/mode < 6, /*with_coverages=*/mode >= 6, lap);
+        into_genotypes_and_phenotypes(gpu, sb, ph, flt, kpm1, /*remove_missing=*/mode < 6 || mode == 8, /*with_coverages=*/mode == 6 || mode == 7, lap);
     GenotypesAndPhenotypes &g = genotypes_and_phenotypes;
-    if (mode >= 6) // fst / heterozygosity use every pool (main.rs:427-455)
+    if (mode == 6 || mode == 7) // fst / heterozygosity use every pool (main.rs:427-455)
         return run_popgen(a, mode == 6, gpu, g.intercept_and_allele_frequencies, g.coverages, g.p, g.n, g.ld, g.chromosome, g.position,
                           g.pool_names, lap);
     if (mode == 5) { // genomic_prediction_cross_validation (main.rs:397-426)
@@ -1115,7 +1125,7 @@ static int run(int argc, char **argv) {
         std::cout << out << "\n";
         return done_ok();
     }
-    const std::string out = ols_with_covariate(gpu, g, a.xxt, a.fname, a.output, a.n_threads, lap);
+    const std::string out = ols_with_covariate(gpu, g, a.xxt, a.fname, a.output, a.n_threads, lap, /*mle=*/mode == 8);
     std::cout << out << "\n";
     return done_ok();
 }

@@ -95,7 +95,7 @@ std::vector<double> pg_tdist_coef(int df);
 int pg_pinv_sym(const double *A, int n, double *out);
 int pg_gp_subset_solve(const double *xxt, int n, const double *Y, int k, const int64_t *rows, int r, double *V);
 int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Z_host, int ncol,
-                    double *out_dev, int colmajor = 0); // out p x ncol, or ncol x p when colmajor
+                    double *out_dev, int colmajor = 0, double *ss_out_dev = nullptr); // out p x ncol, or ncol x p when colmajor; ss: g'g per row
 int pg_pinv_solve_sym(const double *A, int n, const double *B, int k, double *X); // pinv(A) B, Cholesky when A is safely SPD
 
 // launchers (defined in the .hip files)

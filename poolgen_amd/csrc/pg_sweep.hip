@@ -50,6 +50,7 @@ struct SweepDims {
     int64_t ntiles;
     int n, m1, k, tdf, ntcoef;
     int colmajor; // k_gp_beta*: out is k x p instead of p x k
+    double *ss;   // k_gp_beta: if set, sum of squares of every row (the MLE path's g'g)
     double dfe; // n - P as f64 (ols.rs:103)
     double tau; // relative singularity threshold on s_gg / g'g
 };
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_gp_beta(const double *__restrict
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 if (c < D.k) out[D.colmajor ? (int64_t)c * D.p + l : l * D.k + c] = acc[c];
+            if (D.ss) D.ss[l] = s2;
         }
     }
 }
@@ -963,6 +965,7 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
     P.D.dfe = (double)n - (double)(ctx->st_m + 2);
     P.D.tau = 1e-12;
     P.D.colmajor = 0;
+    P.D.ss = nullptr;
     if (ctx->st_m == 0 && ctx->spec_valid && ctx->spec_G == G_dev && ctx->spec_p == p && ctx->spec_n == n &&
         ctx->spec_ld == ld && ctx->spec_k == ctx->st_k && ctx->ph_n == n && ctx->st_Y_matches_ph) {
         // m = 0: the kinship pass already formed the sums of the intercept-only fits from its read of G
@@ -1149,7 +1152,7 @@ int pg_gp_subset_solve(const double *xxt, int n, const double *Y, int k, const i
 
 // out (p x ncol, device) = G Z for a host Z (n x ncol row-major): the slopes of `ncol` fits in ONE pass over G
 int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Z_host, int ncol,
-                    double *out_dev, int colmajor) {
+                    double *out_dev, int colmajor, double *ss_out_dev) {
     const int cols = round_cols(ncol);
     if (cols < 0) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp: at most %d coefficient columns per pass", PG_MAX_SWEEP_COLS);
     const int n_even = (n + 1) & ~1;
@@ -1170,6 +1173,7 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     SweepDims D;
     std::memset(&D, 0, sizeof D);
     D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = ncol; D.colmajor = colmajor;
+    D.ss = ss_out_dev; // (only the scalar-operand kernel below writes it)
     int64_t blocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
     const int64_t cap = (int64_t)ctx->cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
@@ -1177,7 +1181,7 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     // the folds' slopes of a CV repetition (column-major, up to 16 columns): the MFMA form
     const int zrows = (n + SW_CH - 1) / SW_CH * SW_CH;
     const size_t mfma_lds = ((size_t)zrows * 16 + (size_t)SW_WAVES * MB_TILE) * sizeof(double);
-    if (colmajor && ncol >= 5 && ncol <= 16 && mfma_lds <= 150 * 1024 && !std::getenv("POOLGEN_GP_BETA_VALU")) {
+    if (!ss_out_dev && colmajor && ncol >= 5 && ncol <= 16 && mfma_lds <= 150 * 1024 && !std::getenv("POOLGEN_GP_BETA_VALU")) {
         std::vector<double> Z16((size_t)zrows * 16, 0.0);
         for (int i = 0; i < n; ++i)
             for (int c = 0; c < ncol; ++c) Z16[(size_t)i * 16 + c] = Z_host[(size_t)i * ncol + c];
@@ -1204,7 +1208,7 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     // many columns x many pools: Z no longer fits the scalar cache -> the LDS-resident variant (see k_gp_beta_lds)
     const int wdoubles = n_even * cols;
     const size_t lds_need = ((size_t)wdoubles + (size_t)SW_WAVES * SW_TILE) * sizeof(double);
-    if (cols >= 6 && (cols % 2) == 0 && cols <= 24 && (size_t)wdoubles * sizeof(double) > 12288 && lds_need <= 150 * 1024 &&
+    if (!ss_out_dev && cols >= 6 && (cols % 2) == 0 && cols <= 24 && (size_t)wdoubles * sizeof(double) > 12288 && lds_need <= 150 * 1024 &&
         !std::getenv("POOLGEN_GP_BETA_SCALAR")) {
         switch (cols) {
         case 6: rc = launch_gp_beta_lds<6>(ctx, G_dev, ctx->W_dev, out_dev, D, wdoubles); break;

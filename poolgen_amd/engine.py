@@ -216,6 +216,19 @@ class Engine:
                     "pg_ols_kinship_dev")
         return m.value, K, out[0], out[1], out[2]
 
+    def mle_with_covariate(self, G: torch.Tensor, Y, var_explained: float = 0.75, force_m: int = -1, n: int | None = None):
+        """gwas::mle_with_covariate (gwas/mle.rs:307-463), numeric core; parity unpinned (see include/poolgen_hip.h).
+        Returns (m, K, beta, var, pval)."""
+        p, ld, n = self._g_dims(G, n)
+        Yh = _host_f64(Y).reshape(n, -1)
+        k = Yh.shape[1]
+        out = torch.empty((3, p, k), dtype=torch.float64, device=G.device)
+        K = np.empty((n, n)); m = C.c_int()
+        self._check(self._lib.pg_mle_kinship_dev(self._ctx, self._dev(G, torch.float64), p, n, ld, Yh.ctypes.data, k,
+                                                 float(var_explained), int(force_m), C.byref(m), K.ctypes.data,
+                                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()), "pg_mle_kinship_dev")
+        return m.value, K, out[0], out[1], out[2]
+
     # ---- sync-derived batch operators -------------------------------------------------------
     def _batch(self, fn, name, counts: torch.Tensor, pool_sizes, flt: Filter, Y):
         L, n, six = counts.shape

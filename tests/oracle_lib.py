@@ -60,6 +60,8 @@ class Oracle:
         lib.orc_chisq_csv.argtypes = [C.c_char_p, C.c_uint64, vp, i, vp, C.POINTER(OrcFilter), C.c_char_p, i]
         lib.orc_ols_with_covariate.argtypes = [vp, i64, i, i64, vp, i, d, i, vp, vp, vp, vp, vp, vp, vp, i]
         lib.orc_n_eigenvecs_rule.argtypes = [vp, i, d]
+        lib.orc_mle_fit.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
+        lib.orc_mle_with_covariate.argtypes = [vp, i64, i, i64, vp, i, d, i, vp, vp, vp, vp, i]
         lib.orc_kinship.argtypes = [vp, i64, i, i64, vp, i]
         lib.orc_pearsons_correlation.argtypes = [vp, i64, vp, i64, i, C.POINTER(d), C.POINTER(d)]
         lib.orc_multiply_views_xx.argtypes = [vp, i, vp, i, vp, i, vp, vp, i, vp, i, vp]
@@ -221,6 +223,29 @@ class Oracle:
                                             cptr, K.ctypes.data, ev.ctypes.data, cov.ctypes.data, beta.ctypes.data,
                                             var.ctypes.data, pv.ctypes.data, threads)
         return dict(m=m, K=K, evals=ev, cov=cov.reshape(-1)[: n * m].reshape(n, m).copy(), beta=beta, var=var, pval=pv)
+
+    def mle_fit(self, X, y):
+        X = np.ascontiguousarray(X, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        n, P = X.shape
+        b, v, t, p = (np.empty(P) for _ in range(4))
+        rc = self.lib.orc_mle_fit(X.ctypes.data, y.ctypes.data, n, P, b.ctypes.data, v.ctypes.data, t.ctypes.data, p.ctypes.data)
+        return rc, b, v, t, p
+
+    def mle_with_covariate(self, G, Y, var_explained=0.75, force_m=-1, covariate=None, n=None, threads=0):
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        p, ld = G.shape
+        n = ld if n is None else n
+        Y = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        k = Y.shape[1]
+        beta, var, pv = (np.empty((p, k)) for _ in range(3))
+        cptr = None
+        if covariate is not None:
+            covariate = np.ascontiguousarray(covariate, dtype=np.float64).reshape(n, -1)
+            force_m = covariate.shape[1]
+            cptr = covariate.ctypes.data
+        m = self.lib.orc_mle_with_covariate(G.ctypes.data, p, n, ld, Y.ctypes.data, k, float(var_explained), int(force_m), cptr,
+                                            beta.ctypes.data, var.ctypes.data, pv.ctypes.data, threads)
+        return dict(m=m, beta=beta, var=var, pval=pv)
 
     def n_eigenvecs(self, ev, thr):
         ev = np.ascontiguousarray(ev, dtype=np.float64)

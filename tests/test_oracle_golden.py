@@ -261,3 +261,21 @@ def test_pi_golden(oracle):
     assert oracle.round_own(win[0, 1], 4) == e["pop2_window1"] and oracle.round_own(win[1, 1], 4) == e["pop2_window2"]
     assert oracle.round_own(win[0, 4], 4) == e["pop5_window1"] and oracle.round_own(win[1, 4], 4) == e["pop5_window2"]
     assert np.allclose(mean, win.mean(axis=0), rtol=1e-15)
+
+
+def test_mle_restatement_sits_at_the_analytic_optimum(oracle):
+    """gwas/mle.rs is PARITY UNPINNED (no reference test, solver source absent): the restated Nelder-Mead must at least find the
+    optimum of the reference's own cost function -- the OLS coefficients, sigma^2 = 2 RSS / n (mle.rs:27 has 1 / sigma^2)."""
+    rng = np.random.default_rng(3)
+    n = 40
+    X = np.column_stack([np.ones(n), rng.random(n)])
+    y = 1.0 + 2.5 * X[:, 1] + 0.3 * rng.normal(size=n)
+    rc, b, v, t, p = oracle.mle_fit(X, y)
+    assert rc == 0
+    bo = np.linalg.lstsq(X, y, rcond=None)[0]
+    rss = float(((y - X @ bo) ** 2).sum())
+    assert np.allclose(b, bo, rtol=0, atol=2e-5)
+    ve = 2.0 * rss / n
+    vopt = ve * np.diag(np.linalg.inv(X.T @ X))
+    assert np.allclose(v, vopt, rtol=1e-3)
+    assert np.allclose(t, b / v)                                  # as written (mle.rs:175)
