@@ -91,8 +91,13 @@ def main():
     dev_index = local_rank % max(ndev, 1)   # one rank per GPU; wraps only in the 1-GPU rehearsal below
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # POOLGEN_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, library communicator, all-reduce, barriers) with
+    # ONE rank too -- what a 1-GPU box can run of it with the real nccl (= RCCL) backend (tests/test_gpu_bench.py)
+    force_dist = os.environ.get("POOLGEN_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         # nccl == RCCL on ROCm.  POOLGEN_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
         # control flow on a single-GPU box (several ranks sharing cuda:0), never for measurements.
         backend = os.environ.get("POOLGEN_BENCH_BACKEND", "nccl")
@@ -112,9 +117,9 @@ def main():
     # carries the 128-byte unique id and the timing barriers.  Falls back to torch.distributed's all-reduce only if the
     # library cannot set its communicator up (reported in the JSON line as "allreduce").
     allreduce_impl = "none (1 rank)"
-    if world > 1:
+    if use_dist:
         try:
-            allreduce_impl = "RCCL inside libpoolgen_hip (pg_allreduce_sum_dev)" if setup_comm(eng) else \
+            allreduce_impl = "RCCL inside libpoolgen_hip (pg_allreduce_sum_dev)" if setup_comm(eng, force=force_dist) else \
                 f"torch.distributed ({os.environ.get('POOLGEN_BENCH_BACKEND', 'nccl')})"
         except Exception as e:  # keep the run alive: the scaling numbers are worth more than the purity of the path
             print(f"warning: library communicator unavailable ({e}); using torch.distributed all_reduce", file=sys.stderr)
@@ -133,7 +138,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -148,7 +153,7 @@ def main():
         m = step()[0]
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -186,7 +191,7 @@ def main():
                         del os.environ["POOLGEN_TWO_PASS"]
                     else:
                         os.environ["POOLGEN_TWO_PASS"] = old
-            if world > 1:
+            if use_dist:
                 tt = torch.tensor([ldt], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 ldt = float(tt.item())
@@ -278,7 +283,7 @@ def main():
             s = min(args.cpu_sample, p_local)
             rec["cpu_baseline"] = cpu_baseline(G[:s, :n].cpu().numpy(), Y, args.var_explained, args.force_m)
         print(json.dumps(rec))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -21,7 +21,7 @@ def shard_range(p_total: int, rank: int, world: int):
     return lo, hi
 
 
-def setup_comm(engine, group=None) -> bool:
+def setup_comm(engine, group=None, force: bool = False) -> bool:
     """Give `engine` the library's own RCCL communicator over the ranks of the torch.distributed job: rank 0 draws the
     unique id, torch.distributed only carries those 128 bytes to the other ranks (its store / object broadcast), then
     every rank runs ncclCommInitRank inside libpoolgen_hip (pg_comm_init_rank).  Returns False -- and the caller stays
@@ -30,14 +30,15 @@ def setup_comm(engine, group=None) -> bool:
     if not (dist.is_available() and dist.is_initialized()):
         return False
     world = dist.get_world_size(group)
-    if world <= 1 or not hasattr(engine, "comm_init") or os.environ.get("POOLGEN_COMM", "rccl") != "rccl":
+    if (world <= 1 and not force) or not hasattr(engine, "comm_init") or os.environ.get("POOLGEN_COMM", "rccl") != "rccl":
         return False
-    if engine.comm_size == world:
+    if getattr(engine, "_comm_ready", False) and engine.comm_size == world:
         return True
     rank = dist.get_rank(group)
     box = [engine.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0, group=group)
     engine.comm_init(box[0], world, rank)
+    engine._comm_ready = True
     return True
 
 
@@ -49,7 +50,7 @@ def ols_with_covariate_sharded(engine, G_local: torch.Tensor, p_total: int, Y, v
         # POOLGEN_TWO_PASS=1 keeps the plain two-pass path (kinship, then a full sweep) for measurement
         engine.set_phenotypes(None if os.environ.get("POOLGEN_TWO_PASS") == "1" or force_m > 0 else Y)  # lets the kinship pass pre-compute the intercept-only fits
     S = engine.kinship_partial(G_local, n)
-    if getattr(engine, "comm_size", 1) > 1:
+    if getattr(engine, "_comm_ready", False):
         engine.allreduce_sum(S)                      # RCCL inside the library, on the engine's stream
     elif dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)   # engines without their own communicator (gloo rehearsals)

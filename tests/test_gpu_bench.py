@@ -47,3 +47,18 @@ def test_two_rank_control_flow_rehearsal():
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["loci_total"] == 1000001 and d["config"]["loci_per_gpu"] == 500000
     assert d["scaling"] == "strong" and d["value"] > 0
+    # two ranks on ONE device: RCCL refuses, the line says which all-reduce ran instead
+    assert d["config"]["allreduce"].startswith("torch.distributed"), d["config"]
+
+
+def test_one_rank_through_the_real_rccl_path():
+    """The multi-rank code path of bench.py with the REAL backends, as far as one GPU allows: torch.distributed nccl (= RCCL)
+    process group of one rank, the library's own communicator set up through it (pg_comm_init_rank with the id carried by
+    torch.distributed), the kinship all-reduce inside libpoolgen_hip, barriers and max-over-ranks timing."""
+    env = dict(os.environ, POOLGEN_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--loci", "2000000",
+                        "--no-cpu-baseline", "--sweep-steps", "1"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["allreduce"].startswith("RCCL inside libpoolgen_hip"), d["config"]
+    assert d["value"] > 0 and "roofline_sweep" in d and d["roofline_sweep"]["two_pass"]["launches"] == 1
