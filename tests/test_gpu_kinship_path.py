@@ -59,6 +59,25 @@ def test_sweep_without_covariates(engine, oracle, p, n):
     cmp_fit(got, ref, f"p={p} n={n}")
 
 
+@pytest.mark.parametrize("p,n,ld,off", [(1, 8, 8, 0), (7, 5, 6, 0), (129, 37, 40, 0), (1000, 200, 208, 0), (4097, 100, 100, 0),
+                                         (777, 200, 200, 3), (513, 100, 100, 1), (2049, 50, 50, 5), (300, 33, 34, 7), (640, 201, 202, 0)])
+def test_sweep_row_geometries(engine, oracle, p, n, ld, off):
+    """The super-row kernel over awkward geometries: row pitches that put 1, 2, 4 or 8 loci into one line-aligned super-row
+    (ld = 208 / 200 / 100 / 50, 6, 34), padding columns between n and ld, odd n, a column count that is not a multiple of
+    the super-row, a single locus, and a matrix that starts in the middle of an allocation (a rank's slab: not line-aligned)."""
+    from poolgen_amd import synth
+    Gfull = synth.genotype_matrix(p + off, n, "cuda", seed=77, ld=ld)
+    if ld > n:
+        Gfull[:, n:] = 123.0                       # padding must never be read as data
+    G = Gfull[off:]
+    assert G.is_contiguous()
+    Y = synth.phenotypes(Gfull, n, k=2, seed=77)
+    engine.covariates_set(n, None, Y)
+    got = engine.ols_sweep(G, 2, n)
+    ref = oracle.ols_with_covariate(np.ascontiguousarray(G.cpu().numpy()[:, :n]), Y, force_m=0)
+    cmp_fit(got, ref, f"p={p} n={n} ld={ld} off={off}")
+
+
 @pytest.mark.parametrize("n,m,k", [(200, 1, 1), (200, 3, 2), (100, 8, 1), (40, 5, 3)])
 def test_sweep_with_covariates(engine, oracle, exact, n, m, k):
     from test_gpu_exact import assert_close, formula_p
