@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -383,6 +384,211 @@ __global__ __launch_bounds__(SW_THREADS, SW_MINWAVES) void k_ols_sweep_rows(
     }
 }
 
+// ---- the sweep on the matrix cores ------------------------------------------------------------------------------------
+// W'g for 16 loci x 16 columns is one v_mfma_f64_16x16x4_f64 chain: A = 16 loci x 4 pools of G, B = 4 pools x 16 columns of
+// W = [Q | ytilde], D = 16 loci x 16 columns.  The A operand wants lane (i = lane & 15, kk = lane >> 4) to hold pool kk of
+// locus i -- and a lane that loads the 16 bytes at  row i, pools 8 c + 2 kk, 8 c + 2 kk + 1  straight from global memory has
+// exactly the A operands of two MFMAs (the pool order inside a chain is free as long as B follows it).  So there is NO LDS
+// transposition: G goes HBM -> registers -> matrix pipe, 16 rows x 64 bytes per load instruction, the other half of every
+// 128-byte line by the next instruction of the same wave; measured with the arithmetic in place at 6.45 TB/s on 200 pools x
+// 10 M loci (tools/mb_msweep.hip), against 6.3 TB/s for the best staged pattern with no arithmetic at all (tools/mb_pattern).
+// The vector ALU is left with g - g[0] and g'g (3 operations per element whatever the number of columns), the matrix pipe is
+// about a third busy for up to 16 columns, so the kernel is bound by the read of G for every design the product meets.
+//   B lives in LDS ([chunk][lane] as double2 = the two pools of the lane: one conflict-free ds_read_b128 per chunk), filled
+//   once per workgroup from W; column groups beyond 16 (NCG = 2: up to 32 columns) reuse A with a second accumulator.
+//   Loads run U chunks (U x 1 KB per wave) at a time through a ring of R register buffers, so a wave has (R - 1) U .. R U KB
+//   in flight at any time, across tile and 64-locus-group boundaries.
+//   g'g: per-lane partial sums over the lane's pools, summed over the four kk lanes of a locus by one more MFMA against a
+//   matrix of ones -- which also delivers it in the D layout of the other sums.
+//   Closing: the D fragments of four 16-locus tiles go through a wave-private LDS stage (64 loci x (columns + 1)), then one
+//   lane per locus runs the same closing arithmetic as the other sweep kernels and stores 64 consecutive results.
+typedef double ms_d4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+struct MsGeom {
+    int nc;         // 8-pool chunks per locus = ceil(n / 8)
+    int ng;         // groups of U chunks = ceil(nc / U)
+    int cols;       // row pitch of W
+    int cu;         // columns in use = m + 1 + k
+    int pitch;      // doubles per locus in the closing stage (odd: conflict-free lane-per-locus reads)
+    int exp;        // timing experiments (POOLGEN_SWEEP_EXP, wrong results): 1 = no closing arithmetic, 2 = no closing at all,
+                    // 8 = no stores, 16 = stores that stay in the L2
+    int mask_last;  // ... or past its n pools: those elements are zeroed
+    int64_t n64;    // 64-locus groups
+};
+struct MsCursor { int64_t t64; int T, g; };
+
+// The closing code's STORES are written in assembly, for the sake of the loads: the compiler's wait-count pass, on seeing a
+// loop with vector-memory stores (the loop over traits), puts s_waitcnt vmcnt(0) in front of it -- which drains the ring of
+// loads below every 64 loci -- and, merging that path into the head of the main loop, makes the consumer of ring buffer 0
+// wait for all outstanding loads, so that one group instead of R is in flight (measured: 3.06 ms on 200 pools x 10 M loci
+// against 2.5 ms for the same loop in tools/mb_msweep.hip).  Stores the pass cannot see do not trigger any of that, and they
+// can only make its waits for loads longer, never too short: loads return in order, so "at most N operations outstanding"
+// implies that a load with N younger loads behind it has landed, whatever stores are also in flight.
+// (Writing the LOADS in assembly with hand-placed waits was tried first and is wrong: the compiler is free to copy a
+// register it believes defined -- and did, ahead of the wait -- while the load is still in flight.)
+__device__ __forceinline__ void ms_store8(double *addr, double x) {
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(addr), "v"(x) : "memory");
+}
+template <int N, typename F>
+__device__ __forceinline__ void ms_static_for(F &&f) {
+    if constexpr (N > 0) {
+        ms_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int U, int R, int NCG>
+__global__ __launch_bounds__(SW_THREADS, 2) void k_ols_sweep_mfma(
+    const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
+    const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
+    double *__restrict__ pval, const SweepDims D, const MsGeom M) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (scalar: the cursors below live in SGPRs)
+    const int li = lane & 15, lk = lane >> 4;
+    const int ncp = M.ng * U;
+    double2 *Wl = reinterpret_cast<double2 *>(lds); // [NCG][ncp][64]
+    double *stage = lds + (size_t)NCG * ncp * 128 + (size_t)wave * 64 * M.pitch;
+    for (int x = threadIdx.x; x < NCG * ncp * 64; x += SW_THREADS) {
+        const int ln = x & 63, c = (x >> 6) % ncp, cg = (x >> 6) / ncp;
+        const int j = 16 * cg + (ln & 15), pl = 8 * c + 2 * (ln >> 4);
+        double2 w = {0.0, 0.0};
+        if (j < M.cu) {
+            if (pl < D.n) w.x = W[(size_t)pl * M.cols + j];
+            if (pl + 1 < D.n) w.y = W[(size_t)(pl + 1) * M.cols + j];
+        }
+        Wl[x] = w;
+    }
+    __syncthreads();
+    const int64_t wstride = (int64_t)gridDim.x * SW_WAVES;
+    MsCursor ci = {(int64_t)blockIdx.x * SW_WAVES + wave, 0, 0};
+    if (ci.t64 >= M.n64) return;
+    MsCursor cc = ci;
+    // A lane's byte offset inside a 16-locus tile never changes; the tile moves through the (scalar) buffer descriptor, whose
+    // range check also answers reads past the end of the matrix with zeros: no address arithmetic and no clamps per load.
+    const uint32_t lane_off = (uint32_t)((int64_t)li * D.ld * 8 + 16 * lk);
+
+    auto advance = [&](MsCursor &c) {
+        if (++c.g < M.ng) return;
+        c.g = 0;
+        if (++c.T < 4) return;
+        c.T = 0;
+        c.t64 += wstride;
+    };
+    auto issue = [&](uint4_t (&v)[U], const MsCursor &c) {
+        const int64_t row0 = c.t64 * 64 + 16 * c.T;
+        int64_t left = (D.p - row0) * D.ld * 8;
+        left = left < 0 ? 0 : (left > 0xFFFFF000ll ? 0xFFFFF000ll : left);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(G + (left ? row0 : 0) * D.ld), 0,
+                                                                            (int)(uint32_t)left, 0x00020000);
+        const uint32_t vo = lane_off + (uint32_t)(64 * U) * (uint32_t)c.g;
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64u * u, 0, 0);
+    };
+    ms_d4 acc[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) acc[cg] = ms_d4{0.0, 0.0, 0.0, 0.0};
+    double s2 = 0.0, shift = 0.0;
+    auto as_f64 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
+
+    auto products = [&](uint4_t (&v)[U], const double2 (&bq)[NCG][U], const MsCursor &c, auto masked) {
+        ms_static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            double ga = as_f64(v[u].x, v[u].y) - shift, gb = as_f64(v[u].z, v[u].w) - shift;
+            if (decltype(masked)::value) { // the group that holds the row's end: pools n .. are not this locus's
+                const int pl = 8 * (U * c.g + u) + 2 * lk;
+                ga = pl < D.n ? ga : 0.0;
+                gb = pl + 1 < D.n ? gb : 0.0;
+            }
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) {
+                acc[cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, bq[cg][u].x, acc[cg], 0, 0, 0);
+                acc[cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(gb, bq[cg][u].y, acc[cg], 0, 0, 0);
+            }
+            s2 = fma(ga, ga, s2);
+            s2 = fma(gb, gb, s2);
+        });
+    };
+    auto consume = [&](uint4_t (&v)[U], const MsCursor &c) {
+        // the group's B operands first: their LDS latency passes while the wave waits for (or subtracts from) the G values
+        double2 bq[NCG][U];
+        {
+            const double2 *wl = Wl + (size_t)(U * c.g) * 64 + lane;
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+                for (int u = 0; u < U; ++u) bq[cg][u] = wl[(size_t)(cg * ncp + u) * 64];
+        }
+        if (c.g == 0) shift = __shfl(as_f64(v[0].x, v[0].y), li); // any per-locus constant cancels because Z contains the intercept
+        if (c.g != M.ng - 1) {
+            products(v, bq, c, std::false_type{});
+            return;
+        }
+        if (M.mask_last) products(v, bq, c, std::true_type{});
+        else products(v, bq, c, std::false_type{});
+        // ---- end of a 16-locus tile: fragments -> stage ------------------------------------------------------------
+        const ms_d4 e = __builtin_amdgcn_mfma_f64_16x16x4f64(s2, 1.0, ms_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double *sr = stage + (16 * c.T + lk + 4 * r) * M.pitch;
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg)
+                if (16 * cg + li < M.cu) sr[16 * cg + li] = acc[cg][r];
+            if (li == 0) sr[M.cu] = e[r];
+        }
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) acc[cg] = ms_d4{0.0, 0.0, 0.0, 0.0};
+        s2 = 0.0;
+        if (c.T != 3 || (M.exp & 2)) return;
+        // ---- end of a 64-locus group: one lane per locus (gwas/ols.rs:102-116, 139-158) --------------------------------
+        __builtin_amdgcn_wave_barrier();
+        const int64_t l = c.t64 * 64 + lane;
+        if (l < D.p) {
+            const double *sr = stage + lane * M.pitch;
+            double uu = 0.0;
+            for (int a = 0; a < D.m1; ++a) uu = fma(sr[a], sr[a], uu);
+            const double gg = sr[M.cu];
+            const double sgg = gg - uu;
+            const bool bad = !(sgg > D.tau * gg);
+            if (D.k == 1) { // straight-line code and ordinary stores: the wait-count pass then counts them exactly
+                double b = sgg, vb = gg, pv = uu;
+                if (!(M.exp & 1)) ols_close(sgg, sr[D.m1], syy[0], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
+                beta[l] = b;
+                var[l] = vb;
+                pval[l] = pv;
+            } else {
+                for (int jt = 0; jt < D.k; ++jt) {
+                    double b, vb, pv;
+                    ols_close(sgg, sr[D.m1 + jt], syy[jt], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
+                    ms_store8(&beta[l * D.k + jt], b);
+                    ms_store8(&var[l * D.k + jt], vb);
+                    ms_store8(&pval[l * D.k + jt], pv);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // the ring: buffer r is consumed and refilled (for the item R places on) at one place in the loop body
+    uint4_t v[R][U];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { issue(v[r], ci); advance(ci); }
+    // A whole number of turns of the ring and no exits from inside it (with a break after every consume() the wait-count pass
+    // loses track of the order of the loads and waits for far too many): the items past the wave's last one are loads the
+    // descriptor answers with zeros and fits of loci >= p, which are not stored.
+    const int64_t cnt64 = (M.n64 - cc.t64 + wstride - 1) / wstride;
+    const int64_t turns = (cnt64 * 4 * M.ng + R - 1) / R;
+    for (int64_t it = 0; it < turns; ++it) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            consume(v[r], cc);
+            advance(cc);
+            issue(v[r], ci);
+            advance(ci);
+        }
+    }
+}
+
 // gp::ols coefficient pass (gp/ols.rs:47-72): beta_l = sum_i G[l][i] * Z[i][j], the same
 // lane-per-locus streaming pass without the regression epilogue (Z = rows of pinv(X X^T) y
 // scattered to the training pools, zero elsewhere).
@@ -685,6 +891,58 @@ int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
     return PG_OK;
 }
 
+// The MFMA sweep for up to 32 columns.  U (chunks per load group) is the one of 5 .. 8 that pads the ceil(n / 8) chunks of a
+// locus least (200 pools: 25 chunks = 5 groups of 5; 100 pools: 13 -> 14 = 2 groups of 7); the ring is 3 deep for U <= 6, else 2.
+template <int U, int R, int NCG>
+int launch_sweep_mfma_as(pg_ctx *ctx, const SweepArgs &A, MsGeom M) {
+    M.ng = (M.nc + U - 1) / U;
+    const int ncp = M.ng * U;
+    M.exp = std::getenv("POOLGEN_SWEEP_EXP") ? std::atoi(std::getenv("POOLGEN_SWEEP_EXP")) : 0;
+    M.mask_last = 8 * ncp > A.D.n;
+    const size_t shmem = ((size_t)NCG * ncp * 128 + (size_t)SW_WAVES * 64 * M.pitch) * sizeof(double);
+    auto kern = k_ols_sweep_mfma<U, R, NCG>;
+    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    int per_cu = 0;
+    PG_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SW_THREADS, shmem));
+    if (per_cu < 1) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "sweep: %zu bytes of LDS per workgroup do not fit", shmem);
+    if (const char *e = std::getenv("POOLGEN_SWEEP_GRID_MULT")) per_cu = std::max(1, std::atoi(e)); // experiments
+    const int64_t blocks = (M.n64 + SW_WAVES - 1) / SW_WAVES, cap = (int64_t)ctx->cus * per_cu;
+    pg_prof_begin(ctx, PG_K_SWEEP);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W, A.syy,
+                       A.tcoef, A.beta, A.var, A.pval, A.D, M);
+    pg_prof_end(ctx);
+    PG_HIP(ctx, hipGetLastError());
+    return PG_OK;
+}
+
+int launch_sweep_mfma(pg_ctx *ctx, const SweepArgs &A, int cols, int cu) {
+    MsGeom M;
+    M.nc = (A.D.n + 7) / 8;
+    M.cols = cols;
+    M.cu = cu;
+    M.pitch = (cu + 1) | 1;
+    M.n64 = (A.D.p + 63) / 64;
+    int U = 8, best = 1 << 30;
+    for (int u = 8; u >= 5; --u) {
+        const int padded = (M.nc + u - 1) / u * u;
+        if (padded < best) { best = padded; U = u; }
+    }
+    if (const char *e = std::getenv("POOLGEN_SWEEP_U")) { const int u = std::atoi(e); if (u >= 5 && u <= 8) U = u; } // experiments
+    const bool two = cu > 16;
+    if (const char *e = std::getenv("POOLGEN_SWEEP_R")) { // experiments: deeper rings for U = 5
+        const int r = std::atoi(e);
+        if (U == 5 && !two && r == 4) return launch_sweep_mfma_as<5, 4, 1>(ctx, A, M);
+        if (U == 5 && !two && r == 5) return launch_sweep_mfma_as<5, 5, 1>(ctx, A, M);
+        if (U == 5 && !two && r == 2) return launch_sweep_mfma_as<5, 2, 1>(ctx, A, M);
+    }
+    switch (U) {
+    case 5: return two ? launch_sweep_mfma_as<5, 3, 2>(ctx, A, M) : launch_sweep_mfma_as<5, 3, 1>(ctx, A, M);
+    case 6: return two ? launch_sweep_mfma_as<6, 3, 2>(ctx, A, M) : launch_sweep_mfma_as<6, 3, 1>(ctx, A, M);
+    case 7: return two ? launch_sweep_mfma_as<7, 2, 2>(ctx, A, M) : launch_sweep_mfma_as<7, 2, 1>(ctx, A, M);
+    default: return two ? launch_sweep_mfma_as<8, 2, 2>(ctx, A, M) : launch_sweep_mfma_as<8, 2, 1>(ctx, A, M);
+    }
+}
+
 int round_cols(int c) {
     const int sizes[] = {2, 3, 4, 6, 8, 12, 16, 24, PG_MAX_SWEEP_COLS};
     for (int s : sizes)
@@ -976,6 +1234,10 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
         PG_HIP(ctx, hipGetLastError());
         return PG_OK;
     }
+    // the matrix-core sweep unless an A/B run asks for one of the vector-ALU kernels (or the design has more than 32 columns)
+    const int cu = ctx->st_m + 1 + ctx->st_k;
+    if (cu <= 32 && !std::getenv("POOLGEN_SWEEP_V1") && !std::getenv("POOLGEN_SWEEP_V2"))
+        return launch_sweep_mfma(ctx, P, ctx->st_cols, cu);
     int64_t blocks = (P.D.ntiles + SW_WAVES - 1) / SW_WAVES;
     int mult = 8;
     if (const char *e = std::getenv("POOLGEN_SWEEP_GRID_MULT")) mult = std::max(1, std::atoi(e)); // experiments

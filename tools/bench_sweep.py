@@ -10,7 +10,7 @@ from poolgen_amd import Engine, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-variants = [v for v in os.environ.get("SWEEP_VARIANTS", "v2,v1").split(",")]
+variants = [v for v in os.environ.get("SWEEP_VARIANTS", "mf,v2,v1").split(",")]
 eng = Engine(0)
 G = synth.genotype_matrix(p, n, "cuda")
 Y = synth.phenotypes(G[:100000], n, k=1)
@@ -23,19 +23,31 @@ for m in [int(x) for x in os.environ.get('SWEEP_MS', '0,8').split(',')]:
     ref = None
     for rnd in range(2):
         for v in variants:
-            for key in ("POOLGEN_SWEEP_V1", "POOLGEN_SWEEP_V2", "POOLGEN_SWEEP_GRID_MULT", "POOLGEN_SWEEP_NOPF", "POOLGEN_SWEEP_MODE", "POOLGEN_SWEEP_EXP"):
+            for key in ("POOLGEN_SWEEP_V1", "POOLGEN_SWEEP_V2", "POOLGEN_SWEEP_GRID_MULT", "POOLGEN_SWEEP_NOPF", "POOLGEN_SWEEP_MODE", "POOLGEN_SWEEP_EXP", "POOLGEN_SWEEP_U", "POOLGEN_SWEEP_R"):
                 os.environ.pop(key, None)
             if v == "v1":
                 os.environ["POOLGEN_SWEEP_V1"] = "1"
             elif v == "v2":
                 os.environ["POOLGEN_SWEEP_V2"] = "1"
             elif v.startswith("v2exp"):
+                os.environ["POOLGEN_SWEEP_V2"] = "1"
                 os.environ["POOLGEN_SWEEP_EXP"] = v[5:]
             elif v.startswith("v2mode"):
+                os.environ["POOLGEN_SWEEP_V2"] = "1"
                 os.environ["POOLGEN_SWEEP_MODE"] = v[6:]
             elif v == "v2nopf":
+                os.environ["POOLGEN_SWEEP_V2"] = "1"
                 os.environ["POOLGEN_SWEEP_NOPF"] = "1"
             elif v.startswith("v2g"):
+                os.environ["POOLGEN_SWEEP_V2"] = "1"
+                os.environ["POOLGEN_SWEEP_GRID_MULT"] = v[3:]
+            elif v.startswith("mfu"):      # "mf" = the product's default (the matrix-core sweep); mfu<U>: chunks per load group
+                os.environ["POOLGEN_SWEEP_U"] = v[3:]
+            elif v.startswith("mfexp"):    # timing experiments (wrong results)
+                os.environ["POOLGEN_SWEEP_EXP"] = v[5:]
+            elif v.startswith("mfr"):      # mfr<ring depth>
+                os.environ["POOLGEN_SWEEP_R"] = v[3:]
+            elif v.startswith("mfg"):      # mfg<blocks per CU>
                 os.environ["POOLGEN_SWEEP_GRID_MULT"] = v[3:]
             eng.ols_sweep(G, 1, n, out); torch.cuda.synchronize()
             if ref is None:

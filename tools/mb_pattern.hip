@@ -43,6 +43,43 @@ __global__ __launch_bounds__(256) void k_pattern(const char *__restrict__ base, 
     if (s == 12345.678) out[0] = s + lds[0];
 }
 
+// k_locus_first's shape: ONE 128-byte line per row per stage (8 lanes per row, 8 rows per instruction, 8 instructions per
+// stage of 64 rows), NST stages in flight
+template <int NST>
+__global__ __launch_bounds__(256) void k_lines(const char *__restrict__ base, long long ntiles, long long rowlen, long long stride, double *out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane >> 3, piece = lane & 7;
+    const long long wstride = (long long)gridDim.x * 4;
+    const int nst = (int)((rowlen + 127) / 128);
+    double s = 0.0;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += wstride) {
+        const char *tb = base + t * 64 * stride;
+        double2 a[8], b[8], c[8];
+        auto issue = [&](double2 (&v)[8], int st) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                long long in_row = (long long)st * 128 + 16 * piece;
+                in_row = in_row < rowlen - 16 ? in_row : rowlen - 16;
+                v[r] = *reinterpret_cast<const double2 *>(tb + (long long)(8 * r + lr) * stride + in_row);
+            }
+        };
+        auto use = [&](const double2 (&v)[8]) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += v[r].x + v[r].y;
+        };
+        if (NST == 1) { for (int st = 0; st < nst; ++st) { issue(a, st); use(a); } }
+        else if (NST == 2) { issue(a, 0); for (int st = 0; st < nst; st += 2) { if (st + 1 < nst) issue(b, st + 1); use(a); if (st + 2 < nst) issue(a, st + 2); if (st + 1 < nst) use(b); } }
+        else { issue(a, 0); if (nst > 1) issue(b, 1);
+            for (int st = 0; st < nst; st += 3) {
+                if (st + 2 < nst) issue(c, st + 2); use(a);
+                if (st + 3 < nst) issue(a, st + 3); if (st + 1 < nst) use(b);
+                if (st + 4 < nst) issue(b, st + 4); if (st + 2 < nst) use(c);
+            } }
+    }
+    if (s == 12345.678) out[0] = s + lds[0];
+}
+
 // the same in-flight structure on a CONTIGUOUS slab: 16 consecutive 1 KB wave loads per step
 __global__ __launch_bounds__(256) void k_linear16(const char *__restrict__ base, long long nsteps, double *out) {
     extern __shared__ double lds[];
@@ -94,6 +131,19 @@ int main(int argc, char **argv) {
     {
         float ms = timeit(k_linear16, grid, shmem, (const char *)buf, (long long)(bytes / 16384), out);
         printf("%-64s %8.3f ms %8.1f GB/s\n", "contiguous: 16 x 1 KB per wave step", ms, rate(ms, (double)bytes));
+    }
+    for (long long rl : {4800LL, 2400LL}) { // counts rows: 24 n bytes, n = 200 / 100
+        const long long nt = (long long)(bytes / (64 * rl));
+        const double useful = (double)nt * 64 * rl;
+        float ms;
+        ms = timeit(k_lines<1>, grid, shmem, (const char *)buf, nt, rl, rl, out);
+        printf("counts rows %4lld B, one 128-B line per row per stage, 1 stage  in flight: %8.3f ms %8.1f GB/s\n", rl, ms, rate(ms, useful));
+        ms = timeit(k_lines<2>, grid, shmem, (const char *)buf, nt, rl, rl, out);
+        printf("counts rows %4lld B, one 128-B line per row per stage, 2 stages in flight: %8.3f ms %8.1f GB/s\n", rl, ms, rate(ms, useful));
+        ms = timeit(k_lines<3>, grid, shmem, (const char *)buf, nt, rl, rl, out);
+        printf("counts rows %4lld B, one 128-B line per row per stage, 3 stages in flight: %8.3f ms %8.1f GB/s\n", rl, ms, rate(ms, useful));
+        ms = timeit(k_pattern<256, 64, 1>, grid, shmem, (const char *)buf, nt, rl, rl, 0LL, out);
+        printf("counts rows %4lld B, 256-B pieces x 64 rows, 1 chunk in flight:            %8.3f ms %8.1f GB/s\n", rl, ms, rate(ms, useful));
     }
     struct Case { const char *name; long long rowlen, stride, mis; };
     const Case cases[] = {

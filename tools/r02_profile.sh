@@ -57,11 +57,11 @@ out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc passes of `python3
                    "(tools/r02_profile.sh; per-kernel means in r02_pmc_summary.txt): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 being the "
                    "gfx950 wide-read correction of MI355X_MICROARCH.md",
        "source": "profiles/r02_pmc_summary.txt", "workload": "200x10000000",
-       "kinship_hbm_bytes_per_launch": hbm("k_kinship_syrk<true, true>"),
-       "kinship_two_pass_hbm_bytes_per_launch": hbm("k_kinship_syrk<false, true>"),
+       "kinship_hbm_bytes_per_launch": hbm("k_kinship_syrk<true, true, 3>"),
+       "kinship_two_pass_hbm_bytes_per_launch": hbm("k_kinship_syrk<false, true, 3>"),
        "sweep_two_pass_hbm_bytes_per_launch": hbm("k_ols_sweep<2, 0>"),
        "sweep_m8_hbm_bytes_per_launch": hbm("k_ols_sweep_rows<12>")}
-mf, ga = vals.get(("k_kinship_syrk<true, true>", "SQ_VALU_MFMA_BUSY_CYCLES")), vals.get(("k_kinship_syrk<true, true>", "GRBM_GUI_ACTIVE"))
+mf, ga = vals.get(("k_kinship_syrk<true, true, 3>", "SQ_VALU_MFMA_BUSY_CYCLES")), vals.get(("k_kinship_syrk<true, true, 3>", "GRBM_GUI_ACTIVE"))
 if mf and ga: out["kinship_mfma_busy_frac"] = mf / 1024.0 / (ga / 8.0)
 json.dump(out, open("gpurun_out/r02_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
