@@ -437,8 +437,10 @@ __device__ __forceinline__ void ms_static_for(F &&f) {
     }
 }
 
-template <int U, int R, int NCG>
-__global__ __launch_bounds__(SW_THREADS, 2) void k_ols_sweep_mfma(
+// MODE 0: the regression sweep.  MODE 1: the products alone (gp::ols slopes, pg_gp_beta_cols): out = G Z for D.k columns, row-
+// or column-major, no shift, optionally the rows' sums of squares in D.ss; `beta` is the output, the other pointers unused.
+template <int U, int R, int NCG, int MODE>
+__global__ __launch_bounds__(SW_THREADS, NCG == 3 ? 1 : 2) void k_ols_sweep_mfma(
     const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
     const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
     double *__restrict__ pval, const SweepDims D, const MsGeom M) {
@@ -494,7 +496,8 @@ __global__ __launch_bounds__(SW_THREADS, 2) void k_ols_sweep_mfma(
     auto products = [&](uint4_t (&v)[U], const double2 (&bq)[NCG][U], const MsCursor &c, auto masked) {
         ms_static_for<U>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            double ga = as_f64(v[u].x, v[u].y) - shift, gb = as_f64(v[u].z, v[u].w) - shift;
+            double ga = as_f64(v[u].x, v[u].y), gb = as_f64(v[u].z, v[u].w);
+            if constexpr (MODE == 0) { ga -= shift; gb -= shift; }
             if (decltype(masked)::value) { // the group that holds the row's end: pools n .. are not this locus's
                 const int pl = 8 * (U * c.g + u) + 2 * lk;
                 ga = pl < D.n ? ga : 0.0;
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void k_ols_sweep_mfma(
 #pragma unroll
                 for (int u = 0; u < U; ++u) bq[cg][u] = wl[(size_t)(cg * ncp + u) * 64];
         }
-        if (c.g == 0) shift = __shfl(as_f64(v[0].x, v[0].y), li); // any per-locus constant cancels because Z contains the intercept
+        if (MODE == 0 && c.g == 0) shift = __shfl(as_f64(v[0].x, v[0].y), li); // any per-locus constant cancels because Z contains the intercept
         if (c.g != M.ng - 1) {
             products(v, bq, c, std::false_type{});
             return;
@@ -543,14 +546,20 @@ __global__ __launch_bounds__(SW_THREADS, 2) void k_ols_sweep_mfma(
         // ---- end of a 64-locus group: one lane per locus (gwas/ols.rs:102-116, 139-158) --------------------------------
         __builtin_amdgcn_wave_barrier();
         const int64_t l = c.t64 * 64 + lane;
-        if (l < D.p) {
+        if (MODE == 1) {
+            if (l < D.p) {
+                const double *sr = stage + lane * M.pitch;
+                for (int a = 0; a < D.k; ++a) ms_store8(D.colmajor ? &beta[(int64_t)a * D.p + l] : &beta[l * D.k + a], sr[a]);
+                if (D.ss) ms_store8(&D.ss[l], sr[M.cu]);
+            }
+        } else if (l < D.p) {
             const double *sr = stage + lane * M.pitch;
             double uu = 0.0;
             for (int a = 0; a < D.m1; ++a) uu = fma(sr[a], sr[a], uu);
             const double gg = sr[M.cu];
             const double sgg = gg - uu;
             const bool bad = !(sgg > D.tau * gg);
-            if (D.k == 1) { // straight-line code and ordinary stores: the wait-count pass then counts them exactly
+            if (D.k == 1) { // straight-line code and ordinary stores
                 double b = sgg, vb = gg, pv = uu;
                 if (!(M.exp & 1)) ols_close(sgg, sr[D.m1], syy[0], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
                 beta[l] = b;
@@ -891,23 +900,25 @@ int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
     return PG_OK;
 }
 
-// The MFMA sweep for up to 32 columns.  U (chunks per load group) is the one of 5 .. 8 that pads the ceil(n / 8) chunks of a
-// locus least (200 pools: 25 chunks = 5 groups of 5; 100 pools: 13 -> 14 = 2 groups of 7); the ring is 3 deep for U <= 6, else 2.
-template <int U, int R, int NCG>
-int launch_sweep_mfma_as(pg_ctx *ctx, const SweepArgs &A, MsGeom M) {
+// The matrix-core sweep for up to 48 columns.  U (chunks per load group) is the one of 5 .. 8 that pads the ceil(n / 8) chunks
+// of a locus least (200 pools: 25 chunks = 5 groups of 5; 100 pools: 13 -> 14 = 2 groups of 7); the ring is 3 deep for U <= 6,
+// else 2.
+constexpr int MS_MAX_COLS = 48;
+template <int U, int R, int NCG, int MODE>
+int launch_sweep_mfma_as(pg_ctx *ctx, const SweepArgs &A, MsGeom M, int kernel_id) {
     M.ng = (M.nc + U - 1) / U;
     const int ncp = M.ng * U;
     M.exp = std::getenv("POOLGEN_SWEEP_EXP") ? std::atoi(std::getenv("POOLGEN_SWEEP_EXP")) : 0;
     M.mask_last = 8 * ncp > A.D.n;
     const size_t shmem = ((size_t)NCG * ncp * 128 + (size_t)SW_WAVES * 64 * M.pitch) * sizeof(double);
-    auto kern = k_ols_sweep_mfma<U, R, NCG>;
+    auto kern = k_ols_sweep_mfma<U, R, NCG, MODE>;
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     int per_cu = 0;
     PG_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SW_THREADS, shmem));
     if (per_cu < 1) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "sweep: %zu bytes of LDS per workgroup do not fit", shmem);
     if (const char *e = std::getenv("POOLGEN_SWEEP_GRID_MULT")) per_cu = std::max(1, std::atoi(e)); // experiments
     const int64_t blocks = (M.n64 + SW_WAVES - 1) / SW_WAVES, cap = (int64_t)ctx->cus * per_cu;
-    pg_prof_begin(ctx, PG_K_SWEEP);
+    pg_prof_begin(ctx, kernel_id);
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W, A.syy,
                        A.tcoef, A.beta, A.var, A.pval, A.D, M);
     pg_prof_end(ctx);
@@ -915,32 +926,42 @@ int launch_sweep_mfma_as(pg_ctx *ctx, const SweepArgs &A, MsGeom M) {
     return PG_OK;
 }
 
-int launch_sweep_mfma(pg_ctx *ctx, const SweepArgs &A, int cols, int cu) {
+int ms_pick_u(int nc) {
+    int U = 8, best = 1 << 30;
+    for (int u = 8; u >= 5; --u) {
+        const int padded = (nc + u - 1) / u * u;
+        if (padded < best) { best = padded; U = u; }
+    }
+    if (const char *e = std::getenv("POOLGEN_SWEEP_U")) { const int u = std::atoi(e); if (u >= 5 && u <= 8) U = u; } // experiments
+    return U;
+}
+// does the B table ([column groups][padded chunks] KB) plus the closing stage fit the 160 KB of a CU?
+bool ms_fits(int n, int cu) {
+    const int nc = (n + 7) / 8, U = ms_pick_u(nc), ncp = (nc + U - 1) / U * U, ncg = (cu + 15) / 16;
+    return cu <= MS_MAX_COLS && ((size_t)ncg * ncp * 128 + (size_t)SW_WAVES * 64 * ((cu + 1) | 1)) * sizeof(double) <= 160 * 1024;
+}
+
+template <int MODE>
+int launch_sweep_mfma(pg_ctx *ctx, const SweepArgs &A, int cols, int cu, int kernel_id) {
     MsGeom M;
     M.nc = (A.D.n + 7) / 8;
     M.cols = cols;
     M.cu = cu;
     M.pitch = (cu + 1) | 1;
     M.n64 = (A.D.p + 63) / 64;
-    int U = 8, best = 1 << 30;
-    for (int u = 8; u >= 5; --u) {
-        const int padded = (M.nc + u - 1) / u * u;
-        if (padded < best) { best = padded; U = u; }
-    }
-    if (const char *e = std::getenv("POOLGEN_SWEEP_U")) { const int u = std::atoi(e); if (u >= 5 && u <= 8) U = u; } // experiments
-    const bool two = cu > 16;
-    if (const char *e = std::getenv("POOLGEN_SWEEP_R")) { // experiments: deeper rings for U = 5
-        const int r = std::atoi(e);
-        if (U == 5 && !two && r == 4) return launch_sweep_mfma_as<5, 4, 1>(ctx, A, M);
-        if (U == 5 && !two && r == 5) return launch_sweep_mfma_as<5, 5, 1>(ctx, A, M);
-        if (U == 5 && !two && r == 2) return launch_sweep_mfma_as<5, 2, 1>(ctx, A, M);
-    }
+    const int U = ms_pick_u(M.nc);
+    const int ncg = (cu + 15) / 16;
+#define MS_GO(UU, RR)                                                                                             \
+    return ncg == 1 ? launch_sweep_mfma_as<UU, RR, 1, MODE>(ctx, A, M, kernel_id)                                 \
+         : ncg == 2 ? launch_sweep_mfma_as<UU, RR, 2, MODE>(ctx, A, M, kernel_id)                                 \
+                    : launch_sweep_mfma_as<UU, RR, 3, MODE>(ctx, A, M, kernel_id);
     switch (U) {
-    case 5: return two ? launch_sweep_mfma_as<5, 3, 2>(ctx, A, M) : launch_sweep_mfma_as<5, 3, 1>(ctx, A, M);
-    case 6: return two ? launch_sweep_mfma_as<6, 3, 2>(ctx, A, M) : launch_sweep_mfma_as<6, 3, 1>(ctx, A, M);
-    case 7: return two ? launch_sweep_mfma_as<7, 2, 2>(ctx, A, M) : launch_sweep_mfma_as<7, 2, 1>(ctx, A, M);
-    default: return two ? launch_sweep_mfma_as<8, 2, 2>(ctx, A, M) : launch_sweep_mfma_as<8, 2, 1>(ctx, A, M);
+    case 5: MS_GO(5, 3)
+    case 6: MS_GO(6, 3)
+    case 7: MS_GO(7, 2)
+    default: MS_GO(8, 2)
     }
+#undef MS_GO
 }
 
 int round_cols(int c) {
@@ -1234,10 +1255,10 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
         PG_HIP(ctx, hipGetLastError());
         return PG_OK;
     }
-    // the matrix-core sweep unless an A/B run asks for one of the vector-ALU kernels (or the design has more than 32 columns)
+    // the matrix-core sweep unless an A/B run asks for one of the vector-ALU kernels
     const int cu = ctx->st_m + 1 + ctx->st_k;
-    if (cu <= 32 && !std::getenv("POOLGEN_SWEEP_V1") && !std::getenv("POOLGEN_SWEEP_V2"))
-        return launch_sweep_mfma(ctx, P, ctx->st_cols, cu);
+    if (ms_fits(n, cu) && !std::getenv("POOLGEN_SWEEP_V1") && !std::getenv("POOLGEN_SWEEP_V2"))
+        return launch_sweep_mfma<0>(ctx, P, ctx->st_cols, cu, PG_K_SWEEP);
     int64_t blocks = (P.D.ntiles + SW_WAVES - 1) / SW_WAVES;
     int mult = 8;
     if (const char *e = std::getenv("POOLGEN_SWEEP_GRID_MULT")) mult = std::max(1, std::atoi(e)); // experiments
@@ -1440,7 +1461,19 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     const int64_t cap = (int64_t)ctx->cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
     int rc;
-    // the folds' slopes of a CV repetition (column-major, up to 16 columns): the MFMA form
+    // the matrix-core kernel of the sweep in its products-only mode: every shape, one read of G at the sweep's rate
+    if (ms_fits(n, ncol) && (ld % 2) == 0 && (reinterpret_cast<uintptr_t>(G_dev) & 15) == 0 && !std::getenv("POOLGEN_GP_BETA_OLD")) {
+        SweepArgs P;
+        P.G = G_dev; P.W = ctx->W_dev; P.syy = nullptr; P.tcoef = nullptr;
+        P.beta = out_dev; P.var = nullptr; P.pval = nullptr;
+        P.D = D;
+        rc = launch_sweep_mfma<1>(ctx, P, cols, ncol, PG_K_GP_BETA);
+        if (rc) return rc;
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Z is stack-owned
+        return PG_OK;
+    }
+    // (the older forms, kept for A/B timing: POOLGEN_GP_BETA_OLD=1)
+    // the folds' slopes of a CV repetition (column-major, up to 16 columns): the MFMA form over an LDS-staged tile
     const int zrows = (n + SW_CH - 1) / SW_CH * SW_CH;
     const size_t mfma_lds = ((size_t)zrows * 16 + (size_t)SW_WAVES * MB_TILE) * sizeof(double);
     if (!ss_out_dev && colmajor && ncol >= 5 && ncol <= 16 && mfma_lds <= 150 * 1024 && !std::getenv("POOLGEN_GP_BETA_VALU")) {
