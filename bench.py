@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--force-m", type=int, default=-1, help=">=0 forces the number of kinship PCs")
     ap.add_argument("--ld", type=int, default=0, help="leading dimension of G in doubles (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sweep-legs", action="store_true", help="skip the two untimed legs that measure k_ols_sweep")
+    ap.add_argument("--no-sweep-legs", action="store_true", help="skip the two untimed legs that measure k_ols_sweep_mfma")
     ap.add_argument("--sweep-steps", type=int, default=5, help="steps per sweep leg (after the timed region)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     args = ap.parse_args()
@@ -164,9 +164,9 @@ def main():
 
     # ---- after the timed region: the general path, so that the per-locus sweep (north_star's HBM-roofline kernel) has a
     # driver-run number too.  At the default -x 0.75 the eigen rule gives m = 0 and the fits are closed from sums fused into
-    # the kinship pass: k_ols_sweep is never launched by the headline.  Two extra legs of `extra` steps each:
-    #   two_pass : same analysis with the fusion off -> kinship (no fused sums) + k_ols_sweep with [1 | g]   (m = 0)
-    #   m8       : --force-m 8 -> host eigenvectors + k_ols_sweep with [1 | C(8) | g]                           (m = 8)
+    # the kinship pass: the sweep kernel (k_ols_sweep_mfma) is never launched by the headline.  Two extra legs of `extra` steps each:
+    #   two_pass : same analysis with the fusion off -> kinship (no fused sums) + k_ols_sweep_mfma with [1 | g]   (m = 0)
+    #   m8       : --force-m 8 -> host eigenvectors + k_ols_sweep_mfma with [1 | C(8) | g]                      (m = 8)
     legs = {}
     extra = 0 if args.no_sweep_legs else args.sweep_steps
     if extra > 0 and args.force_m < 0:
@@ -257,7 +257,7 @@ def main():
                 "k_kinship_syrk": {"avg_ms": kin_avg, "executed_mfma_tflops": per_s(kin_exec_flops, kin_avg),
                                    "useful_tflops": per_s(kin_useful_flops, kin_avg), "algorithmic_tflops": kin_tflops},
                 "k_kinship_reduce": {"avg_ms": red_ms / max(red_n, 1)},
-                "k_ols_sweep": ({"avg_ms": sw_avg, "gbs_algorithmic": sweep_bytes / (sw_avg * 1e-3) / 1e9,
+                "k_ols_sweep_mfma": ({"avg_ms": sw_avg, "gbs_algorithmic": sweep_bytes / (sw_avg * 1e-3) / 1e9,
                                  "frac_of_hbm_peak": sweep_bytes / (sw_avg * 1e-3) / 1e9 / HBM_PEAK_GBS} if sw_n else
                                 {"avg_ms": 0.0, "note": "not launched by the headline: m = 0 fits closed from the sums fused into the "
                                                         "kinship pass; see roofline_sweep for the general path"}),
@@ -266,7 +266,7 @@ def main():
             },
         }
         if legs:
-            rs = {"kernel": "k_ols_sweep", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            rs = {"kernel": "k_ols_sweep_mfma", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "bytes_per_locus": 8.0 * n + 24.0 * k, "loci_per_launch": p_local, "steps_per_leg": extra,
                   "what": "algorithmic bytes (SURVEY 8d: 8n read + 24k written per locus) / HIP-event launch time, measured after "
                           "the timed headline region in the same process", "traffic_note": traffic_note}

@@ -416,6 +416,8 @@ struct MsGeom {
     int64_t n64;    // 64-locus groups
 };
 struct MsCursor { int64_t t64; int T, g; };
+// one workgroup of 8 waves per CU shares the B table (4 waves with their 512 registers each for 33 .. 48 columns)
+constexpr int ms_threads(int ncg) { return ncg == 3 ? 256 : 512; }
 
 // The closing code's STORES are written in assembly, for the sake of the loads: the compiler's wait-count pass, on seeing a
 // loop with vector-memory stores (the loop over traits), puts s_waitcnt vmcnt(0) in front of it -- which drains the ring of
@@ -440,7 +442,7 @@ __device__ __forceinline__ void ms_static_for(F &&f) {
 // MODE 0: the regression sweep.  MODE 1: the products alone (gp::ols slopes, pg_gp_beta_cols): out = G Z for D.k columns, row-
 // or column-major, no shift, optionally the rows' sums of squares in D.ss; `beta` is the output, the other pointers unused.
 template <int U, int R, int NCG, int MODE>
-__global__ __launch_bounds__(SW_THREADS, NCG == 3 ? 1 : 2) void k_ols_sweep_mfma(
+__global__ __launch_bounds__(ms_threads(NCG), 1) void k_ols_sweep_mfma(
     const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
     const double *__restrict__ tcoef, double *__restrict__ beta, double *__restrict__ var,
     double *__restrict__ pval, const SweepDims D, const MsGeom M) {
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(SW_THREADS, NCG == 3 ? 1 : 2) void k_ols_sweep_mfma
     const int ncp = M.ng * U;
     double2 *Wl = reinterpret_cast<double2 *>(lds); // [NCG][ncp][64]
     double *stage = lds + (size_t)NCG * ncp * 128 + (size_t)wave * 64 * M.pitch;
-    for (int x = threadIdx.x; x < NCG * ncp * 64; x += SW_THREADS) {
+    for (int x = threadIdx.x; x < NCG * ncp * 64; x += ms_threads(NCG)) {
         const int ln = x & 63, c = (x >> 6) % ncp, cg = (x >> 6) / ncp;
         const int j = 16 * cg + (ln & 15), pl = 8 * c + 2 * (ln >> 4);
         double2 w = {0.0, 0.0};
@@ -462,8 +464,8 @@ __global__ __launch_bounds__(SW_THREADS, NCG == 3 ? 1 : 2) void k_ols_sweep_mfma
         Wl[x] = w;
     }
     __syncthreads();
-    const int64_t wstride = (int64_t)gridDim.x * SW_WAVES;
-    MsCursor ci = {(int64_t)blockIdx.x * SW_WAVES + wave, 0, 0};
+    const int64_t wstride = (int64_t)gridDim.x * (ms_threads(NCG) / 64);
+    MsCursor ci = {(int64_t)blockIdx.x * (ms_threads(NCG) / 64) + wave, 0, 0};
     if (ci.t64 >= M.n64) return;
     MsCursor cc = ci;
     // A lane's byte offset inside a 16-locus tile never changes; the tile moves through the (scalar) buffer descriptor, whose
@@ -852,7 +854,7 @@ struct SweepArgs {
 template <int C>
 int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
     const size_t shmem = (size_t)SW_WAVES * SW_TILE * sizeof(double);
-    const bool rows_kernel = std::getenv("POOLGEN_SWEEP_V1") || (C >= 12 && !std::getenv("POOLGEN_SWEEP_V2"));
+    const bool rows_kernel = std::getenv("POOLGEN_SWEEP_V1") || ((C >= 12 || A.D.n <= 32) && !std::getenv("POOLGEN_SWEEP_V2"));
     if (rows_kernel) {
         SweepDims D1 = A.D;
         D1.ntiles = (A.D.p + 63) / 64;
@@ -902,24 +904,26 @@ int launch_sweep(pg_ctx *ctx, const SweepArgs &A, int grid) {
 
 // The matrix-core sweep for up to 48 columns.  U (chunks per load group) is the one of 5 .. 8 that pads the ceil(n / 8) chunks
 // of a locus least (200 pools: 25 chunks = 5 groups of 5; 100 pools: 13 -> 14 = 2 groups of 7); the ring is 3 deep for U <= 6,
-// else 2.
+// else 2.  Fewer than 33 pools stay with the row kernel: measured with 20 and 30 pools x 10-20 M loci, 0.50 / 0.56-0.60 of the
+// HBM peak here against 0.61 / 0.62 there (rows this short are mostly closing arithmetic per byte, and padding below 5 chunks).
 constexpr int MS_MAX_COLS = 48;
 template <int U, int R, int NCG, int MODE>
 int launch_sweep_mfma_as(pg_ctx *ctx, const SweepArgs &A, MsGeom M, int kernel_id) {
+    constexpr int threads = ms_threads(NCG), waves = threads / 64;
     M.ng = (M.nc + U - 1) / U;
     const int ncp = M.ng * U;
     M.exp = std::getenv("POOLGEN_SWEEP_EXP") ? std::atoi(std::getenv("POOLGEN_SWEEP_EXP")) : 0;
     M.mask_last = 8 * ncp > A.D.n;
-    const size_t shmem = ((size_t)NCG * ncp * 128 + (size_t)SW_WAVES * 64 * M.pitch) * sizeof(double);
+    const size_t shmem = ((size_t)NCG * ncp * 128 + (size_t)waves * 64 * M.pitch) * sizeof(double);
     auto kern = k_ols_sweep_mfma<U, R, NCG, MODE>;
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     int per_cu = 0;
-    PG_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SW_THREADS, shmem));
+    PG_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, shmem));
     if (per_cu < 1) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "sweep: %zu bytes of LDS per workgroup do not fit", shmem);
     if (const char *e = std::getenv("POOLGEN_SWEEP_GRID_MULT")) per_cu = std::max(1, std::atoi(e)); // experiments
-    const int64_t blocks = (M.n64 + SW_WAVES - 1) / SW_WAVES, cap = (int64_t)ctx->cus * per_cu;
+    const int64_t blocks = (M.n64 + waves - 1) / waves, cap = (int64_t)ctx->cus * per_cu;
     pg_prof_begin(ctx, kernel_id);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(SW_THREADS), shmem, ctx->stream, A.G, A.W, A.syy,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(threads), shmem, ctx->stream, A.G, A.W, A.syy,
                        A.tcoef, A.beta, A.var, A.pval, A.D, M);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipGetLastError());
@@ -938,7 +942,7 @@ int ms_pick_u(int nc) {
 // does the B table ([column groups][padded chunks] KB) plus the closing stage fit the 160 KB of a CU?
 bool ms_fits(int n, int cu) {
     const int nc = (n + 7) / 8, U = ms_pick_u(nc), ncp = (nc + U - 1) / U * U, ncg = (cu + 15) / 16;
-    return cu <= MS_MAX_COLS && ((size_t)ncg * ncp * 128 + (size_t)SW_WAVES * 64 * ((cu + 1) | 1)) * sizeof(double) <= 160 * 1024;
+    return nc >= 5 && cu <= MS_MAX_COLS && ((size_t)ncg * ncp * 128 + (size_t)(ms_threads(ncg) / 64) * 64 * ((cu + 1) | 1)) * sizeof(double) <= 160 * 1024;
 }
 
 template <int MODE>

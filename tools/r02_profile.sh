@@ -59,8 +59,9 @@ out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc passes of `python3
        "source": "profiles/r02_pmc_summary.txt", "workload": "200x10000000",
        "kinship_hbm_bytes_per_launch": hbm("k_kinship_syrk<true, true, 3>"),
        "kinship_two_pass_hbm_bytes_per_launch": hbm("k_kinship_syrk<false, true, 3>"),
-       "sweep_two_pass_hbm_bytes_per_launch": hbm("k_ols_sweep<2, 0>"),
-       "sweep_m8_hbm_bytes_per_launch": hbm("k_ols_sweep_rows<12>")}
+       # (one kernel serves both legs since the matrix-core sweep: the per-kernel mean is over the launches of both)
+       "sweep_two_pass_hbm_bytes_per_launch": hbm("k_ols_sweep_mfma<5, 3, 1, 0>"),
+       "sweep_m8_hbm_bytes_per_launch": hbm("k_ols_sweep_mfma<5, 3, 1, 0>")}
 mf, ga = vals.get(("k_kinship_syrk<true, true, 3>", "SQ_VALU_MFMA_BUSY_CYCLES")), vals.get(("k_kinship_syrk<true, true, 3>", "GRBM_GUI_ACTIVE"))
 if mf and ga: out["kinship_mfma_busy_frac"] = mf / 1024.0 / (ga / 8.0)
 json.dump(out, open("gpurun_out/r02_pmc_traffic.json", "w"), indent=1)
