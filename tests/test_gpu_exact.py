@@ -49,7 +49,7 @@ def errs(got, ex, pf):
 
 def report(tag, gpu, orc):
     f = lambda e: f"rel beta {e[0]:.2e} abs beta {e[1]:.2e} rel var {e[2]:.2e} abs p {e[3]:.2e} (vs the exact tail {e[4]:.2e})"
-    print(f"\n[{tag}]\n    |GPU    - exact|: {f(gpu)}\n    |oracle - exact|: {f(orc)}")
+    print(f"\n[{tag}]\n    |GPU    - exact|: {f(gpu)}" + (f"\n    |oracle - exact|: {f(orc)}" if orc is not None else ""))
 
 
 def assert_close(got, ex, pf, what):
@@ -76,6 +76,24 @@ def test_covariate_sweep_against_binary128(engine, oracle, exact, n, m, k, capsy
     with capsys.disabled():
         report(f"sweep n={n} m={m} k={k}", errs(got, ex, pf), errs((ref["beta"], ref["var"], ref["pval"]), ex, pf))
     assert_close(got, ex, pf, f"n={n} m={m}")
+
+
+@pytest.mark.parametrize("n,m,k,p", [(200, 14, 3, 1500), (120, 30, 3, 1000), (500, 20, 2, 600), (104, 16, 1, 2100)])
+def test_wide_covariate_sweep_against_binary128(engine, oracle, exact, n, m, k, p, capsys):
+    """More than 16 columns [Q | ytilde]: the matrix-core sweep carries a second and a third accumulator per tile (18, 34, 23
+    columns here; 34 = the most one launch takes), 17 columns sit right behind the edge, n = 500 is the long-row shape of
+    config 4, and p is not a multiple of the 64-locus group."""
+    G, Y = make(p, n, 19, 2)
+    Y = np.hstack([Y, Y[:, :1] ** 2 + 0.3 * Y[:, 1:2]])[:, :k]
+    Gh = G.cpu().numpy()
+    _, _, _, C = exact.kinship_covariates(Gh, force_m=m, n=n)
+    engine.covariates_set(n, C, Y)
+    got = tuple(x.cpu().numpy() for x in engine.ols_sweep(G, k, n))
+    ex = exact.ols_covariate(Gh, Y, C, n=n)
+    pf = formula_p(oracle, ex, n)
+    with capsys.disabled():
+        report(f"wide sweep n={n} m={m} k={k}", errs(got, ex, pf), None)
+    assert_close(got, ex, pf, f"n={n} m={m} k={k}")
 
 
 @pytest.mark.parametrize("n,p,x,force_m", [(60, 4000, 0.99, -1), (60, 4000, 0.985, -1), (200, 6000, 0.75, 3), (120, 5000, 0.75, 8)])
@@ -118,8 +136,8 @@ def test_gp_ols_against_binary128(engine, oracle, exact, n, p, k, rows, capsys):
     assert np.allclose(beta, ex, rtol=RTOL, atol=1e-12 * scale.max())
 
 
-@pytest.mark.parametrize("n,p,k,alpha", [(60, 3000, 1, 0.0), (40, 2000, 2, 0.0), (50, 1500, 1, 1.0)])
-def test_ridge_path_against_binary128_fits(engine, oracle, exact, n, p, k, alpha, capsys):
+@pytest.mark.parametrize("n,p,k,alpha,n_folds", [(60, 3000, 1, 0.0, 4), (40, 2000, 2, 0.0, 4), (50, 1500, 1, 1.0, 4), (130, 1200, 1, 0.0, 20)])
+def test_ridge_path_against_binary128_fits(engine, oracle, exact, n, p, k, alpha, n_folds, capsys):
     """penalise_ridge_like / lasso_like (gp/penalise.rs:133-159, :461-669): the oracle's path with its fold fits taken from
     binary128 (everything downstream of the fits -- expand_and_contract, error_index, arg-min and mode rules -- is
     well conditioned and stays the oracle's literal arithmetic)."""
@@ -128,7 +146,7 @@ def test_ridge_path_against_binary128_fits(engine, oracle, exact, n, p, k, alpha
     Y = synth.phenotypes(G, n, k=2, seed=47)[:, :k]
     rng = np.random.default_rng(8)
     rows = np.array([i for i in range(n) if i % 9 != 4])
-    n_folds, n_reps = 4, 3
+    n_reps = 3       # (20 folds: the folds' slopes are 20 columns of ONE products pass -- two accumulators per tile)
     folds = np.stack([rng.permutation(np.arange(len(rows)) % n_folds) for _ in range(n_reps)])
     beta, lam, perf = engine.gp_ridge(G, Y, rows, folds, n_folds, alpha=alpha, n=n)
     Xt = np.vstack([np.ones((1, n)), G.cpu().numpy()[:, :n]])

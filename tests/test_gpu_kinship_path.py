@@ -68,7 +68,7 @@ def test_sweep_row_geometries(engine, oracle, p, n, ld, off):
     from poolgen_amd import synth
     Gfull = synth.genotype_matrix(p + off, n, "cuda", seed=77, ld=ld)
     if ld > n:
-        Gfull[:, n:] = 123.0                       # padding must never be read as data
+        Gfull[:, n:] = float("nan")                # padding must never be read as data: a NaN there would surface in the fits
     G = Gfull[off:]
     assert G.is_contiguous()
     Y = synth.phenotypes(Gfull, n, k=2, seed=77)
