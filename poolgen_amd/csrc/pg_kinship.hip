@@ -134,6 +134,11 @@ struct KinParams {
     const double *ytil; // k x 256 centred phenotypes, zero padded
     double *spec;       // p x (2 + k)
     int k;
+    // More than one pool-block pair (n > 208): the workgroups that stream the SAME slab of loci are placed on ONE XCD, so that
+    // a slab's lines reach HBM once and the other pairs that stage them hit that XCD's L2 (workgroups go to the XCDs round-robin
+    // by linear id; with (slab, pair) = blockIdx.(x, y) the pairs of a slab landed on different XCDs and each pool column came
+    // from HBM nb - 1 times: 54 GB for the 20 GB of config 4).  xcd_spx = slabs per XCD in that placement, 0 = plain 2-D grid.
+    int xcd_spx, npairs, nslab;
 };
 
 // SMALL (13-tile shape only): the tiles that are not full 16 x 16 blocks of useful products run on v_mfma_f64_4x4x4_4b_f64
@@ -156,10 +161,17 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     const int fi = lane & 15; // pool within fragment / output column
     const int kq = lane >> 4; // locus within k-step / output row group
 
-    // ---- which pair of pool blocks ------------------------------------------------------
+    // ---- which slab of loci, which pair of pool blocks ------------------------------------
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (P.xcd_spx) { // 1-D grid: linear id -> (XCD, position on it) -> (slab, pair); see KinParams::xcd_spx
+        const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3, main = P.xcd_spx * P.npairs;
+        if (s < main) { bx = xcd * P.xcd_spx + s / P.npairs; by = s % P.npairs; }
+        else { const int e = (s - main) * 8 + xcd; bx = 8 * P.xcd_spx + e / P.npairs; by = e % P.npairs; } // the slabs left over
+        if (bx >= P.nslab) return;
+    }
     int bi = 0, bj = 0;
     {
-        int q = blockIdx.y / P.split;
+        int q = by / P.split;
         const int first = P.merged ? 1 : 0; // merged: pairs with bi < bj only
         for (bi = 0; bi < P.nb; ++bi) {
             const int cnt = P.nb - bi - first;
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     const int cntA = P.merged ? (NA > rankA ? (NA - rankA + part - 1) / part : 0) : 0;
     const int cntB = P.merged ? (NB > rankB ? (NB - rankB + part - 1) / part : 0) : 0;
     const int ntiles = diag ? NA : nrect + cntA + cntB;
-    const int split_id = blockIdx.y % P.split;
+    const int split_id = by % P.split;
     // Every wave runs exactly KIN_TPW tile slots so that the k-loop is straight-line code; a slot
     // beyond the tile list recomputes tile 0 into an accumulator that is never stored.
     int acol[KIN_TPW], bcol[KIN_TPW], orow[KIN_TPW], ocol[KIN_TPW];
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         if (!st_on[r]) st_loc[r] = 0;
     }
 
-    const int64_t l_begin = (int64_t)blockIdx.x * P.loci_per_wg;
+    const int64_t l_begin = (int64_t)bx * P.loci_per_wg;
     const int64_t l_end = min(P.p, l_begin + P.loci_per_wg);
     const int nstages = (l_end > l_begin) ? (int)((l_end - l_begin + KIN_KC - 1) / KIN_KC) : 0;
     const int bufsz = KIN_KC * ldsld;
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
                     mfma_set(std::integral_constant<int, s2 & 1>{});
                 });
             }
-            double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
+            double *slab = P.slabs + (size_t)bx * P.npad * P.npad;
             static_for<NT>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
                 constexpr int ti = KIN13_T[W][u][0], tj = KIN13_T[W][u][1];
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         }
         // ---- write this workgroup's partial tiles -----------------------------------------------
         // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
-        double *slab = P.slabs + (size_t)blockIdx.x * P.npad * P.npad;
+        double *slab = P.slabs + (size_t)bx * P.npad * P.npad;
         static_for<TPW>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             bool on;
@@ -663,6 +675,12 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     if (P.loci_per_wg > max_loci_per_wg) P.loci_per_wg = max_loci_per_wg;
     nslab = (int)((p + P.loci_per_wg - 1) / P.loci_per_wg);
 
+    P.npairs = npairs; P.nslab = nslab;
+    P.xcd_spx = 0;
+    if (npairs > 1 && cus % 8 == 0 && !std::getenv("POOLGEN_KIN_NO_XCD")) {
+        const int spx = (cus / 8) / npairs;        // whole slabs (all their pairs) that fit one XCD's CUs
+        if (spx >= 1 && 8 * spx <= nslab) P.xcd_spx = spx;
+    }
     const size_t slab_bytes = (size_t)nslab * P.npad * P.npad * sizeof(double);
     int rc = pg_ws_reserve(ctx, slab_bytes);
     if (rc) return rc;
@@ -696,7 +714,9 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
+        if (P.xcd_spx) hipLaunchKernelGGL(kern, dim3(8 * ((P.xcd_spx * npairs) + ((nslab - 8 * P.xcd_spx) * npairs + 7) / 8)), dim3(KIN_THREADS), shmem,
+                                          ctx->stream, P);
+        else hipLaunchKernelGGL(kern, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
         return hipSuccess;
     };
     pg_prof_begin(ctx, kid);
