@@ -955,15 +955,24 @@ int launch_sweep_mfma(pg_ctx *ctx, const SweepArgs &A, int cols, int cu, int ker
     M.n64 = (A.D.p + 63) / 64;
     const int U = ms_pick_u(M.nc);
     const int ncg = (cu + 15) / 16;
-#define MS_GO(UU, RR)                                                                                             \
-    return ncg == 1 ? launch_sweep_mfma_as<UU, RR, 1, MODE>(ctx, A, M, kernel_id)                                 \
+#define MS_GO(UU, R1, RR)                                                                                         \
+    return ncg == 1 ? launch_sweep_mfma_as<UU, R1, 1, MODE>(ctx, A, M, kernel_id)                                 \
          : ncg == 2 ? launch_sweep_mfma_as<UU, RR, 2, MODE>(ctx, A, M, kernel_id)                                 \
                     : launch_sweep_mfma_as<UU, RR, 3, MODE>(ctx, A, M, kernel_id);
-    switch (U) {
-    case 5: MS_GO(5, 3)
-    case 6: MS_GO(6, 3)
-    case 7: MS_GO(7, 2)
-    default: MS_GO(8, 2)
+    if (const char *e = std::getenv("POOLGEN_SWEEP_R")) { // experiments: other ring depths (one accumulator, the sweep only)
+        const int r = std::atoi(e);
+        if constexpr (MODE == 0) {
+            if (ncg == 1 && U == 5 && r == 2) return launch_sweep_mfma_as<5, 2, 1, 0>(ctx, A, M, kernel_id);
+            if (ncg == 1 && U == 5 && r == 4) return launch_sweep_mfma_as<5, 4, 1, 0>(ctx, A, M, kernel_id);
+            if (ncg == 1 && U == 7 && r == 2) return launch_sweep_mfma_as<7, 2, 1, 0>(ctx, A, M, kernel_id);
+            if (ncg == 1 && U == 8 && r == 2) return launch_sweep_mfma_as<8, 2, 1, 0>(ctx, A, M, kernel_id);
+        }
+    }
+    switch (U) { // ring depth: 3 with one accumulator (205-223 registers at U = 7, 8), 2 for U >= 7 with more (measured: +2 % at n = 500)
+    case 5: MS_GO(5, 3, 3)
+    case 6: MS_GO(6, 3, 3)
+    case 7: MS_GO(7, 3, 2)
+    default: MS_GO(8, 3, 2)
     }
 #undef MS_GO
 }
