@@ -139,6 +139,13 @@ struct KinParams {
     // by linear id; with (slab, pair) = blockIdx.(x, y) the pairs of a slab landed on different XCDs and each pool column came
     // from HBM nb - 1 times: 54 GB for the 20 GB of config 4).  xcd_spx = slabs per XCD in that placement, 0 = plain 2-D grid.
     int xcd_spx, npairs, nslab;
+    // Two or three pool blocks without the merged tile lists (n = 209..224, 257..384): the pairs differ in work (a diagonal pair
+    // of 8 tile columns has 36 tiles, an off-diagonal one 64, the pairs of a short last block fewer still), so each pair gets its
+    // own number of workgroups -- and with it its own slab length -- in proportion to the tile slots its waves run.  With one
+    // slab length for all, the diagonal workgroups finished early and a third of the CUs idled (n = 300: 47 of 79 TFLOP/s).
+    // wq_n[q] > 0 switches this on: pair q = workgroups wq_first[q] .. + wq_n[q] of a 1-D grid, wq_len[q] loci each.
+    int wq_n[6], wq_first[6];
+    int64_t wq_len[6];
 };
 
 // SMALL (13-tile shape only): the tiles that are not full 16 x 16 blocks of useful products run on v_mfma_f64_4x4x4_4b_f64
@@ -168,6 +175,14 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         if (s < main) { bx = xcd * P.xcd_spx + s / P.npairs; by = s % P.npairs; }
         else { const int e = (s - main) * 8 + xcd; bx = 8 * P.xcd_spx + e / P.npairs; by = e % P.npairs; } // the slabs left over
         if (bx >= P.nslab) return;
+    }
+    int64_t loci_per_wg = P.loci_per_wg;
+    if (P.wq_n[0] > 0) { // weighted pairs: see KinParams::wq_n
+        int q = 0;
+        while (q + 1 < P.npairs && (int)blockIdx.x >= P.wq_first[q + 1]) ++q;
+        by = q;
+        bx = (int)blockIdx.x - P.wq_first[q];
+        loci_per_wg = P.wq_len[q];
     }
     int bi = 0, bj = 0;
     {
@@ -261,8 +276,8 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
         if (!st_on[r]) st_loc[r] = 0;
     }
 
-    const int64_t l_begin = (int64_t)bx * P.loci_per_wg;
-    const int64_t l_end = min(P.p, l_begin + P.loci_per_wg);
+    const int64_t l_begin = (int64_t)bx * loci_per_wg;
+    const int64_t l_end = min(P.p, l_begin + loci_per_wg);
     const int nstages = (l_end > l_begin) ? (int)((l_end - l_begin + KIN_KC - 1) / KIN_KC) : 0;
     const int bufsz = KIN_KC * ldsld;
 
@@ -619,14 +634,20 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
 // i <= j (only upper-triangular tiles were written).  256 threads = 64 columns x 4 slab groups: group g
 // adds slabs g, g+4, ... in order, then (g0 + g1) + (g2 + g3) -- deterministic, no atomics, and four
 // times the loads in flight of a one-thread-per-entry loop (the slabs are 88 MB at n = 200).
+constexpr double KIN_PAIR_FLOOR = 2.7; // slots' worth of time a block pair costs at least (stage hand-over)
+struct KinCounts { int blk, nb, n[6]; }; // weighted pairs: slabs that hold the tiles of block pair q (row-major upper triangle); blk = 0: all
 __global__ __launch_bounds__(256) void k_kinship_reduce(const double *__restrict__ slabs, int nslabs, int npad, int n,
-                                                        double add_const, double *__restrict__ S) {
+                                                        double add_const, double *__restrict__ S, const KinCounts C) {
     __shared__ double part[4][64];
     const int jj = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jj;
     const int i = blockIdx.y;
     const bool on = i < n && j < n && i <= j;
     double s = 0.0;
+    if (on && C.blk) {
+        const int bi = i / C.blk, bj = j / C.blk;
+        nslabs = C.n[bi * C.nb - bi * (bi - 1) / 2 + (bj - bi)];
+    }
     if (on) {
         const size_t off = (size_t)i * npad + j;
         const size_t stride = (size_t)npad * npad;
@@ -662,6 +683,26 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     // nb >= 4: 64 + 2 * ceil(36 / (nb - 1)) <= 96 slots; nb == 2: measured -- a win at T = 15, 16 (7.6 -> 6.9 ms at n = 240..256,
     // 4 M loci), a loss at T = 14 where the diagonal workgroups stage few columns
     P.merged = ((P.nb >= 4 || (P.nb == 2 && P.T >= 15)) && !std::getenv("POOLGEN_KIN_NO_MERGE")) ? 1 : 0;
+    if (!P.merged && P.nb >= 2 && P.nb <= 3 && !std::getenv("POOLGEN_KIN_NO_WEIGHTS")) {
+        // the block size that runs the fewest tile slots over all pairs (T = 17: blocks of 6, 6, 5 tile columns = 13 slot units
+        // where 8, 8, 1 ran 16)
+        // (a pair with two slots is bound by its stage hand-over, not by its MFMAs: it costs about 2.7 slots' worth -- measured
+        //  at T = 14, where blocks of 7 + 7 (2, 2 and 4 slots) ran 5.98 ms against 5.46 ms for 8 + 6 (3, 2 and 3))
+        double best = 1e30;
+        int best_tb = P.Tb;
+        for (int tb = (P.T + P.nb - 1) / P.nb; tb <= 8; ++tb) {
+            double units = 0.0;
+            for (int bi = 0; bi < P.nb; ++bi)
+                for (int bj = bi; bj < P.nb; ++bj) {
+                    const int Ta = std::min(tb, P.T - bi * tb), Tbb = std::min(tb, P.T - bj * tb);
+                    if (Ta <= 0 || Tbb <= 0) { units += 1e6; continue; }
+                    const int tiles = bi == bj ? Ta * (Ta + 1) / 2 : Ta * Tbb;
+                    units += std::max(KIN_PAIR_FLOOR, (double)((tiles + KIN_WAVES - 1) / KIN_WAVES));
+                }
+            if (units <= best) { best = units; best_tb = tb; }
+        }
+        P.Tb = best_tb;
+    }
     P.split = (P.merged && P.nb == 2) ? 2 : 1;                                               // nb == 2: all 136 tiles, 68 + 68
     const int npairs = (P.merged ? P.nb * (P.nb - 1) / 2 : P.nb * (P.nb + 1) / 2) * P.split;
     int nslab = cus / npairs;
@@ -680,6 +721,48 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     if (npairs > 1 && cus % 8 == 0 && !std::getenv("POOLGEN_KIN_NO_XCD")) {
         const int spx = (cus / 8) / npairs;        // whole slabs (all their pairs) that fit one XCD's CUs
         if (spx >= 1 && 8 * spx <= nslab) P.xcd_spx = spx;
+    }
+    for (int q = 0; q < 6; ++q) { P.wq_n[q] = 0; P.wq_first[q] = 0; P.wq_len[q] = 0; }
+    KinCounts KC;
+    KC.blk = 0; KC.nb = P.nb;
+    for (int q = 0; q < 6; ++q) KC.n[q] = 0;
+    int grid1d = 0;
+    if (P.nb >= 2 && P.nb <= 3 && !P.merged && !std::getenv("POOLGEN_KIN_NO_WEIGHTS")) {
+        // tile slots a wave of pair (bi, bj) runs per k-step (the kernel's TPW) + a constant for its share of the staging
+        double wgt[6], wsum = 0.0;
+        int q = 0;
+        for (int bi = 0; bi < P.nb; ++bi)
+            for (int bj = bi; bj < P.nb; ++bj, ++q) {
+                const int Ta = std::min(P.Tb, P.T - bi * P.Tb), Tbb = std::min(P.Tb, P.T - bj * P.Tb);
+                const int tiles = bi == bj ? Ta * (Ta + 1) / 2 : Ta * Tbb;
+                wgt[q] = std::max(KIN_PAIR_FLOOR, (double)((tiles + KIN_WAVES - 1) / KIN_WAVES)) + 0.35;
+                wsum += wgt[q];
+            }
+        int used = 0;
+        for (q = 0; q < npairs; ++q) { P.wq_n[q] = std::max(1, (int)(cus * wgt[q] / wsum)); used += P.wq_n[q]; }
+        for (int left = cus - used; left > 0; --left) { // the CUs left over go where the slabs are longest
+            int best = 0;
+            for (q = 1; q < npairs; ++q)
+                if (wgt[q] / P.wq_n[q] > wgt[best] / P.wq_n[best]) best = q;
+            ++P.wq_n[best];
+        }
+        int first = 0, maxn = 0;
+        for (q = 0; q < npairs; ++q) {
+            int64_t len = (p + P.wq_n[q] - 1) / P.wq_n[q];
+            len = (len + KIN_KC - 1) / KIN_KC * KIN_KC;
+            if (len > max_loci_per_wg) len = max_loci_per_wg;
+            P.wq_len[q] = len;
+            P.wq_n[q] = (int)((p + len - 1) / len);
+            P.wq_first[q] = first;
+            first += P.wq_n[q];
+            maxn = std::max(maxn, P.wq_n[q]);
+            KC.n[q] = P.wq_n[q];
+        }
+        grid1d = first;
+        nslab = maxn;
+        P.nslab = nslab;
+        P.xcd_spx = 0;
+        KC.blk = P.Tb * 16;
     }
     const size_t slab_bytes = (size_t)nslab * P.npad * P.npad * sizeof(double);
     int rc = pg_ws_reserve(ctx, slab_bytes);
@@ -714,7 +797,8 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        if (P.xcd_spx) hipLaunchKernelGGL(kern, dim3(8 * ((P.xcd_spx * npairs) + ((nslab - 8 * P.xcd_spx) * npairs + 7) / 8)), dim3(KIN_THREADS), shmem,
+        if (grid1d) hipLaunchKernelGGL(kern, dim3(grid1d), dim3(KIN_THREADS), shmem, ctx->stream, P);
+        else if (P.xcd_spx) hipLaunchKernelGGL(kern, dim3(8 * ((P.xcd_spx * npairs) + ((nslab - 8 * P.xcd_spx) * npairs + 7) / 8)), dim3(KIN_THREADS), shmem,
                                           ctx->stream, P);
         else hipLaunchKernelGGL(kern, dim3(nslab, npairs), dim3(KIN_THREADS), shmem, ctx->stream, P);
         return hipSuccess;
@@ -750,7 +834,7 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     PG_HIP(ctx, hipGetLastError());
     pg_prof_begin(ctx, PG_K_KINSHIP_REDUCE);
     hipLaunchKernelGGL(k_kinship_reduce, dim3((n + 63) / 64, n), dim3(256), 0, ctx->stream,
-                       P.slabs, nslab, P.npad, n, add_intercept ? 1.0 : 0.0, S);
+                       P.slabs, nslab, P.npad, n, add_intercept ? 1.0 : 0.0, S, KC);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipGetLastError());
     return PG_OK;

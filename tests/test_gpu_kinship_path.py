@@ -34,7 +34,8 @@ def cmp_fit(got, ref, what=""):
 
 @pytest.mark.parametrize("p,n,ld", [(3000, 200, None), (777, 100, None), (513, 5, None), (100, 37, 38),
                                     (64, 16, 16), (1, 8, 8), (1000, 250, None), (300, 209, 210),
-                                    (700, 500, None), (333, 401, 402), (257, 385, 386), (200, 640, None)])
+                                    (700, 500, None), (333, 401, 402), (257, 385, 386), (200, 640, None),
+                                    (20011, 300, None), (9001, 224, None), (1030, 360, 362), (40000, 257, 258)])   # 2-3 pool blocks: weighted pairs
 def test_kinship_matches_oracle(engine, oracle, p, n, ld):
     G, _ = make(p, n, 11, ld=ld)
     S = engine.kinship_partial(G, n).cpu().numpy()
