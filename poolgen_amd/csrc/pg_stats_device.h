@@ -50,6 +50,40 @@ __device__ __forceinline__ double pg_t_two_sided_p(double t_abs, int df,
     return p > 1.0 ? 1.0 : p;
 }
 
+// Two tails at once: the same series for two arguments behind ONE stream of coefficient loads.  For a kernel that does nothing
+// but close fits (k_sweep_finish) the call is bound by the latency of its ~13 dependent 64-byte scalar loads, not by its 100
+// FMAs; two loci per lane halve that latency per locus.  Bit-identical to two calls of pg_t_two_sided_p.
+__device__ __forceinline__ void pg_t_two_sided_p_x2(double ta, double tb, int df, const double *__restrict__ coef, int ncoef,
+                                                    double &pa, double &pb) {
+    const double nu = (double)df;
+    const double ca = nu / (nu + ta * ta), cb2 = nu / (nu + tb * tb);
+    const double sa = sqrt(1.0 - ca), sb = sqrt(1.0 - cb2);
+    const double xa = ca * ca, ya = xa * xa, xb = cb2 * cb2, yb = xb * xb;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll 2
+    for (int b = ncoef - 8; b >= 0; b -= 8) {
+        const double *cb = coef + b; // wave-uniform: one s_load_dwordx16 for both arguments
+        a0 = fma(a0, ya, cb[4]); a1 = fma(a1, ya, cb[5]); a2 = fma(a2, ya, cb[6]); a3 = fma(a3, ya, cb[7]);
+        b0 = fma(b0, yb, cb[4]); b1 = fma(b1, yb, cb[5]); b2 = fma(b2, yb, cb[6]); b3 = fma(b3, yb, cb[7]);
+        a0 = fma(a0, ya, cb[0]); a1 = fma(a1, ya, cb[1]); a2 = fma(a2, ya, cb[2]); a3 = fma(a3, ya, cb[3]);
+        b0 = fma(b0, yb, cb[0]); b1 = fma(b1, yb, cb[1]); b2 = fma(b2, yb, cb[2]); b3 = fma(b3, yb, cb[3]);
+    }
+    const double polya = fma(fma(fma(a3, ca, a2), ca, a1), ca, a0), polyb = fma(fma(fma(b3, cb2, b2), cb2, b1), cb2, b0);
+    double Aa, Ab;
+    if (df & 1) {
+        const double c1 = sqrt(ca), c2 = sqrt(cb2);
+        Aa = 0.6366197723675814 * (atan2(sa, c1) + sa * c1 * polya); // 2/pi
+        Ab = 0.6366197723675814 * (atan2(sb, c2) + sb * c2 * polyb);
+    } else {
+        Aa = sa * polya;
+        Ab = sb * polyb;
+    }
+    pa = 1.0 - Aa; pa = pa < 0.0 ? 0.0 : pa; pa = pa > 1.0 ? 1.0 : pa;
+    pb = 1.0 - Ab; pb = pb < 0.0 ? 0.0 : pb; pb = pb > 1.0 ? 1.0 : pb;
+    if (isinf(ta)) pa = 0.0;
+    if (isinf(tb)) pb = 0.0;
+}
+
 // ---- statrs ln_gamma (Lanczos g = 10.900511, 11 terms) --------------------------------------
 __device__ __forceinline__ double pg_ln_gamma(double x) {
     const double dk[11] = {2.48574089138753565546e-5, 1.05142378581721974210,

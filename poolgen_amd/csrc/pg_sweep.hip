@@ -844,6 +844,37 @@ __global__ void k_sweep_finish(const double *__restrict__ spec, const double *__
     }
 }
 
+// One trait (the headline): two loci per lane, `half` apart, their p-value series behind one stream of coefficient loads
+// (pg_t_two_sided_p_x2).  The arithmetic per locus is ols_close's, operation for operation.
+__global__ __launch_bounds__(256) void k_sweep_finish_x2(const double *__restrict__ spec, const double *__restrict__ syy,
+                                                         const double *__restrict__ tcoef, double *__restrict__ beta,
+                                                         double *__restrict__ var, double *__restrict__ pval, const SweepDims D,
+                                                         int64_t half) {
+    const int64_t la = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, lb = la + half;
+    if (la >= half) return;
+    const bool hasb = lb < D.p;
+    const double *pa = spec + la * 3, *pb = spec + (hasb ? lb : la) * 3;
+    double ba, va, pva, bb, vbb, pvb, tta, ttb;
+    auto head = [&](const double *sp, double &b, double &vb, double &tt) -> bool { // false: rank-deficient, everything NaN
+        const double s1 = sp[0], s2 = sp[1];
+        const double sgg = s2 - s1 * s1 / (double)D.n;
+        b = NAN; vb = NAN; tt = 0.0;
+        if (!(sgg > D.tau * s2)) return false;
+        b = sp[2] / sgg;
+        double rss = syy[0] - sp[2] * b;
+        rss = rss < 0.0 ? 0.0 : rss;
+        vb = (rss / D.dfe) / sgg;
+        tt = (fabs(b) <= PG_EPS) ? 0.0 : b / sqrt(vb);
+        return true;
+    };
+    const bool oka = head(pa, ba, va, tta), okb = head(pb, bb, vbb, ttb);
+    pg_t_two_sided_p_x2(fabs(tta), fabs(ttb), D.tdf, tcoef, D.ntcoef, pva, pvb);
+    pva = !oka ? NAN : (fabs(tta) <= PG_EPS || isnan(tta)) ? 1.0 : pva;
+    pvb = !okb ? NAN : (fabs(ttb) <= PG_EPS || isnan(ttb)) ? 1.0 : pvb;
+    beta[la] = ba; var[la] = va; pval[la] = pva;
+    if (hasb) { beta[lb] = bb; var[lb] = vbb; pval[lb] = pvb; }
+}
+
 struct SweepArgs {
     const double *G, *W, *syy, *tcoef;
     double *beta, *var, *pval;
@@ -1262,8 +1293,13 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
         ctx->spec_ld == ld && ctx->spec_k == ctx->st_k && ctx->ph_n == n && ctx->st_Y_matches_ph) {
         // m = 0: the kinship pass already formed the sums of the intercept-only fits from its read of G
         pg_prof_begin(ctx, PG_K_SWEEP_FINISH);
-        hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ctx->spec_dev, ctx->syy_dev, ctx->tcoef_dev, beta_dev, var_dev, pval_dev, P.D);
+        if (ctx->st_k == 1 && !std::getenv("POOLGEN_FINISH_X1")) {
+            const int64_t half = ((p + 1) / 2 + 255) / 256 * 256;
+            hipLaunchKernelGGL(k_sweep_finish_x2, dim3((unsigned)(half / 256)), dim3(256), 0, ctx->stream, ctx->spec_dev, ctx->syy_dev,
+                               ctx->tcoef_dev, beta_dev, var_dev, pval_dev, P.D, half);
+        } else
+            hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->spec_dev, ctx->syy_dev, ctx->tcoef_dev, beta_dev, var_dev, pval_dev, P.D);
         pg_prof_end(ctx);
         PG_HIP(ctx, hipGetLastError());
         return PG_OK;
