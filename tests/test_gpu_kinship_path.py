@@ -61,11 +61,14 @@ def test_sweep_without_covariates(engine, oracle, p, n):
 
 
 @pytest.mark.parametrize("p,n,ld,off", [(1, 8, 8, 0), (7, 5, 6, 0), (129, 37, 40, 0), (1000, 200, 208, 0), (4097, 100, 100, 0),
-                                         (777, 200, 200, 3), (513, 100, 100, 1), (2049, 50, 50, 5), (300, 33, 34, 7), (640, 201, 202, 0)])
+                                         (777, 200, 200, 3), (513, 100, 100, 1), (2049, 50, 50, 5), (300, 33, 34, 7), (640, 201, 202, 0),
+                                         (1, 40, 40, 0), (63, 200, 200, 1), (65, 100, 124, 0), (17, 500, 500, 2), (4100, 68, 70, 0)])
 def test_sweep_row_geometries(engine, oracle, p, n, ld, off):
-    """The super-row kernel over awkward geometries: row pitches that put 1, 2, 4 or 8 loci into one line-aligned super-row
-    (ld = 208 / 200 / 100 / 50, 6, 34), padding columns between n and ld, odd n, a column count that is not a multiple of
-    the super-row, a single locus, and a matrix that starts in the middle of an allocation (a rank's slab: not line-aligned)."""
+    """The sweep kernels over awkward geometries (the matrix-core kernel from 33 pools up, the row kernel below): row pitches
+    that put 1, 2, 4 or 8 loci into one 128-byte-aligned run (ld = 208 / 200 / 100 / 50, 6, 34), padding columns between n and ld
+    (NaN there must never be read as data), odd n, pool counts that are not a multiple of the 8-pool chunk or of the load group,
+    fewer loci than one 16-locus tile or one 64-locus group, a single locus, and a matrix that starts in the middle of an
+    allocation (a rank's slab: not line-aligned)."""
     from poolgen_amd import synth
     Gfull = synth.genotype_matrix(p + off, n, "cuda", seed=77, ld=ld)
     if ld > n:
