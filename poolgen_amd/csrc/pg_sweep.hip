@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void k_sweep_finish_x2(const double *__restric
                                                          double *__restrict__ var, double *__restrict__ pval, const SweepDims D,
                                                          int64_t half) {
     const int64_t la = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, lb = la + half;
-    if (la >= half) return;
+    if (la >= half || la >= D.p) return; // (half is rounded up to the workgroup: fewer than 2 x 256 loci leave lanes with nothing)
     const bool hasb = lb < D.p;
     const double *pa = spec + la * 3, *pb = spec + (hasb ? lb : la) * 3;
     double ba, va, pva, bb, vbb, pvb, tta, ttb;

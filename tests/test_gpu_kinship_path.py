@@ -113,6 +113,22 @@ def test_full_path_default_threshold(engine, oracle):
     cmp_fit((beta, var, pv), ref, "full path")
 
 
+@pytest.mark.parametrize("p", [1, 64, 130, 255, 257, 511, 777, 1025])
+def test_fused_fits_stay_inside_their_outputs(engine, oracle, p):
+    """The m = 0 fits closed from the fused sums (two loci per lane, k_sweep_finish_x2): locus counts around the workgroup size,
+    outputs embedded in a sentinel-filled buffer that must come back untouched on both sides."""
+    n = 40
+    G, Y = make(p, n, 31)
+    big = torch.full((3, p + 512, 1), -7.25, dtype=torch.float64, device="cuda")
+    out = big[:, 256:256 + p, :]
+    m, K, beta, var, pv = engine.ols_with_covariate(G, Y[:, :1], 0.0, force_m=0, out=out)   # (force_m = 0: the fused path whatever K says)
+    assert m == 0
+    torch.cuda.synchronize()
+    assert bool((big[:, :256] == -7.25).all()) and bool((big[:, 256 + p:] == -7.25).all()), "wrote outside the output arrays"
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y[:, :1], force_m=0)
+    cmp_fit((beta, var, pv), ref, f"fused p={p}")
+
+
 def test_full_path_rule_picks_covariates(engine, oracle, exact):
     from test_gpu_exact import assert_close, formula_p
     p, n = 4000, 60
