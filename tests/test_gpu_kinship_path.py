@@ -129,6 +129,30 @@ def test_fused_fits_stay_inside_their_outputs(engine, oracle, p):
     cmp_fit((beta, var, pv), ref, f"fused p={p}")
 
 
+@pytest.mark.parametrize("n,k,m", [(40, 1, 0), (40, 2, 3), (20, 1, 0), (200, 1, 8), (72, 3, 20)])
+def test_sweep_stays_inside_its_outputs(engine, oracle, n, k, m):
+    """Every sweep kernel (matrix-core: one trait, several traits, two accumulators; row kernel for short rows), locus counts around
+    the 16-locus tile and the 64-locus group: the outputs sit in a sentinel-filled buffer that must come back untouched around them,
+    and G is followed by NaNs that must not be read as data."""
+    rng = np.random.default_rng(3)
+    for p in (1, 15, 16, 17, 63, 64, 65, 127, 129, 1000):
+        from poolgen_amd import synth
+        Gbig = torch.full((p + 70, n), float("nan"), dtype=torch.float64, device="cuda")
+        Gbig[:p] = synth.genotype_matrix(p, n, "cuda", seed=p)
+        G = Gbig[:p]
+        Y = synth.phenotypes(synth.genotype_matrix(500, n, "cuda", seed=5), n, k=2, seed=5)
+        Y = np.hstack([Y, Y[:, :1] ** 2])[:, :k]
+        C = None if m == 0 else np.linalg.qr(rng.normal(size=(n, m)))[0]
+        engine.covariates_set(n, C, Y)
+        big = torch.full((3, p + 512, k), -7.25, dtype=torch.float64, device="cuda")
+        out = big[:, 256:256 + p, :]
+        got = engine.ols_sweep(G, k, n, out)
+        torch.cuda.synchronize()
+        assert bool((big[:, :256] == -7.25).all()) and bool((big[:, 256 + p:] == -7.25).all()), f"p={p}: wrote outside the output arrays"
+        ref = oracle.ols_with_covariate(G.cpu().numpy(), Y, covariate=C, n=n) if m else oracle.ols_with_covariate(G.cpu().numpy(), Y, force_m=0)
+        cmp_fit(got, ref, f"n={n} k={k} m={m} p={p}")
+
+
 def test_full_path_rule_picks_covariates(engine, oracle, exact):
     from test_gpu_exact import assert_close, formula_p
     p, n = 4000, 60
