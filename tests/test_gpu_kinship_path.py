@@ -153,6 +153,32 @@ def test_sweep_stays_inside_its_outputs(engine, oracle, n, k, m):
         cmp_fit(got, ref, f"n={n} k={k} m={m} p={p}")
 
 
+def test_sweep_random_shapes(engine, oracle):
+    """Forty seeded random shapes (pools 2 .. 300, row pitch n .. n + 40, 1-3 traits, 0-12 well-conditioned covariates, loci 1 .. 3000,
+    slab offsets) through whichever sweep kernel the library picks, against the oracle."""
+    from poolgen_amd import synth
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        n = int(rng.integers(5, 301))
+        k = int(rng.integers(1, 4))
+        m = int(rng.integers(0, min(12, n - 4) + 1)) if n >= 8 else 0
+        ld = n + 2 * int(rng.integers(0, 21)); ld += ld & 1
+        p = int(rng.integers(1, 3001))
+        off = int(rng.integers(0, 9))
+        Gfull = synth.genotype_matrix(p + off, n, "cuda", seed=1000 + case, ld=ld)
+        if ld > n:
+            Gfull[:, n:] = float("nan")
+        G = Gfull[off:]
+        Y = synth.phenotypes(synth.genotype_matrix(400, n, "cuda", seed=7), n, k=2, seed=case)
+        Y = np.hstack([Y, Y[:, :1] ** 2])[:, :k]
+        C = None if m == 0 else np.linalg.qr(rng.normal(size=(n, m)))[0]
+        engine.covariates_set(n, C, Y)
+        got = engine.ols_sweep(G, k, n)
+        Gh = np.ascontiguousarray(G.cpu().numpy()[:, :n])
+        ref = oracle.ols_with_covariate(Gh, Y, covariate=C, n=n) if m else oracle.ols_with_covariate(Gh, Y, force_m=0)
+        cmp_fit(got, ref, f"case {case}: n={n} ld={ld} k={k} m={m} p={p} off={off}")
+
+
 def test_full_path_rule_picks_covariates(engine, oracle, exact):
     from test_gpu_exact import assert_close, formula_p
     p, n = 4000, 60
