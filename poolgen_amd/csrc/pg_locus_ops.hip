@@ -570,6 +570,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
 #else
         if (pre.valid) { lastD = pre.D; lasts = pre.s; advance(pre); }
 #endif
+        if (!cur.valid) return; // (past the wave's last unit: see the main loop)
         if (s == 0) {
             A.clear();
 #pragma unroll
@@ -623,15 +624,13 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
     };
 
     static_for<0, LN_DEPTH>([&](auto kc) { prefetch(kc); });
-    for (;;) {
-        bool stop = false;
-        static_for<0, LN_DEPTH>([&](auto kc) {
-            if (!stop) {
-                step(kc);
-                stop = !cur.valid;
-            }
-        });
-        if (stop) break;
+    // Whole turns of the ring and no exit from inside one: with a test after every step the compiler's wait-count pass loses the
+    // order of the loads and makes ring slot 0 wait for ALL outstanding loads (vmcnt(7..0) where vmcnt(23..16) is right), i.e. the
+    // pipeline drained every LN_DEPTH-th stage.  (Found in the sweep kernel, where it cost 10 %; here the other waves of the CU
+    // covered the drain: 0.573 ms before and after at 100 pools x 1 M loci.)  The steps of the last turn that lie past the wave's
+    // last unit land and re-issue dummy loads and do nothing else.
+    while (cur.valid) {
+        static_for<0, LN_DEPTH>([&](auto kc) { step(kc); });
     }
 }
 
