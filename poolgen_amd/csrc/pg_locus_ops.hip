@@ -458,8 +458,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
     uint4_t S[LN_DEPTH][8]; // LN_DEPTH stages of loads in flight per lane
     Sums<OP, NJ, K> A;
     double q[NJ];
-    uint32_t orc[NJ];
-    double mincov = 0.0;
+    double mincov = INFINITY;
     int n_missing = 0;
 
     // a unit's descriptor: first row, start offset inside its line, lines per row, buffer resource.
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
         double cd[NJ], f[NJ];
         double rs = 0.0; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { cd[j] = (double)c[j]; rs = rs + cd[j]; orc[j] |= c[j]; }
+        for (int j = 0; j < NJ; ++j) { cd[j] = (double)c[j]; rs = rs + cd[j]; }
         const bool rowok = rs != 0.0;
         // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0,
         // divided by 1) and the pool is counted in n_missing, which poisons / skips what NaN would
@@ -511,7 +510,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
         const double rinv = recip_for_div(rsd);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) f[j] = div_by(cd[j], rsd, rinv);
-        mincov = (pi == 0 || rs < mincov) ? rs : mincov;   // sync.rs:223-227
+        mincov = fmin(mincov, rs);                         // sync.rs:223-227 (starts at +inf: one v_min instead of compare + selects)
         n_missing += rowok ? 0 : 1;
         const double wi = w[pi];
         // q += f * w_i with separate multiply and add; NaN frequencies contribute 0 (sync.rs:258-271)
@@ -574,8 +573,8 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
         if (s == 0) {
             A.clear();
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) { q[j] = 0.0; orc[j] = 0u; }
-            mincov = 0.0;
+            for (int j = 0; j < NJ; ++j) q[j] = 0.0;
+            mincov = INFINITY;
             n_missing = 0;
             done = 0;
         }
@@ -602,7 +601,9 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
             for (int j = 0; j < NJ; ++j) {
                 kp[j] = !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
                 nk += kp[j] ? 1 : 0;
-                dropped_with_reads = dropped_with_reads || (!kp[j] && orc[j] != 0u);
+                // "has reads" = a positive column sum of the frequencies: a count > 0 makes its pool covered and its frequency > 0
+                // (>= 1 / (6 * 2^32)), and sums of non-negative terms do not cancel -- one compare here instead of an OR per pool
+                dropped_with_reads = dropped_with_reads || (!kp[j] && A.cs[j] != 0.0);
             }
             bool alive = !(mincov < P.min_cov);                                        // sync.rs:227
             alive = alive && nk >= 2;                                                  // sync.rs:284
