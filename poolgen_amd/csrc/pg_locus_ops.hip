@@ -450,10 +450,21 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
     const int cu = period > LO_WAVES ? period : LO_WAVES;   // units per chunk
     const int64_t nchunks = (nunits + cu - 1) / cu;
 
-    // staging assignment: lane -> (row g8 of 8, 16-byte piece of the line)
+    // staging assignment.  LN_MAP16 (default): a load instruction takes 64 bytes of 16 rows (lane: row lane & 15, 16-byte piece
+    // lane >> 4), the two halves of a line in consecutive instructions -- the access shape tools/mb_msweep.hip measured at 6.4 TB/s
+    // on 2.4 KB rows where 8 rows x 128 bytes per instruction (LN_MAP16 = 0: lane -> row lane >> 3, piece lane & 7) reaches 5.8.
+#ifndef LN_MAP16
+#define LN_MAP16 1
+#endif
+#if LN_MAP16
+    const int g16 = lane & 15, piece4 = lane >> 4;
+    const uint32_t vbase = (uint32_t)g16 * pstride + (uint32_t)piece4 * 16u;
+    char *tstore = tile + g16 * LN_PITCH + piece4 * 16;
+#else
     const int g8 = lane >> 3, piece = lane & 7;
     const uint32_t vbase = (uint32_t)g8 * pstride + (uint32_t)piece * 16u;
     char *tstore = tile + g8 * LN_PITCH + piece * 16;
+#endif
 
     uint4_t S[LN_DEPTH][8]; // LN_DEPTH stages of loads in flight per lane
     Sums<OP, NJ, K> A;
@@ -489,13 +500,21 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
         const uint32_t v0 = vbase + (uint32_t)s * 128u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) // the whole offset goes through the VGPR: the scalar offset is not range-checked on gfx9
+#if LN_MAP16
+            S[k][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (uint32_t)(j >> 1) * 16u * pstride + (uint32_t)(j & 1) * 64u, 0, 0);
+#else
             S[k][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (uint32_t)j * 8u * pstride, 0, 0);
+#endif
     };
     auto land = [&](auto kc, int s) {
         constexpr int k = decltype(kc)::value;
         char *p = tstore + (s & 1) * 128;
 #pragma unroll
+#if LN_MAP16
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4_t *>(p + (j >> 1) * (16 * LN_PITCH) + (j & 1) * 64) = S[k][j];
+#else
         for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4_t *>(p + j * (8 * LN_PITCH)) = S[k][j];
+#endif
     };
     // one pool of this lane's locus
     auto pool = [&](const uint32_t (&c)[NJ], int pi) {

@@ -145,5 +145,14 @@ int main(int argc, char **argv) {
         printf("grid %4d  32 B / lane, 52 MFMA + 52 FMA per tile                    : %8.3f ms %8.1f GB/s\n", grid, ms, bytes / ms / 1e6);
         if (mult == 8) check("32 B / lane");
     }
+    {   // the count operators' row length (24 n bytes at n = 100 = 2400 B; here 296 doubles = 2368 B = 37 chunks), loads only
+        const long long ld2 = 296, p2 = (long long)(gib * (1ull << 30) / (8.0 * ld2)) / 16 * 16;
+        const double bytes2 = (double)p2 * ld2 * 8;
+        for (int mult : {8, 16}) {
+            float ms = timeit(k_msweep<37, 0, false>, cus * mult, (const double *)G, p2 / 16, ld2, (const double *)Wt, (double *)nullptr);
+            printf("grid %4d  rows of %lld B, 16 B / lane (16 rows x 64 B per instruction), loads only : %8.3f ms %8.1f GB/s\n", cus * mult, ld2 * 8, ms,
+                   bytes2 / ms / 1e6);
+        }
+    }
     return 0;
 }
