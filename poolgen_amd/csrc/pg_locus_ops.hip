@@ -600,7 +600,10 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
         int hi = (int)((128u * (uint32_t)(s + 1) - delta) / 24u); // pools complete once line s has landed
         hi = hi < n ? hi : n;
 #ifndef LN_EXP_NOCOMPUTE
-#pragma unroll 2
+#ifndef LN_UNROLL
+#define LN_UNROLL 1 // measured 1 .. 4 at 100 pools x 1 M loci: 0.549 / 0.564 / 0.555 / 0.562 ms (ols_iter), 0.625 / 0.653 / 0.646 / 0.735 (pearson_corr)
+#endif
+#pragma unroll LN_UNROLL
         for (int i = done; i < hi; ++i) {
             uint32_t e[NJ];
             read_pool(delta + 24u * (uint32_t)i, e);
