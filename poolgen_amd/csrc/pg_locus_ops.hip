@@ -31,8 +31,14 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-constexpr int LO_THREADS = 256;
-constexpr int LO_WAVES = 4;
+#ifndef LO_WAVES_DEF
+#define LO_WAVES_DEF 4   // waves per workgroup of the streaming kernels
+#endif
+#ifndef LO_BLOCKS_DEF
+#define LO_BLOCKS_DEF 2  // workgroups per CU they are compiled for
+#endif
+constexpr int LO_WAVES = LO_WAVES_DEF;
+constexpr int LO_THREADS = 64 * LO_WAVES;
 constexpr int LO_CHP = 8;                 // pools per stage
 constexpr int LO_ROWB = LO_CHP * 24;      // 192 bytes of counts per locus per stage
 constexpr int LO_PITCH = LO_ROWB + 16;    // 208: odd number of 16-byte slots
@@ -421,12 +427,12 @@ __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poiso
 constexpr int LN_PITCH = 272;
 constexpr int LN_TILEB = 64 * LN_PITCH;
 #ifndef LN_DEPTH_DEF
-#define LN_DEPTH_DEF 3
+#define LN_DEPTH_DEF 1
 #endif
 constexpr int LN_DEPTH = LN_DEPTH_DEF;
 
 template <int OP, bool RNS, int K>
-__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_first(
+__global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
     const uint32_t *__restrict__ counts, const double *__restrict__ w, const double *__restrict__ Y,
     int32_t *__restrict__ rec_flags, double *__restrict__ rec, unsigned long long *__restrict__ unit_again,
     const LocusParams P, const int period) {
@@ -1118,7 +1124,7 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     const int64_t ntiles = (L + 63) / 64;
     int64_t blocks = (ntiles + LO_WAVES - 1) / LO_WAVES;
 #ifndef LO_GRID_PER_CU
-#define LO_GRID_PER_CU 2
+#define LO_GRID_PER_CU LO_BLOCKS_DEF
 #endif
     const int64_t cap = (int64_t)cus * LO_GRID_PER_CU; // = the resident blocks (2 waves/SIMD): one long item sequence per wave
     const int grid = (int)(blocks < cap ? blocks : cap);
