@@ -419,12 +419,12 @@ __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poiso
 // rows of one alignment class (rows r0, r0 + period, ...): every lane streams its row line by line,
 // all lanes see the same pools complete at the same stage, so the pool loop and the w / Y operands
 // stay wave-uniform.  Stage s = line s of each of the 64 rows: 8 x (8 rows x 128 B) buffer loads per
-// lane-group into a 2-line ring per row in LDS (pitch 272 B = 17 x 16: conflict-free row-wise reads);
+// lane-group into ONE line per row in LDS (pitch 144 B = 9 x 16: conflict-free row-wise reads);
 // a pool that straddles two lines is read across the ring.  The descriptor covers the unit's lines
 // only (a line that holds a valid byte lies in the same page as that byte, so whole-line reads are
 // safe at both ends of the batch), out-of-range lines come back as zeros, and the (unit, stage) pairs
 // of a wave form ONE flat sequence whose next loads are in flight while the current stage computes.
-constexpr int LN_PITCH = 272;
+constexpr int LN_PITCH = 144;  // one 128-byte line per row + 16: an odd number of 16-byte slots (conflict-free row-wise reads)
 constexpr int LN_TILEB = 64 * LN_PITCH;
 #ifndef LN_DEPTH_DEF
 #define LN_DEPTH_DEF 1
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *tile = lds_raw + wave * LN_TILEB;
-    const char *rowp = tile + lane * LN_PITCH; // this lane's 2-line ring
+    const char *rowp = tile + lane * LN_PITCH; // this lane's row: the line of the current stage
     const int n = P.n;
     const int64_t L = P.L;
     const uint32_t rowb = (uint32_t)n * 24u;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
     };
     auto land = [&](auto kc, int s) {
         constexpr int k = decltype(kc)::value;
-        char *p = tstore + (s & 1) * 128;
+        char *p = tstore;
 #pragma unroll
 #if LN_MAP16
         for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4_t *>(p + (j >> 1) * (16 * LN_PITCH) + (j & 1) * 64) = S[k][j];
@@ -543,14 +543,28 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
         for (int j = 0; j < NJ; ++j) q[j] = q[j] + f[j] * wi;
         A.add_pool(f, rowok, Y + (size_t)pi * K);
     };
-    auto read_pool = [&](uint32_t ring_off, uint32_t (&e)[NJ]) {
-        // 24 bytes at ring offset ring_off (a multiple of 8), possibly wrapping around the 256-byte ring
-        const uint2_t a = *reinterpret_cast<const uint2_t *>(rowp + (ring_off & 255u));
-        const uint2_t b = *reinterpret_cast<const uint2_t *>(rowp + ((ring_off + 8u) & 255u));
-        const uint2_t d = *reinterpret_cast<const uint2_t *>(rowp + ((ring_off + 16u) & 255u));
+    // LDS holds ONE line per row (the line of the current stage).  A pool (24 bytes) that starts in the previous line leaves 8 or
+    // 16 bytes there: the last 16 bytes of every line are carried over in registers (cy0, cy1) before the next line overwrites it.
+    // (Two lines per row -- 17 KB of LDS per wave -- measured 6-8 % slower.)
+    uint2_t cy0 = {0u, 0u}, cy1 = {0u, 0u};
+    auto unpack_pool = [&](const uint2_t &a, const uint2_t &b, const uint2_t &d, uint32_t (&e)[NJ]) {
         const uint32_t c0[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) e[j] = c0[aj(j)];
+    };
+    auto read_pool = [&](uint32_t off, uint32_t (&e)[NJ]) { // 24 bytes at offset off (a multiple of 8, <= 104) of the current line
+        const uint2_t a = *reinterpret_cast<const uint2_t *>(rowp + off);
+        const uint2_t b = *reinterpret_cast<const uint2_t *>(rowp + off + 8u);
+        const uint2_t d = *reinterpret_cast<const uint2_t *>(rowp + off + 16u);
+        unpack_pool(a, b, d, e);
+    };
+    auto read_pool_across = [&](int old_bytes, uint32_t (&e)[NJ]) { // old_bytes (8 or 16, wave-uniform) of the pool sit in the carry
+        const uint2_t n0 = *reinterpret_cast<const uint2_t *>(rowp);
+        if (old_bytes == 16) unpack_pool(cy0, cy1, n0, e);
+        else {
+            const uint2_t n1 = *reinterpret_cast<const uint2_t *>(rowp + 8u);
+            unpack_pool(cy1, n0, n1, e);
+        }
     };
 
     // flat (unit, stage) sequence of this wave: chunk -> unit inside the chunk -> stage.  Two cursors
@@ -587,6 +601,12 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
         const int nlines = cur.D.nlines;
         const int64_t r0 = cur.D.r0;
         __builtin_amdgcn_wave_barrier();
+        { // the tail of the line that is about to be overwritten
+            const uint4_t tl = *reinterpret_cast<const uint4_t *>(rowp + 112);
+            cy0 = uint2_t{tl.x, tl.y};
+            cy1 = uint2_t{tl.z, tl.w};
+        }
+        __builtin_amdgcn_wave_barrier();
 #ifndef LN_EXP_NOLOAD
         land(kc, s);
         __builtin_amdgcn_wave_barrier();
@@ -609,14 +629,21 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
 #ifndef LN_UNROLL
 #define LN_UNROLL 1 // measured 1 .. 4 at 100 pools x 1 M loci: 0.549 / 0.564 / 0.555 / 0.562 ms (ols_iter), 0.625 / 0.653 / 0.646 / 0.735 (pearson_corr)
 #endif
+        const int lo0 = (int)(delta + 24u * (uint32_t)done) - 128 * s; // offset of the stage's first pool in this line: >= 0, -8 or -16
+        if (done < hi && lo0 < 0) {
+            uint32_t e[NJ];
+            read_pool_across(-lo0, e);
+            pool(e, done);
+            ++done;
+        }
 #pragma unroll LN_UNROLL
         for (int i = done; i < hi; ++i) {
             uint32_t e[NJ];
-            read_pool(delta + 24u * (uint32_t)i, e);
+            read_pool(delta + 24u * (uint32_t)i - 128u * (uint32_t)s, e);
             pool(e, i);
         }
 #else
-        if (hi == 12345) { uint32_t e[NJ]; read_pool(delta, e); pool(e, 0); }
+        if (hi == 12345) { uint32_t e[NJ]; read_pool(0u, e); pool(e, 0); }
 #endif
         done = hi;
         if (s == nlines - 1) {
