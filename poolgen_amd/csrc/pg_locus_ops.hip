@@ -525,13 +525,15 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
     // one pool of this lane's locus
     auto pool = [&](const uint32_t (&c)[NJ], int pi) {
         double cd[NJ], f[NJ];
-        double rs = 0.0; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { cd[j] = (double)c[j]; rs = rs + cd[j]; }
+        for (int j = 0; j < NJ; ++j) cd[j] = (double)c[j];
+        double rs = cd[0]; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175); 0 + c0 = c0 exactly
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) rs = rs + cd[j];
         const bool rowok = rs != 0.0;
         // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0,
         // divided by 1) and the pool is counted in n_missing, which poisons / skips what NaN would
-        const double rsd = rowok ? rs : 1.0;
+        const double rsd = fmax(rs, 1.0); // rs is a whole number >= 0: 1 for an uncovered pool, rs otherwise (one instruction)
         const double rinv = recip_for_div(rsd);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) f[j] = div_by(cd[j], rsd, rinv);
