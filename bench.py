@@ -16,13 +16,15 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# torch / numpy are imported by the RANK processes only (worker()): the launching parent of `--gpus N` must never initialise a GPU
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -31,7 +33,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, fp64 matrix (not in the local guide)
 
 
-def cpu_baseline(G_sample_host: np.ndarray, Y: np.ndarray, var_explained: float, force_m: int):
+def cpu_baseline(G_sample_host, Y, var_explained: float, force_m: int):
     """The oracle (a port of the reference algorithm), timed on this box's host cores."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib
@@ -66,7 +68,83 @@ def cpu_baseline(G_sample_host: np.ndarray, Y: np.ndarray, var_explained: float,
                       f"per-locus LU fits, OpenMP over loci, {dt:.1f} s"}
 
 
-def main():
+def secondary_legs(eng, dev, args, torch, np):
+    """BASELINE configs[1] (ols_iter / pearson_corr / chisq_test from counts, 100 pools x 1M loci) and configs[3] (ridge lambda path
+    with 10 x 10-fold CV, 500 pools x 5M loci), each a few launches on resident synthetic inputs with HIP-event kernel times
+    (pg_profile_get: one event pair per operator call, on the library's stream).  Untimed with respect to the headline `value`."""
+    from poolgen_amd import Filter, synth
+    t_all = time.perf_counter()
+    sec = {"what": "untimed legs after the headline region; kernel_ms = HIP events around the operator's kernels on the library's "
+                   "stream (mean over `launches`); frac = algorithmic bytes (or flops) per launch / kernel time / peak"}
+    # configs[1]: 24 n bytes of counts per locus (SURVEY 8d: integer front-end, bytes/locus = 4*6*n)
+    n1, L1 = 100, int(args.secondary_loci)
+    counts = synth.sync_counts(L1, n1, dev)
+    G1 = synth.genotype_matrix(min(L1, 1 << 18), n1, dev)
+    Y1 = synth.phenotypes(G1, n1, k=1)
+    del G1
+    ps = np.full(n1, 20.0)
+    flt = Filter()
+    ops = {}
+    for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(counts, ps, flt, Y1), "ols_iter"),
+                          ("pearson_corr", lambda: eng.correlation(counts, ps, flt, Y1), "pearson"),
+                          ("chisq_test", lambda: eng.chisq(counts, ps, flt), "chisq")):
+        fn(); fn()
+        eng.profile_reset()
+        reps = 10
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t0) / reps
+        ms, cnt = eng.profile_get(kid)
+        kms = ms / max(cnt, 1)
+        by = 24.0 * n1 * L1
+        ops[name] = {"kernel_ms": kms, "launches": int(cnt), "bytes_per_launch": by, "achieved_gbs": by / (kms * 1e-3) / 1e9,
+                     "frac": by / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "wall_ms_per_call": wall * 1e3, "loci_per_s": L1 / (kms * 1e-3)}
+    sec["count_operators"] = {"config": f"BASELINE configs[1]: synthetic sync counts {n1} pools x {L1} loci, 1 trait, CLI default filter",
+                              "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_locus": 24.0 * n1, **ops}
+    del counts
+    # configs[3]: ridge path (alpha = 0), 11 lambda, 10 repetitions x 10 folds, folds fixed by fold[i] = (i + rep) mod 10
+    n3, p3, reps3, folds3 = 500, int(args.ridge_loci), 10, 10
+    try:
+        G3 = synth.genotype_matrix(p3, n3, dev)
+        Y3 = synth.phenotypes(G3[:100000], n3, k=1)
+        rows = np.arange(n3)
+        fold_of = np.stack([(rows + r) % folds3 for r in range(reps3)]).astype(np.int32)
+        eng.gp_ridge(G3, Y3, rows, fold_of, folds3, n=n3)
+        eng.profile_reset()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        beta, lam, perf = eng.gp_ridge(G3, Y3, rows, fold_of, folds3, n=n3)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        x_ms, x_n = eng.profile_get("gp_xxt")
+        b_ms, b_n = eng.profile_get("gp_beta")
+        pr_ms, pr_n = eng.profile_get("gp_predict")
+        gb = 8.0 * n3 * p3
+        xfl = 2.0 * n3 * n3 * (p3 + 1)
+        rd = {"config": f"BASELINE configs[3]: ridge lambda path, {n3} pools x {p3} loci, {reps3} repetitions x {folds3} folds, 11 lambda",
+              "wall_s": wall, "lambda": [float(x) for x in np.asarray(lam).ravel()],
+              "xxt": {"kernel_ms": x_ms / max(x_n, 1), "launches": int(x_n), "flops_per_launch": xfl, "bound": "mfma",
+                      "achieved_tflops_algorithmic": xfl / (x_ms / max(x_n, 1) * 1e-3) / 1e12 if x_n else None,
+                      "note": "2 n^2 (p+1) / time as SURVEY 8d counts it; one triangle is computed, so this is not a utilisation"},
+              "coefficient_pass": {"kernel_ms": b_ms / max(b_n, 1), "launches": int(b_n), "bytes_per_launch": gb, "bound": "hbm",
+                                   "achieved_gbs": gb / (b_ms / max(b_n, 1) * 1e-3) / 1e9 if b_n else None,
+                                   "frac": gb / (b_ms / max(b_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if b_n else None},
+              "prediction_pass": {"kernel_ms": pr_ms / max(pr_n, 1), "launches": int(pr_n), "bytes_per_launch": gb, "bound": "hbm",
+                                  "achieved_gbs": gb / (pr_ms / max(pr_n, 1) * 1e-3) / 1e9 if pr_n else None,
+                                  "frac": gb / (pr_ms / max(pr_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if pr_n else None},
+              "passes_over_G": int(b_n + pr_n + x_n)}
+        sec["ridge"] = rd
+        del G3
+    except Exception as e:   # a leg that cannot run (e.g. not enough free HBM next to the headline's G) is reported, not fatal
+        sec["ridge"] = {"error": f"{type(e).__name__}: {e}"}
+    sec["seconds"] = time.perf_counter() - t_all
+    return sec
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -79,16 +157,149 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep-legs", action="store_true", help="skip the two untimed legs that measure k_ols_sweep_mfma")
     ap.add_argument("--sweep-steps", type=int, default=5, help="steps per sweep leg (after the timed region)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the untimed BASELINE configs[1] / configs[3] legs (count operators 100 x 1M, ridge path 500 x 5M)")
+    ap.add_argument("--secondary-loci", type=int, default=1_000_000, help="loci of the count-operator leg (configs[1]: 1M)")
+    ap.add_argument("--ridge-loci", type=int, default=5_000_000, help="loci of the ridge leg (configs[3]: 5M)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
-    args = ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="seconds the self-launching parent of --gpus N > 1 waits for its rank processes before it kills them")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _kill_group(proc):
+    """End one rank process we started (and whatever it started): its own process group, by id -- never by pattern."""
+    if proc.poll() is not None:
+        return
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            proc.wait(timeout=10)
+            return
+        except subprocess.TimeoutExpired:
+            continue
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the
+    launcher.  It starts N rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU,
+    each in its own process group), waits for them under --launch-timeout, relays rank 0's ONE JSON line and exits non-zero
+    if any rank failed or hung (every rank is then killed by pid).  It never imports torch, never creates an Engine and never
+    re-execs itself: nothing here has initialised a GPU.  The reference's counterpart is the thread-per-chunk fan-out of
+    base/sync.rs:913-939 with the one reduction of gwas/ols.rs:291-295 inside the ranks."""
+    n = args.gpus
+    port = _free_port()
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool's driver (RCCL needs it across processes)
+    env0.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                POOLGEN_BENCH_LAUNCHED="1")
+    procs, logs = [], []
+    tmp = tempfile.mkdtemp(prefix="poolgen_bench_")
+    try:
+        for r in range(n):
+            env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+            out = open(os.path.join(tmp, f"rank{r}.out"), "w+")
+            err = open(os.path.join(tmp, f"rank{r}.err"), "w+")
+            logs.append((out, err))
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env, stdout=out,
+                                          stderr=err, cwd=str(ROOT), start_new_session=True))
+        deadline = time.monotonic() + args.launch_timeout
+        failed = None
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                alive = [r for r, c in enumerate(codes) if c is None]
+                failed = f"ranks {alive} still running after --launch-timeout {args.launch_timeout:.0f} s (hung?)"
+                break
+            time.sleep(0.2)
+        if failed:
+            # a rank that died leaves the others inside a collective: give them a moment to notice, then end them
+            t_end = time.monotonic() + 5.0
+            while time.monotonic() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+            for p in procs:
+                _kill_group(p)
+        def tail(f, nbytes=3000):
+            f.flush(); f.seek(0); s = f.read(); return s[-nbytes:]
+        if failed:
+            print(f"bench.py --gpus {n}: {failed}; all ranks ended", file=sys.stderr)
+            for r, (out, err) in enumerate(logs):
+                t = tail(err).strip()
+                if t:
+                    print(f"---- rank {r} stderr (tail) ----\n{t}", file=sys.stderr)
+            return 1
+        for r, (out, err) in enumerate(logs):   # warnings of the ranks stay visible
+            t = tail(err, 1500).strip()
+            if t:
+                print(f"---- rank {r} stderr (tail) ----\n{t}", file=sys.stderr)
+        lines = [l for l in tail(logs[0][0], 1 << 20).splitlines() if l.startswith("{")]
+        if len(lines) != 1:
+            print(f"bench.py --gpus {n}: rank 0 printed {len(lines)} JSON lines, expected 1", file=sys.stderr)
+            return 1
+        print(lines[0])
+        return 0
+    finally:
+        for p in procs:
+            _kill_group(p)
+        for out, err in logs:
+            out.close(); err.close()
+        try:
+            for f in os.listdir(tmp):
+                os.unlink(os.path.join(tmp, f))
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    worker(args)
+
+
+def worker(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)   # one rank per GPU; wraps only in the 1-GPU rehearsal below
+    if os.environ.get("POOLGEN_BENCH_TEST_HANG") in (str(rank), "all"):   # tests/test_bench_launcher.py: a rank that never comes back
+        time.sleep(3600)
+    if world != args.gpus:
+        # a launcher that disagrees with --gpus is a mistake in the command, not something to paper over: the line would
+        # carry an n_gpus the driver did not ask for
+        if rank == 0:
+            print(f"error: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    ndev = torch.cuda.device_count()          # does not initialise the GPU
+    rehearsal = os.environ.get("POOLGEN_BENCH_BACKEND", "nccl") != "nccl"
+    if world > ndev and not rehearsal:
+        if rank == 0:
+            print(f"error: --gpus {world} but only {ndev} GPU(s) are visible (POOLGEN_BENCH_BACKEND=gloo rehearses the control "
+                  f"flow with several ranks on one GPU; it is never a measurement)", file=sys.stderr)
+        sys.exit(2)
+    dev_index = local_rank % max(ndev, 1)   # one rank per GPU; wraps only in the 1-GPU rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     # POOLGEN_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, library communicator, all-reduce, barriers) with
@@ -118,12 +329,20 @@ def main():
     # library cannot set its communicator up (reported in the JSON line as "allreduce").
     allreduce_impl = "none (1 rank)"
     if use_dist:
-        try:
-            allreduce_impl = "RCCL inside libpoolgen_hip (pg_allreduce_sum_dev)" if setup_comm(eng, force=force_dist) else \
-                f"torch.distributed ({os.environ.get('POOLGEN_BENCH_BACKEND', 'nccl')})"
-        except Exception as e:  # keep the run alive: the scaling numbers are worth more than the purity of the path
-            print(f"warning: library communicator unavailable ({e}); using torch.distributed all_reduce", file=sys.stderr)
-            allreduce_impl = "torch.distributed (library communicator failed: %s)" % type(e).__name__
+        # setup_comm answers the same on every rank (its stages end in agreements over torch.distributed), so either every
+        # rank all-reduces inside the library or every rank uses dist.all_reduce -- never a mixture
+        if setup_comm(eng, force=force_dist):
+            allreduce_impl = "RCCL inside libpoolgen_hip (pg_allreduce_sum_dev)"
+        else:
+            allreduce_impl = f"FALLBACK torch.distributed all_reduce ({os.environ.get('POOLGEN_BENCH_BACKEND', 'nccl')}): " \
+                             f"the library communicator was not set up on every rank"
+            if rank == 0:
+                print("warning: " + allreduce_impl, file=sys.stderr)
+    comm_size = int(eng.comm_size)          # pg_comm_size: the ranks the LIBRARY's communicator spans (1 without one)
+    try:
+        rccl_version = int(eng.comm_version()) if use_dist else None   # ncclGetVersion of the RCCL the library loaded
+    except Exception:
+        rccl_version = None
     G = synth.genotype_matrix(p_local, n, dev, start=lo, ld=(args.ld or None))
     # phenotype: 10 causal loci spread over the WHOLE matrix; any rank can regenerate any locus
     causal = [(p_total * (2 * i + 1)) // 20 for i in range(10)]
@@ -199,6 +418,10 @@ def main():
             ls_ms, ls_n = eng.profile_get("sweep")
             legs[tag] = dict(m=int(lm), ms_per_step=ldt / extra * 1e3, kin_avg=lk_ms / max(lk_n, 1),
                              sw_avg=ls_ms / max(ls_n, 1), sw_n=int(ls_n))
+    # ---- BASELINE configs[1] and configs[3], driver-visible: after the timed region, bounded, 1 GPU only ----
+    secondary = None
+    if world == 1 and not args.no_secondary and args.force_m < 0:
+        secondary = secondary_legs(eng, dev, args, torch, np)
     eng.profile(False)
 
     if rank == 0:
@@ -251,7 +474,11 @@ def main():
             "config": {"workload": f"ols_iter_with_kinship {n} pools x {p_total} loci (BASELINE configs[2])",
                        "pools": n, "loci_total": p_total, "loci_per_gpu": p_local, "traits": k,
                        "xxt_eigen_variance_explained": args.var_explained, "n_eigenvecs": m,
-                       "parallelism": f"locus-sharded x{world}, 1 all-reduce of {n}x{n} fp64", "allreduce": allreduce_impl},
+                       "parallelism": f"locus-sharded x{world}, 1 all-reduce of {n}x{n} fp64", "allreduce": allreduce_impl,
+                       "comm_size": comm_size, "rccl_version": rccl_version,
+                       "launcher": ("bench.py (self-launched ranks)" if os.environ.get("POOLGEN_BENCH_LAUNCHED") == "1" else
+                                    "external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "none (single process)"),
+                       "rehearsal": bool(rehearsal and world > 1)},
             "roofline": roof,
             "kernels": {
                 "k_kinship_syrk": {"avg_ms": kin_avg, "executed_mfma_tflops": per_s(kin_exec_flops, kin_avg),
@@ -279,6 +506,8 @@ def main():
             rs["achieved"] = rs["two_pass"]["achieved"]; rs["frac"] = rs["two_pass"]["frac"]
             rs["traffic"] = rs["two_pass"]["traffic"]
             rec["roofline_sweep"] = rs
+        if secondary:
+            rec["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             s = min(args.cpu_sample, p_local)
             rec["cpu_baseline"] = cpu_baseline(G[:s, :n].cpu().numpy(), Y, args.var_explained, args.force_m)

@@ -66,7 +66,7 @@ int pg_synchronize(pg_ctx *ctx);
 /* Per-kernel HIP-event timing (used by bench.py for the roofline record). */
 enum pg_kernel_id { PG_K_KINSHIP = 0, PG_K_KINSHIP_REDUCE = 1, PG_K_SWEEP = 2, PG_K_OLS_ITER = 3,
                     PG_K_PEARSON = 4, PG_K_CHISQ = 5, PG_K_GP_XXT = 6, PG_K_GP_BETA = 7,
-                    PG_K_SWEEP_FINISH = 8, PG_K_ALLREDUCE = 9, PG_K_COUNT = 10 };
+                    PG_K_SWEEP_FINISH = 8, PG_K_ALLREDUCE = 9, PG_K_GP_PREDICT = 10, PG_K_COUNT = 11 };
 int pg_profile_enable(pg_ctx *ctx, int on);
 int pg_profile_reset(pg_ctx *ctx);
 /* Synchronises, then returns total milliseconds and launch count of one kernel id. */

@@ -85,7 +85,7 @@ SIGNATURES = {
 }
 
 KERNEL_IDS = {"kinship": 0, "kinship_reduce": 1, "sweep": 2, "ols_iter": 3, "pearson": 4,
-              "chisq": 5, "gp_xxt": 6, "gp_beta": 7, "sweep_finish": 8, "allreduce": 9}
+              "chisq": 5, "gp_xxt": 6, "gp_beta": 7, "sweep_finish": 8, "allreduce": 9, "gp_predict": 10}
 
 
 def load_library():

@@ -4,6 +4,9 @@
 //   hostcheck parse <sync> <threads>   : "L n" then one line per locus: chrom pos counts[n*6]
 #include "host_util.h"
 #include "pileup.h"
+#include "rank_gate.h"
+#include <atomic>
+#include <thread>
 #include <fstream>
 #include <chrono>
 #include <cstdio>
@@ -23,7 +26,24 @@ int main(int argc, char **argv) {
     try {
         if (argc < 2) return 2;
         const std::string mode = argv[1];
-        if (mode == "num") { // hostcheck num <f64|u64|i64> <text>: the strict parsers of the flag values and the phenotype file
+        if (mode == "gate") { // hostcheck gate <ranks> <failing rank or -1> <rounds>: the rank threads' go / abort agreement
+            const int R = std::atoi(argv[2]), bad = std::atoi(argv[3]), rounds = std::atoi(argv[4]);
+            RankGate gate(R);
+            std::atomic<int> entered{0}, own{0}, aborted{0}, finished{0};
+            std::vector<std::thread> th;
+            for (int r = 0; r < R; ++r)
+                th.emplace_back([&, r] {
+                    try {
+                        for (int i = 0; i < rounds; ++i) {
+                            gate.pass([&] { if (r == bad && i == rounds - 1) throw std::runtime_error("rank failed"); });
+                            if (i == rounds - 1) ++entered; // the "collective": every rank or none
+                        }
+                        ++finished;
+                    } catch (const RankAborted &) { ++aborted; } catch (const std::exception &) { ++own; }
+                });
+            for (auto &t : th) t.join();
+            std::cout << "entered " << entered << " own " << own << " aborted " << aborted << " finished " << finished << "\n";
+        } else if (mode == "num") { // hostcheck num <f64|u64|i64> <text>: the strict parsers of the flag values and the phenotype file
             const std::string kind = argv[2], text = argc > 3 ? argv[3] : "";
             double d; uint64_t u; int64_t i;
             if (kind == "f64") { if (parse_f64_strict(text, d)) std::cout << "ok " << rust_display(d) << "\n"; else std::cout << "reject\n"; }

@@ -19,9 +19,12 @@
 #include <climits>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <condition_variable>
 #include <exception>
 #include "gp_cv.h"
 #include "operators.h"
+#include "rank_gate.h"
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
@@ -327,6 +330,14 @@ static RankSetup rank_setup(const Args &a, bool need_comm) {
     RankSetup r;
     r.n_ranks = a.n_gpus > 0 ? a.n_gpus : 1;
     for (int i = 0; i < r.n_ranks; ++i) r.devices.push_back(a.gpu_ids.empty() ? i : a.gpu_ids[i]);
+    // every ordinal is checked BEFORE any rank thread exists: a rank that cannot open its device would otherwise leave the
+    // others waiting for it inside ncclCommInitRank
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    for (int i = 0; i < r.n_ranks; ++i)
+        if (r.devices[i] < 0 || r.devices[i] >= ndev)
+            throw std::runtime_error("rank " + std::to_string(i) + " asks for GPU " + std::to_string(r.devices[i]) + " but " +
+                                     std::to_string(ndev) + " GPU(s) are visible (--n-gpus / --gpu-ids)");
     const int total = std::max(a.n_threads, 1);
     for (int i = 0; i < r.n_ranks; ++i) r.threads.push_back(std::max(1, total / r.n_ranks + (i < total % r.n_ranks ? 1 : 0)));
     const char *e = std::getenv("PGH_COMM");
@@ -357,6 +368,8 @@ static void run_ranks(int n_ranks, F fn) { // fn(rank) on one thread per rank; t
         th.emplace_back([&, r] { try { fn(r); } catch (...) { err[r] = std::current_exception(); } });
     try { fn(0); } catch (...) { err[0] = std::current_exception(); }
     for (auto &t : th) t.join();
+    for (auto &e : err) // the rank that failed first-hand, not the ones that stopped because of it
+        if (e) { try { std::rethrow_exception(e); } catch (const RankAborted &) {} catch (...) { throw; } }
     for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
@@ -416,16 +429,26 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &l
     }
     auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
-    // ---- phase A, per rank: parse piece c + 1 || H2D + loader + partial kinship of piece c -----------------------
-    run_ranks(R, [&](int r) {
+    // every rank's context is created here, on the main thread: a GPU that cannot be opened ends the run before any rank
+    // thread exists
+    for (int r = 0; r < R; ++r) {
         KinRank &K = ranks[r];
         hip_ok(hipSetDevice(K.device), "hipSetDevice");
         if (r == 0 && gpu0.device == K.device) K.gpu = &gpu0;
         else { K.own.reset(new Ctx(K.device)); K.gpu = K.own.get(); }
+    }
+    RankGate gate(R);
+    // ---- phase A, per rank: parse piece c + 1 || H2D + loader + partial kinship of piece c -----------------------
+    run_ranks(R, [&](int r) {
+        KinRank &K = ranks[r];
         Ctx &gpu = *K.gpu;
-        if (rs.rccl) gpu.ok(pg_comm_init_rank(gpu.c, rs.id, R, r), "RCCL communicator"); // collective over the rank threads
-        K.S_total.assign((size_t)n2 * n2, 0.0);
-        hip_ok(hipMalloc((void **)&K.S_dev, sizeof(double) * n2 * n2), "device memory");
+        gate.pass([&] {
+            hip_ok(hipSetDevice(K.device), "hipSetDevice");
+            K.S_total.assign((size_t)n2 * n2, 0.0);
+            hip_ok(hipMalloc((void **)&K.S_dev, sizeof(double) * n2 * n2), "device memory");
+        });
+        if (rs.rccl) // collective over the rank threads: entered by all of them or by none, and its outcome agreed on
+            gate.pass([&] { gpu.ok(pg_comm_init_rank(gpu.c, rs.id, R, r), "RCCL communicator"); });
         if (K.c0 >= K.c1) return;
         auto alloc_for = [&K](int i) { // two pinned buffers that grow on demand and are handed out in turn
             SyncAlloc al;
@@ -554,8 +577,10 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &l
     run_ranks(R, [&](int r) {
         KinRank &K = ranks[r];
         Ctx &gpu = *K.gpu;
-        hip_ok(hipSetDevice(K.device), "hipSetDevice");
-        hip_ok(hipMemcpy(K.S_dev, rs.rccl ? K.S_total.data() : S_host.data(), sizeof(double) * n2 * n2, hipMemcpyHostToDevice), "H2D kinship");
+        gate.pass([&] {
+            hip_ok(hipSetDevice(K.device), "hipSetDevice");
+            hip_ok(hipMemcpy(K.S_dev, rs.rccl ? K.S_total.data() : S_host.data(), sizeof(double) * n2 * n2, hipMemcpyHostToDevice), "H2D kinship");
+        });
         if (rs.rccl) gpu.ok(pg_allreduce_sum_dev(gpu.c, K.S_dev, (int64_t)n2 * n2), "RCCL all-reduce of the kinship sums");
         gpu.ok(pg_kinship_set(gpu.c, K.S_dev, p, n2, Y.data(), k, a.xxt, -1, &K.m, nullptr, nullptr), "ols_iter_with_kinship");
         int64_t off = K.col0;

@@ -132,6 +132,11 @@ extern "C" int pg_ols_kinship_sharded_dev(pg_ctx *ctx, const double *G_dev, int6
     if (!ctx) return PG_ERR_INVALID;
     PG_CHECK(ctx, p_total >= p_local && p_local > 0, "ols_kinship_sharded: p_total (%lld) < p_local (%lld)", (long long)p_total,
              (long long)p_local);
+    // Without a communicator the all-reduce below is the identity: a slab that is not the whole matrix would silently give
+    // K = S_local / p_total and wrong fits.
+    if (!ctx->comm && p_total != p_local)
+        return pg_fail(ctx, PG_ERR_STATE, "ols_kinship_sharded: p_total (%lld) != p_local (%lld) on a context without a communicator "
+                       "(pg_comm_init_rank first, or pass the whole matrix)", (long long)p_total, (long long)p_local);
     PG_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->S_n < n) {
         PG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -655,6 +655,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 const dim3 grid(nblk2, (n + bthreads - 1) / bthreads);
                 const size_t lds = sizeof(double) * chunk * n_folds * (LP + 2);
                 const Proxy X{proxy_dev, k, j};
+                pg_prof_begin(ctx, PG_K_GP_PREDICT);
 #define PG_PREDICT_FOLDS(LPV)                                                                                              \
     case LPV:                                                                                                              \
         hipLaunchKernelGGL(k_gp_predict_folds<LPV>, grid, dim3(bthreads), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, p, n, \
@@ -665,6 +666,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                     PG_PREDICT_FOLDS(12) PG_PREDICT_FOLDS(14) PG_PREDICT_FOLDS(16)
                 }
 #undef PG_PREDICT_FOLDS
+                pg_prof_end(ctx);
                 hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 63) / 64), dim3(512), 0, ctx->stream, W.part, nblk2, n, W.yhat);
                 if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                     hipStreamSynchronize(ctx->stream) != hipSuccess)

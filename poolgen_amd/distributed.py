@@ -21,12 +21,25 @@ def shard_range(p_total: int, rank: int, world: int):
     return lo, hi
 
 
+def _all_agree(ok: bool, group=None) -> bool:
+    """True on every rank iff `ok` is True on every rank (MIN all-reduce of a flag over torch.distributed)."""
+    on_gpu = str(dist.get_backend(group)).lower().startswith("nccl")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=(torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu"))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 def setup_comm(engine, group=None, force: bool = False) -> bool:
     """Give `engine` the library's own RCCL communicator over the ranks of the torch.distributed job: rank 0 draws the
     unique id, torch.distributed only carries those 128 bytes to the other ranks (its store / object broadcast), then
-    every rank runs ncclCommInitRank inside libpoolgen_hip (pg_comm_init_rank).  Returns False -- and the caller stays
-    on torch.distributed's all-reduce -- when there is a single rank, when the engine has no RCCL entry points (the CPU
-    stand-in of the gloo tests) or when several ranks share one GPU (RCCL refuses that; the 1-GPU rehearsal)."""
+    every rank runs ncclCommInitRank inside libpoolgen_hip (pg_comm_init_rank).
+
+    Returns the SAME answer on every rank: True = every rank holds a communicator of `world` ranks; False = no rank does and
+    the caller stays on torch.distributed's all-reduce -- a single rank, an engine without RCCL entry points (the CPU
+    stand-in of the gloo tests), POOLGEN_COMM != rccl, or any rank failing at any stage (RCCL not loadable, id not drawn,
+    ncclCommInitRank refused -- e.g. several ranks on one GPU).  Every stage ends in an agreement over torch.distributed
+    before the next one starts, so no rank is left alone inside a collective (a rank that cannot load RCCL never lets the
+    others enter ncclCommInitRank)."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
     world = dist.get_world_size(group)
@@ -35,10 +48,36 @@ def setup_comm(engine, group=None, force: bool = False) -> bool:
     if getattr(engine, "_comm_ready", False) and engine.comm_size == world:
         return True
     rank = dist.get_rank(group)
-    box = [engine.comm_unique_id() if rank == 0 else None]
+    # stage 1: can every rank load RCCL at all?
+    try:
+        engine.comm_version()
+        ok = True
+    except Exception:
+        ok = False
+    if not _all_agree(ok, group):
+        return False
+    # stage 2: the id.  The broadcast always runs; a failure travels as None.
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = engine.comm_unique_id()
+        except Exception:
+            box[0] = None
     dist.broadcast_object_list(box, src=0, group=group)
-    engine.comm_init(box[0], world, rank)
-    engine._comm_ready = True
+    if box[0] is None:
+        return False
+    # stage 3: the collective init, then agree on its outcome; a partial success is undone everywhere
+    try:
+        engine.comm_init(box[0], world, rank)
+        ok = engine.comm_size == world
+    except Exception:
+        ok = False
+    if not _all_agree(ok, group):
+        try:
+            engine.comm_destroy()
+        except Exception:
+            pass
+        return False
     return True
 
 

@@ -52,8 +52,10 @@ class Engine:
         if rc != 0:
             raise NativeError(f"pg_create failed ({rc}): {self._lib.pg_last_error(None).decode()}")
         self._ctx = ctx
+        self._comm_ready = False   # True while this context holds an RCCL communicator (comm_init .. comm_destroy)
 
     def close(self):
+        self._comm_ready = False
         if getattr(self, "_ctx", None):
             self._lib.pg_destroy(self._ctx)
             self._ctx = None
@@ -100,8 +102,10 @@ class Engine:
         """Collective: every rank of the node calls it with the same id (ncclCommInitRank on this engine's GPU)."""
         assert len(unique_id) == 128
         self._check(self._lib.pg_comm_init_rank(self._ctx, C.c_char_p(unique_id), int(nranks), int(rank)), "pg_comm_init_rank")
+        self._comm_ready = True
 
     def comm_destroy(self):
+        self._comm_ready = False   # allreduce_sum would be the identity from here on: callers must fall back
         self._check(self._lib.pg_comm_destroy(self._ctx), "pg_comm_destroy")
 
     @property

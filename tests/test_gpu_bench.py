@@ -47,8 +47,57 @@ def test_two_rank_control_flow_rehearsal():
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["loci_total"] == 1000001 and d["config"]["loci_per_gpu"] == 500000
     assert d["scaling"] == "strong" and d["value"] > 0
-    # two ranks on ONE device: RCCL refuses, the line says which all-reduce ran instead
-    assert d["config"]["allreduce"].startswith("torch.distributed"), d["config"]
+    # two ranks on ONE device: RCCL refuses (on every rank: setup_comm answers the same everywhere), the line says which
+    # all-reduce ran instead
+    assert d["config"]["allreduce"].startswith("FALLBACK torch.distributed"), d["config"]
+    assert d["config"]["launcher"].startswith("external") and d["config"]["comm_size"] == 1
+
+
+def _no_launcher_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_self_launched_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` exactly as the driver starts it -- no launcher, no WORLD_SIZE: bench.py starts its own two rank
+    processes (the parent never touches the GPU), and prints ONE line with n_gpus = 2.  On this 1-GPU box the two ranks share
+    cuda:0 over gloo (POOLGEN_BENCH_BACKEND=gloo, the rehearsal switch; the line says so)."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--loci", "1000001",
+                        "--no-cpu-baseline", "--sweep-steps", "1"], capture_output=True, text=True, cwd=ROOT,
+                       env=_no_launcher_env(POOLGEN_BENCH_BACKEND="gloo"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["loci_per_gpu"] == 500000 and d["value"] > 0
+    assert d["config"]["launcher"].startswith("bench.py") and d["config"]["rehearsal"] is True
+    assert d["config"]["allreduce"].startswith("FALLBACK torch.distributed") and d["config"]["comm_size"] == 1
+    assert "secondary" not in d            # configs[1] / configs[3] are single-GPU legs
+
+
+def test_self_launch_refuses_more_ranks_than_gpus():
+    # without the rehearsal switch two ranks on one GPU are refused by every rank, and the parent reports it: non-zero, no line
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--loci", "100000",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=_no_launcher_env(), timeout=600)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_secondary_legs_in_the_line():
+    """BASELINE configs[1] and configs[3] are part of the driver-run line (reduced sizes here; the default run uses 1M / 5M)."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--loci", "500000", "--no-cpu-baseline",
+                        "--sweep-steps", "1", "--secondary-loci", "200000", "--ridge-loci", "200000"], capture_output=True, text=True,
+                       cwd=ROOT, env=_no_launcher_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    sec = d["secondary"]
+    co = sec["count_operators"]
+    for op in ("ols_iter", "pearson_corr", "chisq_test"):
+        assert co[op]["kernel_ms"] > 0 and co[op]["launches"] == 10 and 0 < co[op]["frac"] < 1
+        assert co[op]["bytes_per_launch"] == 24.0 * 100 * 200000
+    rd = sec["ridge"]
+    assert "error" not in rd, rd
+    assert rd["coefficient_pass"]["launches"] >= 10 and rd["prediction_pass"]["launches"] >= 10 and rd["wall_s"] > 0
+    assert 0 < rd["coefficient_pass"]["frac"] < 1 and 0 < rd["prediction_pass"]["frac"] < 1
 
 
 def test_one_rank_through_the_real_rccl_path():
@@ -61,4 +110,5 @@ def test_one_rank_through_the_real_rccl_path():
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["config"]["allreduce"].startswith("RCCL inside libpoolgen_hip"), d["config"]
+    assert d["config"]["comm_size"] == 1 and d["config"]["rccl_version"] >= 20000
     assert d["value"] > 0 and "roofline_sweep" in d and d["roofline_sweep"]["two_pass"]["launches"] == 1

@@ -341,6 +341,10 @@ def test_multi_gpu_kinship_ranks(tmp_path, thr):
     # RCCL itself needs one GPU per rank; asking for two ranks on one device is refused with a clear message
     r = subprocess.run(base + ["-o", str(tmp_path / "x.csv"), "--n-gpus", "2", "--gpu-ids", "0,0"], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "one GPU per rank" in r.stderr
+    # ranks on GPUs the box does not have: refused before any rank thread exists (a rank that cannot open its device would
+    # leave the others inside ncclCommInitRank for ever) -- an error within seconds, never a hang
+    r = subprocess.run(base + ["-o", str(tmp_path / "z.csv"), "--n-gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not (tmp_path / "z.csv").exists()
     # an unsorted input cannot be split over ranks
     r = subprocess.run([a if a != str(srt) else str(GOLD / "test.sync") for a in base] + ["-o", str(tmp_path / "y.csv"), "--n-gpus", "2",
                        "--gpu-ids", "0,0"], capture_output=True, text=True, env=dict(env, PGH_COMM="host"))

@@ -98,6 +98,10 @@ def test_rccl_inside_the_library_one_rank(engine):
     assert launches == 1 and ms >= 0.0
     with pytest.raises(Exception):
         eng.comm_init(eng.comm_unique_id(), 1, 0)   # one communicator per context
+    assert eng._comm_ready
     eng.comm_destroy()
-    assert eng.comm_size == 1
+    assert eng.comm_size == 1 and not eng._comm_ready
+    # without a communicator the all-reduce is the identity: a slab that is not the whole matrix must be refused, not summed wrongly
+    with pytest.raises(Exception, match="communicator"):
+        eng.ols_with_covariate_sharded(G[:1000].contiguous(), p, Y, 0.75, n=n)
     eng.close()
