@@ -404,428 +404,18 @@ __device__ __forceinline__ void emit_record(const Sums<OP, NJ, K> &S, bool poiso
     });
 }
 
-// ---- first pass: every locus, one read of its counts ----------------------------------------------
-// Computes the filter quantities (coverage, q_j) AND, speculatively, the operator's sums with every
-// candidate allele in play.  If every allele the filter then drops has zero counts in every pool (the
-// common case: absent alleles), the row sums over the surviving alleles equal the ones used, i.e. the
-// speculative sums ARE the reference's.  Otherwise (a dropped allele with reads, e.g. a
-// sequencing-error allele below the MAF) the locus is appended to `second` and k_locus_second redoes
-// its sums over the surviving alleles, as the reference's second to_frequencies does.
-// RNS = "remove Ns" (the CLI default, main.rs:203): column 4 is not in play at all.
-//
-// Memory access: HBM is read in whole, aligned 128-byte lines, each exactly once per row.  A row is
-// 24n bytes, so rows start at different offsets inside a line; the rows whose start offset is the same
-// are `period` apart (period = 128 / gcd(24n, 128), 1..16).  A wave therefore works on a UNIT of 64
-// rows of one alignment class (rows r0, r0 + period, ...): every lane streams its row line by line,
-// all lanes see the same pools complete at the same stage, so the pool loop and the w / Y operands
-// stay wave-uniform.  Stage s = line s of each of the 64 rows: 8 x (8 rows x 128 B) buffer loads per
-// lane-group into ONE line per row in LDS (pitch 144 B = 9 x 16: conflict-free row-wise reads);
-// a pool that straddles two lines is read across the ring.  The descriptor covers the unit's lines
-// only (a line that holds a valid byte lies in the same page as that byte, so whole-line reads are
-// safe at both ends of the batch), out-of-range lines come back as zeros, and the (unit, stage) pairs
-// of a wave form ONE flat sequence whose next loads are in flight while the current stage computes.
-constexpr int LN_PITCH = 144;  // one 128-byte line per row + 16: an odd number of 16-byte slots (conflict-free row-wise reads)
-constexpr int LN_TILEB = 64 * LN_PITCH;
-#ifndef LN_DEPTH_DEF
-#define LN_DEPTH_DEF 1
-#endif
-constexpr int LN_DEPTH = LN_DEPTH_DEF;
-
-template <int OP, bool RNS, int K>
-__global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_first(
-    const uint32_t *__restrict__ counts, const double *__restrict__ w, const double *__restrict__ Y,
-    int32_t *__restrict__ rec_flags, double *__restrict__ rec, unsigned long long *__restrict__ unit_again,
-    const LocusParams P, const int period) {
-    constexpr int NJ = RNS ? 5 : 6;
-    auto aj = [](int jj) { return (RNS && jj >= 4) ? jj + 1 : jj; };
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *tile = lds_raw + wave * LN_TILEB;
-    const char *rowp = tile + lane * LN_PITCH; // this lane's row: the line of the current stage
-    const int n = P.n;
-    const int64_t L = P.L;
-    const uint32_t rowb = (uint32_t)n * 24u;
-    const int pshift = __builtin_ctz(period);              // period is a power of two
-    const uint32_t pstride = (uint32_t)period * rowb;      // bytes between consecutive rows of a unit
-    // units: group g = 64 * period consecutive rows, class c = row offset inside the period.  A block
-    // owns chunks of max(4, period) consecutive units (whole groups: the record stores of a group's
-    // classes interleave, so they should meet in one L2) and its 4 waves take them round-robin.
-    const int64_t ngroups = (L + 64 * (int64_t)period - 1) >> (6 + pshift);
-    const int64_t nunits = ngroups * period;
-    const int cu = period > LO_WAVES ? period : LO_WAVES;   // units per chunk
-    const int64_t nchunks = (nunits + cu - 1) / cu;
-
-    // staging assignment.  LN_MAP16 (default): a load instruction takes 64 bytes of 16 rows (lane: row lane & 15, 16-byte piece
-    // lane >> 4), the two halves of a line in consecutive instructions -- the access shape tools/mb_msweep.hip measured at 6.4 TB/s
-    // on 2.4 KB rows where 8 rows x 128 bytes per instruction (LN_MAP16 = 0: lane -> row lane >> 3, piece lane & 7) reaches 5.8.
-#ifndef LN_MAP16
-#define LN_MAP16 1
-#endif
-#if LN_MAP16
-    const int g16 = lane & 15, piece4 = lane >> 4;
-    const uint32_t vbase = (uint32_t)g16 * pstride + (uint32_t)piece4 * 16u;
-    char *tstore = tile + g16 * LN_PITCH + piece4 * 16;
-#else
-    const int g8 = lane >> 3, piece = lane & 7;
-    const uint32_t vbase = (uint32_t)g8 * pstride + (uint32_t)piece * 16u;
-    char *tstore = tile + g8 * LN_PITCH + piece * 16;
-#endif
-
-    uint4_t S[LN_DEPTH][8]; // LN_DEPTH stages of loads in flight per lane
-    Sums<OP, NJ, K> A;
-    double q[NJ];
-    double mincov = INFINITY;
-    int n_missing = 0;
-
-    // a unit's descriptor: first row, start offset inside its line, lines per row, buffer resource.
-    // Everything in it is wave-uniform by construction (readfirstlane says so to the compiler, or
-    // every load would be wrapped in a waterfall loop).
-    struct Unit { int64_t r0; uint32_t delta; int nlines; uint32_t base_lo, base_hi; int nrec; };
-    auto make_unit = [&](int64_t u) {
-        Unit d;
-        const int64_t g = u >> pshift;
-        d.r0 = (g << (6 + pshift)) + (u - (g << pshift));
-        const uint64_t addr0 = reinterpret_cast<uint64_t>(counts) + (uint64_t)d.r0 * rowb;
-        d.delta = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)addr0 & 127u));
-        d.nlines = (int)((d.delta + rowb + 127u) >> 7);
-        int64_t rows = d.r0 < L ? (L - d.r0 + period - 1) >> pshift : 0;
-        rows = rows < 64 ? rows : 64;
-        const uint32_t span = rows > 0 ? ((d.delta + (uint32_t)(rows - 1) * pstride + rowb + 127u) & ~127u) : 0u;
-        const uint64_t basev = addr0 & ~(uint64_t)127;
-        d.base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)basev);
-        d.base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(basev >> 32));
-        d.nrec = __builtin_amdgcn_readfirstlane((int)span);
-        return d;
-    };
-    auto issue = [&](auto kc, const Unit &d, int s) {
-        constexpr int k = decltype(kc)::value;
-        const uint64_t base = ((uint64_t)d.base_hi << 32) | d.base_lo;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(base), 0, d.nrec, 0x00020000);
-        const uint32_t v0 = vbase + (uint32_t)s * 128u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) // the whole offset goes through the VGPR: the scalar offset is not range-checked on gfx9
-#if LN_MAP16
-            S[k][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (uint32_t)(j >> 1) * 16u * pstride + (uint32_t)(j & 1) * 64u, 0, 0);
-#else
-            S[k][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (uint32_t)j * 8u * pstride, 0, 0);
-#endif
-    };
-    auto land = [&](auto kc, int s) {
-        constexpr int k = decltype(kc)::value;
-        char *p = tstore;
-#pragma unroll
-#if LN_MAP16
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4_t *>(p + (j >> 1) * (16 * LN_PITCH) + (j & 1) * 64) = S[k][j];
-#else
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4_t *>(p + j * (8 * LN_PITCH)) = S[k][j];
-#endif
-    };
-    // one pool of this lane's locus
-    auto pool = [&](const uint32_t (&c)[NJ], int pi) {
-        double cd[NJ], f[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) cd[j] = (double)c[j];
-        double rs = cd[0]; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175); 0 + c0 = c0 exactly
-#pragma unroll
-        for (int j = 1; j < NJ; ++j) rs = rs + cd[j];
-        const bool rowok = rs != 0.0;
-        // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0,
-        // divided by 1) and the pool is counted in n_missing, which poisons / skips what NaN would
-        const double rsd = fmax(rs, 1.0); // rs is a whole number >= 0: 1 for an uncovered pool, rs otherwise (one instruction)
-        const double rinv = recip_for_div(rsd);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) f[j] = div_by(cd[j], rsd, rinv);
-        mincov = fmin(mincov, rs);                         // sync.rs:223-227 (starts at +inf: one v_min instead of compare + selects)
-        n_missing += rowok ? 0 : 1;
-        const double wi = w[pi];
-        // q += f * w_i with separate multiply and add; NaN frequencies contribute 0 (sync.rs:258-271)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) q[j] = q[j] + f[j] * wi;
-        A.add_pool(f, rowok, Y + (size_t)pi * K);
-    };
-    // LDS holds ONE line per row (the line of the current stage).  A pool (24 bytes) that starts in the previous line leaves 8 or
-    // 16 bytes there: the last 16 bytes of every line are carried over in registers (cy0, cy1) before the next line overwrites it.
-    // (Two lines per row -- 17 KB of LDS per wave -- measured 6-8 % slower.)
-    uint2_t cy0 = {0u, 0u}, cy1 = {0u, 0u};
-    auto unpack_pool = [&](const uint2_t &a, const uint2_t &b, const uint2_t &d, uint32_t (&e)[NJ]) {
-        const uint32_t c0[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) e[j] = c0[aj(j)];
-    };
-    auto read_pool = [&](uint32_t off, uint32_t (&e)[NJ]) { // 24 bytes at offset off (a multiple of 8, <= 104) of the current line
-        const uint2_t a = *reinterpret_cast<const uint2_t *>(rowp + off);
-        const uint2_t b = *reinterpret_cast<const uint2_t *>(rowp + off + 8u);
-        const uint2_t d = *reinterpret_cast<const uint2_t *>(rowp + off + 16u);
-        unpack_pool(a, b, d, e);
-    };
-    auto read_pool_across = [&](int old_bytes, uint32_t (&e)[NJ]) { // old_bytes (8 or 16, wave-uniform) of the pool sit in the carry
-        const uint2_t n0 = *reinterpret_cast<const uint2_t *>(rowp);
-        if (old_bytes == 16) unpack_pool(cy0, cy1, n0, e);
-        else {
-            const uint2_t n1 = *reinterpret_cast<const uint2_t *>(rowp + 8u);
-            unpack_pool(cy1, n0, n1, e);
-        }
-    };
-
-    // flat (unit, stage) sequence of this wave: chunk -> unit inside the chunk -> stage.  Two cursors
-    // walk it: `pre` issues loads LN_DEPTH items ahead of `cur`, which lands and computes them.
-    struct Cursor { int64_t chunk; int q; int s; bool valid; Unit D; };
-    auto unit_of = [&](int64_t ch, int q_) { return ch * cu + q_; };
-    auto advance = [&](Cursor &c) {
-        if (++c.s < c.D.nlines) return;
-        c.s = 0;
-        c.q += LO_WAVES;
-        if (c.q >= cu || unit_of(c.chunk, c.q) >= nunits) { c.q = wave; c.chunk += gridDim.x; }
-        const int64_t u = unit_of(c.chunk, c.q);
-        c.valid = c.chunk < nchunks && u < nunits;
-        if (c.valid) c.D = make_unit(u);
-    };
-    Cursor cur;
-    cur.chunk = blockIdx.x; cur.q = wave; cur.s = 0;
-    // (wave < cu always; a missing unit here means none later either)
-    if (cur.chunk >= nchunks || unit_of(cur.chunk, cur.q) >= nunits) return;
-    cur.valid = true;
-    cur.D = make_unit(unit_of(cur.chunk, cur.q));
-    Cursor pre = cur;
-    Unit lastD = cur.D; // what a dummy load re-reads once `pre` has run off the end
-    int lasts = 0;
-    int done = 0;       // pools of the current unit already processed
-
-    auto prefetch = [&](auto kc) {
-        if (pre.valid) { lastD = pre.D; lasts = pre.s; advance(pre); }
-        issue(kc, lastD, lasts);
-    };
-    auto step = [&](auto kc) {
-        const int s = cur.s;
-        const uint32_t delta = cur.D.delta;
-        const int nlines = cur.D.nlines;
-        const int64_t r0 = cur.D.r0;
-        __builtin_amdgcn_wave_barrier();
-        { // the tail of the line that is about to be overwritten
-            const uint4_t tl = *reinterpret_cast<const uint4_t *>(rowp + 112);
-            cy0 = uint2_t{tl.x, tl.y};
-            cy1 = uint2_t{tl.z, tl.w};
-        }
-        __builtin_amdgcn_wave_barrier();
-#ifndef LN_EXP_NOLOAD
-        land(kc, s);
-        __builtin_amdgcn_wave_barrier();
-        prefetch(kc); // in flight while this and the next LN_DEPTH - 1 stages are computed
-#else
-        if (pre.valid) { lastD = pre.D; lasts = pre.s; advance(pre); }
-#endif
-        if (!cur.valid) return; // (past the wave's last unit: see the main loop)
-        if (s == 0) {
-            A.clear();
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) q[j] = 0.0;
-            mincov = INFINITY;
-            n_missing = 0;
-            done = 0;
-        }
-        int hi = (int)((128u * (uint32_t)(s + 1) - delta) / 24u); // pools complete once line s has landed
-        hi = hi < n ? hi : n;
-#ifndef LN_EXP_NOCOMPUTE
-#ifndef LN_UNROLL
-#define LN_UNROLL 1 // measured 1 .. 4 at 100 pools x 1 M loci: 0.549 / 0.564 / 0.555 / 0.562 ms (ols_iter), 0.625 / 0.653 / 0.646 / 0.735 (pearson_corr)
-#endif
-        const int lo0 = (int)(delta + 24u * (uint32_t)done) - 128 * s; // offset of the stage's first pool in this line: >= 0, -8 or -16
-        if (done < hi && lo0 < 0) {
-            uint32_t e[NJ];
-            read_pool_across(-lo0, e);
-            pool(e, done);
-            ++done;
-        }
-#pragma unroll LN_UNROLL
-        for (int i = done; i < hi; ++i) {
-            uint32_t e[NJ];
-            read_pool(delta + 24u * (uint32_t)i - 128u * (uint32_t)s, e);
-            pool(e, i);
-        }
-#else
-        if (hi == 12345) { uint32_t e[NJ]; read_pool(0u, e); pool(e, 0); }
-#endif
-        done = hi;
-        if (s == nlines - 1) {
-            // filter decisions (sync.rs:223-300) and the record of this locus
-            const int64_t l = r0 + (int64_t)lane * period;
-            int nk = 0;
-            bool kp[NJ];
-            bool dropped_with_reads = false;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                kp[j] = !((q[j] < P.maf) | (q[j] > (1.00 - P.maf)));
-                nk += kp[j] ? 1 : 0;
-                // "has reads" = a positive column sum of the frequencies: a count > 0 makes its pool covered and its frequency > 0
-                // (>= 1 / (6 * 2^32)), and sums of non-negative terms do not cancel -- one compare here instead of an OR per pool
-                dropped_with_reads = dropped_with_reads || (!kp[j] && A.cs[j] != 0.0);
-            }
-            bool alive = !(mincov < P.min_cov);                                        // sync.rs:227
-            alive = alive && nk >= 2;                                                  // sync.rs:284
-            alive = alive && n_missing != n;                                           // sync.rs:293
-            alive = alive && !(((double)n_missing / (double)n) > P.max_miss);          // sync.rs:297
-            alive = alive && l < L;
-            const bool again = alive && dropped_with_reads;
-#ifdef LN_EXP_NOSTORE
-            if (nk == 12345)
-#endif
-            emit_record<OP, NJ, K>(A, n_missing > 0, kp, alive, again, l < L, rec_flags, rec,
-                                   unit_of(cur.chunk, cur.q) * 64 + lane, aj, P.sort_desc != 0);
-            // which lanes of this unit need the second pass: one 64-bit mask per unit, expanded into the
-            // dense list by k_locus_compact (no returning atomic here: its wait would drain the loads in flight)
-            const unsigned long long bal = __ballot(again);
-            if (lane == 0) unit_again[unit_of(cur.chunk, cur.q)] = bal;
-        }
-        advance(cur);
-    };
-
-    static_for<0, LN_DEPTH>([&](auto kc) { prefetch(kc); });
-    // Whole turns of the ring and no exit from inside one: with a test after every step the compiler's wait-count pass loses the
-    // order of the loads and makes ring slot 0 wait for ALL outstanding loads (vmcnt(7..0) where vmcnt(23..16) is right), i.e. the
-    // pipeline drained every LN_DEPTH-th stage.  (Found in the sweep kernel, where it cost 10 %; here the other waves of the CU
-    // covered the drain: 0.573 ms before and after at 100 pools x 1 M loci.)  The steps of the last turn that lie past the wave's
-    // last unit land and re-issue dummy loads and do nothing else.
-    while (cur.valid) {
-        static_for<0, LN_DEPTH>([&](auto kc) { step(kc); });
-    }
-}
-
-// ---- expand the per-unit "again" masks into the dense list of loci for the second pass ---------------
-__global__ __launch_bounds__(256) void k_locus_compact(const unsigned long long *__restrict__ unit_again,
-                                                       int64_t nunits, int period, int64_t *__restrict__ second,
-                                                       unsigned long long *__restrict__ second_count) {
-    __shared__ int part[256];
-    __shared__ unsigned long long base_s;
-    const int tid = threadIdx.x;
-    const int64_t u = (int64_t)blockIdx.x * 256 + tid;
-    const unsigned long long m = u < nunits ? unit_again[u] : 0ull;
-    const int c = __popcll(m);
-    part[tid] = c;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) { // inclusive scan
-        const int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    const int total = part[255];
-    if (total == 0) return; // block-uniform
-    if (tid == 0) base_s = atomicAdd(second_count, (unsigned long long)total);
-    __syncthreads();
-    if (c) {
-        const int pshift = __builtin_ctz(period);
-        const int64_t g = u >> pshift;
-        const int64_t r0 = (g << (6 + pshift)) + (u - (g << pshift));
-        int64_t *dst = second + base_s + (part[tid] - c);
-        unsigned long long mm = m;
-        int i = 0;
-        while (mm) {
-            const int b = __builtin_ctzll(mm);
-            mm &= mm - 1;
-            dst[i++] = r0 + (int64_t)b * period;
-        }
-    }
-}
-
-// ---- second pass: only the loci the first pass listed ----------------------------------------------
-// One lane per listed locus (rows gathered through the list), sums over the SURVIVING alleles only.
-template <int OP, int PB, int K>
-__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
-    const uint32_t *__restrict__ counts, const double *__restrict__ Y, int32_t *__restrict__ rec_flags,
-    double *__restrict__ rec, const int64_t *__restrict__ second,
-    const unsigned long long *__restrict__ second_count, const LocusParams P) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    char *tile = lds_raw + wave * LO_TILEB;
-    int64_t *lidx = reinterpret_cast<int64_t *>(lds_raw + LO_WAVES * LO_TILEB) + wave * 64;
-    const char *row = tile + lane * LO_PITCH;
-    const int n = P.n;
-    const int nfull = n / LO_CHP;
-    const int nst = (n + LO_CHP - 1) / LO_CHP;
-    const int64_t cnt = (int64_t)*second_count;
-    const int64_t ntiles = (cnt + 63) / 64;
-    const int64_t wstride = (int64_t)gridDim.x * LO_WAVES;
-    auto aj = [](int jj) { return jj; };
-    StageRegs S;
-    Sums<OP, NA, K> A;
-    for (int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave; t < ntiles; t += wstride) {
-        const int64_t e = t * 64 + lane;
-        const int64_t l = second[e < cnt ? e : cnt - 1];
-        lidx[lane] = l;
-        __builtin_amdgcn_wave_barrier();
-        const int64_t slot = unit_slot(l, P.pshift);
-        const int mask = rec_flags[slot];
-        bool keep[NA];
-#pragma unroll
-        for (int j = 0; j < NA; ++j) keep[j] = (mask & (2 << j)) != 0;
-        auto rowsel = [&](int r) { return lidx[r]; };
-        A.clear();
-        int n_missing = 0;
-        for (int st = 0; st < nst; ++st) {
-            const int pool0 = st * LO_CHP;
-            const int np = st < nfull ? LO_CHP : n - pool0;
-            if (st < nfull) {
-                stage_load<PB, false>(S, counts, n, pool0, np, lane, rowsel);
-                stage_store<PB, false>(S, tile, np, lane);
-            } else {
-                stage_load<8, true>(S, counts, n, pool0, np, lane, rowsel);
-                stage_store<8, true>(S, tile, np, lane);
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-            for (int i = 0; i < np; ++i) {
-                const uint2_t a = *reinterpret_cast<const uint2_t *>(row + i * 24);
-                const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
-                const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
-                const uint32_t c[NA] = {a.x, a.y, b.x, b.y, d.x, d.y};
-                double cd[NA], f[NA];
-                double rs = 0.0; // row sum over the surviving alleles (second to_frequencies, sync.rs:170-175)
-#pragma unroll
-                for (int j = 0; j < NA; ++j) { cd[j] = keep[j] ? (double)c[j] : 0.0; rs = rs + cd[j]; }
-                const bool rowok = rs != 0.0;
-                const double rsd = rowok ? rs : 1.0;
-                const double rinv = recip_for_div(rsd);
-                n_missing += rowok ? 0 : 1;
-#pragma unroll
-                for (int j = 0; j < NA; ++j) f[j] = div_by(cd[j], rsd, rinv);
-                A.add_pool(f, rowok, Y + (size_t)(pool0 + i) * K);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        emit_record<OP, NA, K>(A, n_missing > 0, keep, true, false, e < cnt, rec_flags, rec, slot, aj, P.sort_desc != 0);
-    }
-}
-
-// ---- closing kernels: one thread per locus, from the compact record (see emit_record) ----------------
-// ols_iter: literal normal equations in the reference's column order (ols.rs:58-160) on the PN = nk
-// columns [1 | f_ord[1] | ... | f_ord[nk-1]], specialised on PN so that the common biallelic locus pays
-// for a 2 x 2 factorisation only.
+// ---- ols_iter fit from its sufficient statistics (shared by the streaming pass and the closing kernel) ------------
+// Literal normal equations in the reference's column order (ols.rs:58-160) on the PN columns [1 | f_ord[1] | ... |
+// f_ord[PN-1]] (the major allele, rank 0, is the one ols.rs:227-230 drops), specialised on PN so that the common biallelic
+// locus pays for a 2 x 2 factorisation only.  cs = column sums, xxs = sum f_a f_b, xy = sum f_a y_t (y centred on the host).
+// Returns `singular` (zero pivot or det(inv) == 0: the locus is dropped, ols.rs:77-83), the diagonal of the inverse through
+// the coefficients b and p-values pv of the PN - 1 design columns for the kk traits of this launch.
 template <int PN>
-__device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t rb, int k, int ordbits, bool alive,
-                                          const double *__restrict__ tcoef, int32_t *__restrict__ n_out,
-                                          int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
-                                          double *__restrict__ stat_out, double *__restrict__ pv_out, int64_t l,
-                                          const LocusParams &P) {
-    constexpr int D = PN - 1;
+__device__ __forceinline__ void ols_solve(const double (&cs)[PN - 1], const double (&xxs)[PN - 1][PN - 1],
+                                          const double (&xy)[PN - 1][MAXK], int kk, const LocusParams &P,
+                                          const double *__restrict__ tcoef, bool &singular,
+                                          double (&bout)[MAXK][PN - 1], double (&pvout)[MAXK][PN - 1]) {
     const int n = P.n;
-    const int kk = k; // 1 or 2 traits in this launch: the record was laid out with K = k
-    double cs[D], xxs[D][D], xy[D][MAXK];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int f0 = d * (1 + kk) + d * (d + 1) / 2;
-        cs[d] = rec[rb + (size_t)f0 * 64];
-#pragma unroll
-        for (int t = 0; t < MAXK; ++t) xy[d][t] = (t < kk) ? rec[rb + (size_t)(f0 + 1 + t) * 64] : 0.0;
-#pragma unroll
-        for (int c = 0; c <= d; ++c) {
-            const double v = rec[rb + (size_t)(f0 + 1 + kk + c) * 64];
-            xxs[d][c] = v;
-            xxs[c][d] = v;
-        }
-    }
     double A[PN][PN];
     auto xtx = [&](int r, int c) -> double {
         if (r == 0 && c == 0) return (double)n;
@@ -838,7 +428,7 @@ __device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t
 #pragma unroll
         for (int c = 0; c < PN; ++c) A[r][c] = xtx(r, c);
     // LU with partial pivoting, first max |a| in the column (the oracle's lu_factor; LAPACK dgetf2)
-    bool singular = false;
+    singular = false;
     int piv[PN];
 #pragma unroll
     for (int kq = 0; kq < PN; ++kq) {
@@ -955,19 +545,9 @@ __device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t
         }
         if (zero_piv || det == 0.0) singular = true;
     }
-    const bool ok = alive && !singular; // Err -> the whole locus is dropped (ols.rs:250-253)
-    if (P.t0 == 0) {
-        n_out[l] = ok ? D : 0;
-#pragma unroll
-        for (int r = 0; r < PG_MAX_OUT; ++r) {
-            const bool on = ok && r < D;
-            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * (r + 1))) & 7) : -1;
-            mf_out[l * PG_MAX_OUT + r] = (on && r < D) ? cs[r < D ? r : 0] / (double)n : NAN; // ols.rs:266
-        }
-    }
 #pragma unroll
     for (int tt = 0; tt < MAXK; ++tt) {
-        if (tt >= k) continue;
+        if (tt >= kk) continue;
         // X'y with the centred phenotype (slopes are invariant to the shift; it removes the
         // y-bar^2 cancellation from the residual sum of squares)
         double xty[PN], b[PN];
@@ -991,20 +571,696 @@ __device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t
         rss = rss < 0.0 ? 0.0 : rss;
         const double ve = rss / ((double)n - (double)PN); // ols.rs:103
 #pragma unroll
-        for (int r = 0; r < PG_MAX_OUT; ++r) {
-            double pv = NAN, bb = NAN;
-            if (r < D) {
-                if (ok) {
-                    bb = b[r + 1 < PN ? r + 1 : 0];
-                    const double vb = ve * dinv[r + 1 < PN ? r + 1 : 0];             // ols.rs:111-116
-                    const double tstat = (fabs(bb) <= PG_EPS) ? 0.0 : bb / sqrt(vb); // ols.rs:143-147
-                    if (fabs(tstat) <= PG_EPS) pv = 1.0;
-                    else if (isnan(tstat)) pv = 1.0;
-                    else pv = pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef);
+        for (int r = 0; r < PN - 1; ++r) {
+            const double bb = b[r + 1];
+            const double vb = ve * dinv[r + 1];                              // ols.rs:111-116
+            const double tstat = (fabs(bb) <= PG_EPS) ? 0.0 : bb / sqrt(vb); // ols.rs:143-147
+            double pv;
+            if (fabs(tstat) <= PG_EPS) pv = 1.0;
+            else if (isnan(tstat)) pv = 1.0;
+            else pv = pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef);
+            bout[tt][r] = bb;
+            pvout[tt][r] = pv;
+        }
+    }
+}
+
+// pearsons_correlation (gwas/correlation_test.rs:7-71) from the shifted sums over the complete pairs
+__device__ __forceinline__ void pearson_close(double sx, double sxx, double sxy, double sy, double syy, double m, int n,
+                                              const LocusParams &P, const double *__restrict__ tcoef, double &rr, double &pp) {
+    const double cxy = sxy - sx * sy / m;
+    const double cxx = sxx - sx * sx / m;
+    const double cyy = syy - sy * sy / m;
+    const double r0 = cxy / (sqrt(cxx) * sqrt(cyy));      // :50-52
+    rr = NAN; pp = NAN;
+    if (isnan(r0)) return;                                // :53-56
+    const double sden = (1.0 - r0 * r0) / ((double)n - 2.0); // :57
+    if (sden <= 0.0) { rr = r0; pp = PG_EPS; return; }    // :58-61
+    const double tstat = r0 / sqrt(sden);
+    pp = (n > 2) ? pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef) : NAN;
+    rr = round(r0 * 1e7) / 1e7; // sensible_round(r, 7), :70 (half away from zero)
+}
+
+// ---- the streaming pass (round 3): every locus, ONE read of its counts, fits closed in place ------------------------
+// One lane per locus, as the filter demands: q_j = sum_i f_ij w_i must be accumulated sequentially in pool order with
+// separate multiply and add (sync.rs:258-282), and a lane walking its own row does exactly that.  What changed against
+// round 2's k_locus_first (measurements: tools/mb_locus_dma.hip, profiles/r03_mb_locus_*.log):
+//  * A lane takes M = period consecutive loci, one after the other, as ONE stream of M * 24 n bytes: that many bytes are a
+//    whole number of 128-byte lines (period = 128 / gcd(24 n, 128)), so every lane's stream starts at the same offset inside
+//    a line, no line is shared by two lanes (the alignment-class units of round 2 fetched the line two neighbouring rows
+//    share twice: +4 % at 100 pools), every lane sees the same pools complete at the same step (the pool loop and the w / Y
+//    operands stay wave-uniform), and a unit -- 64 lanes x M loci -- is one contiguous run of loci whose results leave as
+//    whole lines.
+//  * A stream starts on a pool, so a ring turn of three lines = 384 bytes = 16 pools is unrolled with every LDS offset an
+//    immediate (a batch that does not start on a 128-byte boundary is read in windows that straddle two lines: correct,
+//    slower); w_i and y_i come from a table in LDS (one broadcast read per pool) instead of scalar loads whose wait also
+//    waited for the LDS.  With that the arithmetic of a pool (filter + the
+//    operator's sums, ~60 fp64 instructions) hides completely behind the loads at two waves per SIMD: the pass runs at the
+//    rate of its request pattern (64 rows x 128 bytes per step and wave: 5.4 .. 5.9 TB/s by row length).
+//  * Speculation as before: the operator's sums are taken with every candidate allele in play; they ARE the reference's
+//    when every allele the filter drops has no reads (the common case).  New: only what a biallelic fit needs is summed
+//    (per allele sum f, sum f^2, sum f y -- not the 15 cross products), and such a fit is CLOSED IN PLACE when its last pool
+//    has passed (ols_solve<2> / pearson_close / the chi-square tail) -- no record stream, no closing kernel.  Loci that drop
+//    an allele with reads, or (ols_iter, pearson_corr) keep three or more alleles, go to a dense list (one returning atomic
+//    per unit that has any) for k_locus_second + k_locus_close, which redo them from the counts.
+//  * Results are staged per unit in LDS (16 + 16 K bytes per locus) and written at the unit's end as contiguous runs: the
+//    per-lane stores of a locus-strided layout reached HBM as partial lines and cost 130 us per million loci.
+constexpr int ST_SLOTB = 64 * 128;  // LDS bytes of a wave's line slot: [16 rows x 64 B per load instruction][4 row groups x 2 halves]
+constexpr int ST_PPT = 16;          // pools per ring turn of 3 lines
+constexpr int ST_STAGE = 8192;      // LDS bytes per wave for the results of a unit
+
+template <int OP, int NJ, int K>
+struct Acc { // running sums of one locus, every candidate allele in play; everything accumulated sequentially in pool order
+    double q[NJ], cs[NJ];
+    double dd[NJ];        // OLS: sum f^2; CHISQ: sum f^2 / rowsum
+    double xy[NJ * K];    // OLS: sum f y; PEARSON: sum x y over complete pairs
+    double px[NJ * K], pxx[NJ * K], py[K], pyy[K], pn[K], shx[NJ];
+    double total, mincov;
+    int n_missing;
+    bool shset;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { q[j] = 0.0; cs[j] = 0.0; dd[j] = 0.0; shx[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < NJ * K; ++j) { xy[j] = 0.0; px[j] = 0.0; pxx[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < K; ++j) { py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
+        total = 0.0;
+        mincov = INFINITY;
+        n_missing = 0;
+        shset = false;
+    }
+};
+
+struct StreamOut { // where the results go (device pointers of the operator's output arrays)
+    int32_t *n_out, *ids;
+    double *mf, *stat, *pv;
+};
+
+template <int OP, bool RNS, int K>
+__global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
+    const uint32_t *__restrict__ counts, const double *__restrict__ wy, const double *__restrict__ tcoef,
+    int32_t *__restrict__ rec_flags, int64_t *__restrict__ second, unsigned long long *__restrict__ second_count,
+    const StreamOut O, const LocusParams P, const int M, const int staged) {
+    constexpr int NJ = RNS ? 5 : 6;
+    constexpr int TW = (OP == OP_OLS || OP == OP_PEARSON) ? 1 + K : 1; // doubles per pool in the table: w_i, y_i0, ...
+    constexpr int RECB = 16 + 16 * K;                                  // bytes of a staged result
+    auto aj = [](int jj) { return (RNS && jj >= 4) ? jj + 1 : jj; };
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *slotp = lds_raw + wave * ST_SLOTB;
+    char *stage = lds_raw + LO_WAVES * ST_SLOTB + wave * ST_STAGE;
+    const double *tab = reinterpret_cast<const double *>(lds_raw + LO_WAVES * (ST_SLOTB + ST_STAGE));
+    const int n = P.n;
+    const int64_t L = P.L;
+    {
+        double *t = reinterpret_cast<double *>(lds_raw + LO_WAVES * (ST_SLOTB + ST_STAGE));
+        for (int i = threadIdx.x; i < TW * n; i += LO_THREADS) t[i] = wy[i];
+        __syncthreads();
+    }
+    const uint32_t rowb = (uint32_t)n * 24u;
+    const uint32_t srb = (uint32_t)M * rowb;              // bytes of a lane's stream: a whole number of lines
+    const int nh = (int)(srb >> 7);                       // lines per stream
+    const uint64_t base0 = reinterpret_cast<uint64_t>(counts);
+    const int npool = M * n;                              // pools of a stream
+    const int64_t lpu = (int64_t)64 * M;                  // loci per unit
+    const int64_t nunits = (L + lpu - 1) / lpu;
+    const uint64_t total_bytes = (uint64_t)L * rowb;
+    const int64_t wid = (int64_t)blockIdx.x * LO_WAVES + wave, wstride = (int64_t)gridDim.x * LO_WAVES;
+    if (wid >= nunits) return;
+
+    // load role of this lane: row rr of a group of 16 rows, 16-byte piece pp of a 64-byte half line
+    const int rr = lane & 15, pp = lane >> 4;
+    uint32_t vb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) vb[g] = (uint32_t)(16 * g + rr) * srb + (uint32_t)pp * 16u;
+    // this lane's own row inside the slot: piece P of the line at ((lane >> 4) * 2 + P / 4) * 1024 + (P % 4) * 256 + (lane & 15) * 16
+    const char *cell = slotp + (lane >> 4) * 2048 + (lane & 15) * 16;
+
+    // ---- the request side: one line ahead of the compute side, across the wave's units ------------------------------
+    int64_t pre_u = wid;
+    int pre_h = 0;
+    uint4_t SR[8]; // the line in flight: 8 load instructions of 16 rows x 64 bytes
+    auto issue_line = [&]() {
+        if (pre_u < nunits) {
+            // descriptor of THIS line: base = the unit's start + 128 h, range = what is left of the batch; bytes past the batch come
+            // back as zeros (uncovered pools of loci that are never stored)
+            const uint64_t uo = (uint64_t)pre_u * 64u * srb + (uint64_t)pre_h * 128u;
+            const uint64_t ub = base0 + uo;
+            // (rounded up to the 16 bytes of a load: a batch ends on an 8-byte boundary, its base is 16-byte aligned)
+            const uint64_t left = total_bytes > uo ? ((total_bytes - uo + 15u) & ~(uint64_t)15) : 0;
+            const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(left > 0xffffffffull ? 0xffffffffu : (uint32_t)left));
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ub >> 32));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<char *>(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) // the two halves of a row group's line in consecutive instructions
+                SR[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vb[i >> 1] + (uint32_t)(i & 1) * 64u, 0, 0);
+            if (++pre_h >= nh) { pre_h = 0; pre_u += wstride; }
+        }
+    };
+    auto land_line = [&]() {
+        char *dst = slotp + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4_t *>(dst + i * 1024) = SR[i];
+    };
+
+    // ---- per-lane state ------------------------------------------------------------------------------------------------
+    Acc<OP, NJ, K> A; // the locus being summed
+    // the locus whose last pool has passed, reduced at that moment to what its closing needs (the heavy part runs once per ring
+    // turn, after the turn's pools): filter decisions in `fh`, the selected sums in `fv`
+    //   OLS     fv = cs, sum f^2, sum f y_t of the design column (the minor allele of a biallelic locus)
+    //   PEARSON fv = cs, sum x, sum x^2, sum x y of the first surviving allele, then sum y, sum y^2, pairs
+    //   CHISQ   fv = cs[NJ], sum f^2 / rowsum [NJ], total        LOAD  fv = cs[NJ]
+    constexpr int NFV = (OP == OP_OLS) ? 2 + K : (OP == OP_PEARSON) ? 7 : (OP == OP_CHISQ) ? 2 * NJ + 1 : NJ;
+    double fv[NFV];
+    int fh = 0;          // bit 0 alive | 1..6 surviving alleles | 7 again | 8..10 nk | 11 poisoned | 12..14 id of the closed allele | 15.. kept mask by slot
+    bool fin_pending = false;
+    int fin_i = 0;       // which of the lane's M loci it is
+    int pi = 0, iloc = 0;
+    uint2_t cy0 = {0u, 0u}, cy1 = {0u, 0u}; // the last 16 bytes of the previous line
+
+    // filter decisions of the locus in A (sync.rs:223-300) and the sums its closing will want
+    auto boundary = [&]() {
+        int nk = 0, keepmask = 0, slotmask = 0;
+        bool dropped_with_reads = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool kpj = !((A.q[j] < P.maf) | (A.q[j] > (1.00 - P.maf)));
+            nk += kpj ? 1 : 0;
+            keepmask |= kpj ? (2 << aj(j)) : 0;
+            slotmask |= kpj ? (1 << j) : 0;
+            // "has reads" = a positive column sum of the frequencies: a count > 0 makes its pool covered and its frequency > 0, and sums of
+            // non-negative terms do not cancel
+            dropped_with_reads = dropped_with_reads || (!kpj && A.cs[j] != 0.0);
+        }
+        bool alive = !(A.mincov < P.min_cov);                                        // sync.rs:227
+        alive = alive && nk >= 2;                                                    // sync.rs:284
+        alive = alive && A.n_missing != n;                                           // sync.rs:293
+        alive = alive && !(((double)A.n_missing / (double)n) > P.max_miss);          // sync.rs:297
+        const bool again = alive && dropped_with_reads;
+        int idc = 0;
+        if (OP == OP_OLS || OP == OP_PEARSON) {
+            // the two survivors of a biallelic locus: slots sa < sb
+            int sa = 0, sb = 0, seen = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool kpj = (slotmask >> j) & 1;
+                sa = (kpj && seen == 0) ? j : sa;
+                sb = (kpj && seen == 1) ? j : sb;
+                seen += kpj ? 1 : 0;
+            }
+            int sc = sa; // PEARSON: all surviving alleles but the LAST, unsorted (gwas/correlation_test.rs:94-126): the first of two
+            if (OP == OP_OLS) {
+                // stable sort by decreasing column sum (sync.rs:477-506): rank 0 = the major allele, dropped (ols.rs:227-230)
+                const double ca = pickn<NJ>(A.cs, sa), cb = pickn<NJ>(A.cs, sb);
+                sc = (cb > ca) ? sa : sb; // the design column: the minor allele
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) idc = (sc == j) ? aj(j) : idc;
+            fv[0] = pickn<NJ>(A.cs, sc);
+            if (OP == OP_OLS) {
+                fv[1] = pickn<NJ>(A.dd, sc);
+#pragma unroll
+                for (int t = 0; t < K; ++t) fv[2 + t] = pick_trait<NJ, K>(A.xy, sc, t);
+            } else {
+                fv[1] = pick_trait<NJ, K>(A.px, sc, 0);
+                fv[2] = pick_trait<NJ, K>(A.pxx, sc, 0);
+                fv[3] = pick_trait<NJ, K>(A.xy, sc, 0);
+                fv[4] = A.py[0]; fv[5] = A.pyy[0]; fv[6] = A.pn[0];
+            }
+        } else if (OP == OP_CHISQ) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { fv[j] = A.cs[j]; fv[NJ + j] = A.dd[j]; }
+            fv[2 * NJ] = A.total;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fv[j] = A.cs[j];
+        }
+        fh = (alive ? FLAG_ALIVE : 0) | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT) | ((A.n_missing > 0) ? (1 << 11) : 0) |
+             (idc << 12) | (slotmask << 15);
+    };
+
+    // one pool of this lane's locus
+    struct TabRow { double w, y[K]; };
+    auto read_tab = [&](int ti) { // broadcast read of the pool's table entry: w_i, y_i
+        const double *t = tab + ti * TW;
+        TabRow r;
+        r.w = t[0];
+#pragma unroll
+        for (int tt = 0; tt < K; ++tt) r.y[tt] = (TW > 1) ? t[TW > 1 ? 1 + tt : 0] : 0.0;
+        return r;
+    };
+    auto pool = [&](const uint2_t &wa, const uint2_t &wb, const uint2_t &wd, const TabRow &tr, auto chkc) {
+        constexpr bool CHK = decltype(chkc)::value;
+        const uint32_t c0[6] = {wa.x, wa.y, wb.x, wb.y, wd.x, wd.y};
+        double cd[NJ], f[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cd[j] = (double)c0[aj(j)];
+        double rs = cd[0]; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175); 0 + c0 = c0 exactly
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) rs = rs + cd[j];
+        const bool rowok = rs != 0.0;
+        // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0, divided by 1) and the pool
+        // is counted in n_missing, which poisons / skips what NaN would
+        const double rsd = fmax(rs, 1.0);
+        const double rinv = recip_for_div(rsd);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f[j] = div_by(cd[j], rsd, rinv);
+        A.mincov = fmin(A.mincov, rs);                       // sync.rs:223-227
+        A.n_missing += rowok ? 0 : 1;
+        const double wi = tr.w;
+        // q += f * w_i with separate multiply and add; NaN frequencies contribute 0 (sync.rs:258-271)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) A.q[j] = A.q[j] + f[j] * wi;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) A.cs[j] = A.cs[j] + f[j];
+        if (OP == OP_OLS) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) A.dd[j] = fma(f[j], f[j], A.dd[j]);
+#pragma unroll
+            for (int tt = 0; tt < K; ++tt) {
+                const double y = tr.y[tt];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) A.xy[j * K + tt] = fma(f[j], y, A.xy[j * K + tt]);
+            }
+        } else if (OP == OP_PEARSON) {
+            if (rowok && !A.shset) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) A.shx[j] = f[j];
+                A.shset = true;
+            }
+#pragma unroll
+            for (int tt = 0; tt < K; ++tt) {
+                const double y = tr.y[tt];             // shifted by its first valid value on the host
+                const bool ok = rowok && !isnan(y);    // pairwise complete (correlation_test.rs:22-26)
+                const double ye = ok ? y : 0.0;        // an incomplete pair contributes exact zeros instead of being skipped
+                A.py[tt] = A.py[tt] + ye;
+                A.pyy[tt] = fma(ye, ye, A.pyy[tt]);
+                A.pn[tt] = A.pn[tt] + (ok ? 1.0 : 0.0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const double x = ok ? f[j] - A.shx[j] : 0.0;
+                    const int e = j * K + tt;
+                    A.px[e] = A.px[e] + x;
+                    A.pxx[e] = fma(x, x, A.pxx[e]);
+                    A.xy[e] = fma(x, ye, A.xy[e]);
                 }
             }
-            stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = bb;
-            pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pv;
+        } else if (OP == OP_CHISQ) { // chi2 = total * (sum_j A_j / cs_j - 1), A_j = sum_i f_ij^2 / rowsum_i
+            double rsum = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rsum = rsum + f[j]; // row sum of the frequencies (~1)
+            A.total = A.total + rsum;
+            const double rsd2 = rowok ? rsum : 1.0;
+            const double ri = recip_for_div(rsd2);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) A.dd[j] = A.dd[j] + div_by(f[j] * f[j], rsd2, ri);
+        }
+        // the locus' last pool: decide, keep what the closing needs (it runs at the end of the turn) and start the next locus
+        if constexpr (CHK) {
+            if (++pi == n) {
+                pi = 0;
+                boundary();
+                fin_i = iloc++;
+                fin_pending = true;
+                A.clear();
+            }
+        }
+    };
+
+    // one staged result: n_out | ids (3 bits each) + nk << 16 | mean frequency | statistic per trait | p-value per trait
+    auto put_result = [&](int idx, int nout, int idsp, double mf, const double (&st)[K], const double (&pv)[K]) {
+        char *r = stage + (size_t)idx * RECB;
+        *reinterpret_cast<uint2_t *>(r) = uint2_t{(uint32_t)nout, (uint32_t)idsp};
+        *reinterpret_cast<double *>(r + 8) = mf;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            *reinterpret_cast<double *>(r + 16 + 16 * t) = st[t];
+            *reinterpret_cast<double *>(r + 24 + 16 * t) = pv[t];
+        }
+    };
+    // the operator's output arrays of locus l from one result
+    auto store_result = [&](int64_t l, int nout, int idsp, double mf, const double (&st)[K], const double (&pv)[K]) {
+        const int nk = (idsp >> 16) & 7;
+        if (OP == OP_CHISQ) {
+            O.n_out[l] = nout;
+#pragma unroll
+            for (int r = 0; r < PG_MAX_OUT; ++r) O.ids[l * PG_MAX_OUT + r] = (r < nk) ? ((idsp >> (3 * r)) & 7) : -1;
+            O.stat[l] = st[0];
+            O.pv[l] = pv[0];
+            return;
+        }
+        if (P.t0 == 0 || OP == OP_PEARSON) {
+            O.n_out[l] = nout;
+#pragma unroll
+            for (int r = 0; r < PG_MAX_OUT; ++r) {
+                O.ids[l * PG_MAX_OUT + r] = (r < nout) ? (idsp & 7) : -1; // (only single-output loci are closed in this pass)
+                O.mf[l * PG_MAX_OUT + r] = (r < nout) ? mf : NAN;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int r = 0; r < PG_MAX_OUT; ++r) {
+                O.stat[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + t] = (r < nout) ? st[t] : NAN;
+                O.pv[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + t] = (r < nout) ? pv[t] : NAN;
+            }
+    };
+
+    // ---- a finished locus: close it here or list it for the second pass ------------------------------------------------------------
+    auto finish = [&](int64_t unit) {
+        const int64_t l = unit * lpu + (int64_t)lane * M + fin_i;
+        const bool valid = l < L;
+        const int nk = (fh >> H_NK_SHIFT) & 7;
+        const int keepmask = fh & 0x7e;
+        const int slotmask = (fh >> 15) & 63;
+        const bool alive = (fh & FLAG_ALIVE) != 0 && valid;
+        const bool again = alive && (fh & FLAG_SECOND) != 0;
+        const double pz = (fh & (1 << 11)) ? NAN : 0.0; // x + NaN = NaN: an uncovered pool makes the reference's plain sums NaN
+        // three or more surviving alleles need the cross products (ols_iter) or several outputs (pearson_corr): second pass
+        const bool deferred = alive && (again || ((OP == OP_OLS || OP == OP_PEARSON) && nk >= 3));
+        if (OP == OP_LOAD) {
+            // the loader wants the header of every locus: surviving alleles in the order its columns take (sync.rs:1033-1037)
+            int ordbits = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int r = 0;
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    if (i == j) continue;
+                    const bool before = P.sort_desc ? (fv[i < NFV ? i : 0] > fv[j < NFV ? j : 0] || (fv[i < NFV ? i : 0] == fv[j < NFV ? j : 0] && i < j)) : i < j;
+                    r += (((slotmask >> i) & 1) && before) ? 1 : 0;
+                }
+                ordbits |= ((slotmask >> j) & 1) ? (aj(j) << (3 * r)) : 0;
+            }
+            const int hdr = (alive ? FLAG_ALIVE : 0) | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT) | (ordbits << H_ORD_SHIFT);
+            if (staged) *reinterpret_cast<int32_t *>(stage + (size_t)(lane * M + fin_i) * 4) = hdr;
+            else if (valid) rec_flags[l] = hdr;
+        } else if (deferred) {
+            rec_flags[l] = FLAG_ALIVE | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT); // the second pass wants the surviving alleles
+        }
+        // the dense list of the second pass: one returning atomic per unit that has any (its wait drains the line in flight: rare)
+        {
+            const bool listed = (OP == OP_LOAD) ? again : deferred;
+            const unsigned long long bal = __ballot(listed);
+            if (bal) {
+                unsigned long long basev = 0;
+                if (lane == 0) basev = atomicAdd(second_count, (unsigned long long)__popcll(bal));
+                basev = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(basev >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)basev);
+                if (listed) second[basev + __popcll(bal & ((1ull << lane) - 1ull))] = l;
+            }
+        }
+        if (OP == OP_LOAD) return;
+        // ---- close the locus ------------------------------------------------------------------------------------------------------
+        int nout = 0, idsp = 0;
+        double mf = NAN, st[K], pv[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) { st[t] = NAN; pv[t] = NAN; }
+        const bool simple = alive && !deferred;
+        if (OP == OP_CHISQ) {
+            // every surviving allele is listed (column order), alive or not (the row of the locus)
+            int r = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool kpj = (slotmask >> j) & 1;
+                idsp |= kpj ? (aj(j) << (3 * r)) : 0;
+                r += kpj ? 1 : 0;
+            }
+            idsp |= nk << 16;
+            if (__any(simple)) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc = ((slotmask >> j) & 1) ? acc + fv[(NJ + j) < NFV ? NJ + j : 0] / fv[j < NFV ? j : 0] : acc;
+                const double chi2 = fv[(2 * NJ) < NFV ? 2 * NJ : 0] * (acc - 1.0) + pz; // tables/chisq_test.rs:15-31 regrouped
+                const double df = (double)(n * nk) - 1.0;
+                const double p = pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)); // :33-35
+                if (simple) { st[0] = chi2; pv[0] = p; nout = nk; }
+            }
+        } else if (__any(simple)) {
+            if (OP == OP_OLS) {
+                double cs1[1], xx1[1][1], xy1[1][MAXK], b1[MAXK][1], p1[MAXK][1];
+                cs1[0] = fv[0] + pz;
+                xx1[0][0] = fv[1 < NFV ? 1 : 0] + pz;
+#pragma unroll
+                for (int t = 0; t < MAXK; ++t) xy1[0][t] = (t < K) ? fv[(2 + t) < NFV ? 2 + t : 0] + pz : 0.0;
+                bool singular;
+                ols_solve<2>(cs1, xx1, xy1, K, P, tcoef, singular, b1, p1);
+                if (simple && !singular) { // Err -> the whole locus is dropped (ols.rs:250-253)
+                    nout = 1;
+                    idsp = (fh >> 12) & 7;
+                    mf = cs1[0] / (double)n; // ols.rs:266
+#pragma unroll
+                    for (int t = 0; t < K; ++t) { st[t] = b1[t][0]; pv[t] = p1[t][0]; }
+                }
+            } else { // OP_PEARSON
+                double rr, pp;
+                pearson_close(fv[1 < NFV ? 1 : 0], fv[2 < NFV ? 2 : 0], fv[3 < NFV ? 3 : 0], fv[4 < NFV ? 4 : 0], fv[5 < NFV ? 5 : 0],
+                              fv[6 < NFV ? 6 : 0], n, P, tcoef, rr, pp);
+                if (simple) {
+                    nout = 1;
+                    idsp = (fh >> 12) & 7;
+                    mf = (fv[0] + pz) / (double)n; // x.mean(), :119: the plain mean is NaN with an uncovered pool
+                    st[0] = rr; pv[0] = pp;
+                }
+            }
+        }
+        // a deferred locus gets the "dropped" pattern here; k_locus_close overwrites it later in the stream
+        if (staged) put_result(lane * M + fin_i, nout, idsp, mf, st, pv);
+        else if (valid) store_result(l, nout, idsp, mf, st, pv);
+    };
+
+    // the unit's results as contiguous runs: lane -> locus round * 64 + lane of the unit
+    auto flush_unit = [&](int64_t unit) {
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < M; ++r) {
+            const int idx = r * 64 + lane;
+            const int64_t l = unit * lpu + idx;
+            if (l < L) {
+                if (OP == OP_LOAD) rec_flags[l] = *reinterpret_cast<const int32_t *>(stage + (size_t)idx * 4);
+                else {
+                    const char *rp = stage + (size_t)idx * RECB;
+                    const uint2_t h = *reinterpret_cast<const uint2_t *>(rp);
+                    double st[K], pv[K];
+#pragma unroll
+                    for (int t = 0; t < K; ++t) {
+                        st[t] = *reinterpret_cast<const double *>(rp + 16 + 16 * t);
+                        pv[t] = *reinterpret_cast<const double *>(rp + 24 + 16 * t);
+                    }
+                    store_result(l, (int)h.x, (int)h.y, *reinterpret_cast<const double *>(rp + 8), st, pv);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int64_t cur_u = wid;
+    if (n < ST_PPT) {
+        // fewer pools than a ring turn holds: several loci could end inside one turn.  Such rows are at most 360 bytes; every lane
+        // reads its own stream straight from memory, pool by pool (same sums, same closing, no staging of lines)
+        for (; cur_u < nunits; cur_u += wstride) {
+            A.clear();
+            pi = 0; iloc = 0; fin_pending = false;
+            const uint64_t so = ((uint64_t)cur_u * 64u + (uint64_t)lane) * srb; // this lane's stream
+            for (int sp = 0; sp < npool; ++sp) {
+                const uint64_t o = so + (uint64_t)sp * 24u;
+                uint2_t wv[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+                if (o + 24u <= total_bytes) {
+                    const uint2_t *g = reinterpret_cast<const uint2_t *>(reinterpret_cast<const char *>(counts) + o);
+                    wv[0] = g[0]; wv[1] = g[1]; wv[2] = g[2];
+                }
+                pool(wv[0], wv[1], wv[2], read_tab(pi), std::true_type{});
+                if (fin_pending) {
+                    finish(cur_u);
+                    fin_pending = false;
+                }
+            }
+            if (staged) flush_unit(cur_u);
+        }
+        return;
+    }
+    // ---- one step: land the line that was in flight, request the next one, run the pools that end in this line ----------
+    issue_line();
+    while (cur_u < nunits) {
+        A.clear();
+        pi = 0; iloc = 0; fin_pending = false;
+        const int nturn = nh / 3; // a stream is a whole number of lines AND of pools: a whole number of turns (384 = lcm(128, 24))
+        // a ring turn: three lines, sixteen pools
+        auto turn = [&](auto chkc) {
+            static_for<0, 3>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                __builtin_amdgcn_wave_barrier();
+                land_line(); // the compiler waits for the registers
+                __builtin_amdgcn_wave_barrier();
+                issue_line(); // in flight while this line is computed
+                // the pools whose LAST byte lies in this line: slots JFIRST .. JLAST of the turn
+                constexpr int JFIRST = (s * 128) / 24;            // first j with 24 j + 23 >= 128 s
+                constexpr int JLAST = ((s + 1) * 128 - 24) / 24;  // last j with 24 j + 23 < 128 (s + 1)
+                auto read_words = [&](auto jc, uint2_t (&wv)[3]) {
+                    constexpr int j = decltype(jc)::value;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int uw = 24 * j + 8 * k - s * 128; // offset inside this line; < 0: one of the two carried words
+                        if (uw >= 0) wv[k] = *reinterpret_cast<const uint2_t *>(cell + (uw / 64) * 1024 + ((uw / 16) & 3) * 256 + (uw & 8));
+                        else wv[k] = (uw == -16) ? cy0 : cy1;
+                    }
+                };
+                // one pool ahead, by hand: the reads of pool j + 1 are issued in front of the arithmetic of pool j (the test for the
+                // locus' end makes every pool a basic block of its own, and the compiler does not move loads across those: left alone,
+                // every pool exposed two LDS round trips)
+                uint2_t wc[3], wn[3];
+                TabRow tc, tn;
+                read_words(std::integral_constant<int, JFIRST>{}, wc);
+                tc = read_tab(pi);
+                static_for<JFIRST, JLAST + 1>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (j < JLAST) {
+                        read_words(std::integral_constant<int, j + 1>{}, wn);
+                        tn = read_tab(pi + 1 == n ? 0 : pi + 1);
+                    }
+                    pool(wc[0], wc[1], wc[2], tc, chkc);
+                    if constexpr (j < JLAST) {
+                        wc[0] = wn[0]; wc[1] = wn[1]; wc[2] = wn[2];
+                        tc = tn;
+                    }
+                });
+                { // the last 16 bytes of this line, for a pool that starts here and ends in the next line
+                    const uint4_t tl = *reinterpret_cast<const uint4_t *>(cell + 1024 + 3 * 256);
+                    cy0 = uint2_t{tl.x, tl.y};
+                    cy1 = uint2_t{tl.z, tl.w};
+                }
+            });
+        };
+        for (int T = 0; T < nturn; ++T) {
+            turn(std::true_type{});
+            if (fin_pending) { // (at most one locus ends per turn: n >= 16 pools, checked by the host)
+                finish(cur_u);
+                fin_pending = false;
+            }
+        }
+        if (staged) flush_unit(cur_u);
+        cur_u += wstride;
+    }
+}
+
+// ---- second pass: only the loci the first pass listed ----------------------------------------------
+// One lane per listed locus (rows gathered through the list), sums over the SURVIVING alleles only.
+template <int OP, int PB, int K>
+__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
+    const uint32_t *__restrict__ counts, const double *__restrict__ Y, int32_t *__restrict__ rec_flags,
+    double *__restrict__ rec, const int64_t *__restrict__ second,
+    const unsigned long long *__restrict__ second_count, const LocusParams P) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    char *tile = lds_raw + wave * LO_TILEB;
+    int64_t *lidx = reinterpret_cast<int64_t *>(lds_raw + LO_WAVES * LO_TILEB) + wave * 64;
+    const char *row = tile + lane * LO_PITCH;
+    const int n = P.n;
+    const int nfull = n / LO_CHP;
+    const int nst = (n + LO_CHP - 1) / LO_CHP;
+    const int64_t cnt = (int64_t)*second_count;
+    const int64_t ntiles = (cnt + 63) / 64;
+    const int64_t wstride = (int64_t)gridDim.x * LO_WAVES;
+    auto aj = [](int jj) { return jj; };
+    StageRegs S;
+    Sums<OP, NA, K> A;
+    for (int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave; t < ntiles; t += wstride) {
+        const int64_t e = t * 64 + lane;
+        const int64_t l = second[e < cnt ? e : cnt - 1];
+        lidx[lane] = l;
+        __builtin_amdgcn_wave_barrier();
+        const int64_t slot = unit_slot(l, P.pshift);
+        const int mask = rec_flags[slot];
+        bool keep[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) keep[j] = (mask & (2 << j)) != 0;
+        auto rowsel = [&](int r) { return lidx[r]; };
+        A.clear();
+        int n_missing = 0;
+        for (int st = 0; st < nst; ++st) {
+            const int pool0 = st * LO_CHP;
+            const int np = st < nfull ? LO_CHP : n - pool0;
+            if (st < nfull) {
+                stage_load<PB, false>(S, counts, n, pool0, np, lane, rowsel);
+                stage_store<PB, false>(S, tile, np, lane);
+            } else {
+                stage_load<8, true>(S, counts, n, pool0, np, lane, rowsel);
+                stage_store<8, true>(S, tile, np, lane);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int i = 0; i < np; ++i) {
+                const uint2_t a = *reinterpret_cast<const uint2_t *>(row + i * 24);
+                const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
+                const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
+                const uint32_t c[NA] = {a.x, a.y, b.x, b.y, d.x, d.y};
+                double cd[NA], f[NA];
+                double rs = 0.0; // row sum over the surviving alleles (second to_frequencies, sync.rs:170-175)
+#pragma unroll
+                for (int j = 0; j < NA; ++j) { cd[j] = keep[j] ? (double)c[j] : 0.0; rs = rs + cd[j]; }
+                const bool rowok = rs != 0.0;
+                const double rsd = rowok ? rs : 1.0;
+                const double rinv = recip_for_div(rsd);
+                n_missing += rowok ? 0 : 1;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) f[j] = div_by(cd[j], rsd, rinv);
+                A.add_pool(f, rowok, Y + (size_t)(pool0 + i) * K);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        emit_record<OP, NA, K>(A, n_missing > 0, keep, true, false, e < cnt, rec_flags, rec, slot, aj, P.sort_desc != 0);
+    }
+}
+
+// ---- closing kernel: one thread per locus of the second pass' list, from the compact record (see emit_record) -----
+template <int PN>
+__device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t rb, int k, int ordbits, bool alive,
+                                          const double *__restrict__ tcoef, int32_t *__restrict__ n_out,
+                                          int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
+                                          double *__restrict__ stat_out, double *__restrict__ pv_out, int64_t l,
+                                          const LocusParams &P) {
+    constexpr int D = PN - 1;
+    const int n = P.n;
+    const int kk = k; // 1 or 2 traits in this launch: the record was laid out with K = k
+    double cs[D], xxs[D][D], xy[D][MAXK];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int f0 = d * (1 + kk) + d * (d + 1) / 2;
+        cs[d] = rec[rb + (size_t)f0 * 64];
+#pragma unroll
+        for (int t = 0; t < MAXK; ++t) xy[d][t] = (t < kk) ? rec[rb + (size_t)(f0 + 1 + t) * 64] : 0.0;
+#pragma unroll
+        for (int c = 0; c <= d; ++c) {
+            const double v = rec[rb + (size_t)(f0 + 1 + kk + c) * 64];
+            xxs[d][c] = v;
+            xxs[c][d] = v;
+        }
+    }
+    bool singular;
+    double bo[MAXK][D], po[MAXK][D];
+    ols_solve<PN>(cs, xxs, xy, kk, P, tcoef, singular, bo, po);
+    const bool ok = alive && !singular; // Err -> the whole locus is dropped (ols.rs:250-253)
+    if (P.t0 == 0) {
+        n_out[l] = ok ? D : 0;
+#pragma unroll
+        for (int r = 0; r < PG_MAX_OUT; ++r) {
+            const bool on = ok && r < D;
+            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * (r + 1))) & 7) : -1;
+            mf_out[l * PG_MAX_OUT + r] = on ? cs[r < D ? r : 0] / (double)n : NAN; // ols.rs:266
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < MAXK; ++tt) {
+        if (tt >= k) continue;
+#pragma unroll
+        for (int r = 0; r < PG_MAX_OUT; ++r) {
+            const bool on = ok && r < D;
+            stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? bo[tt][r < D ? r : 0] : NAN;
+            pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? po[tt][r < D ? r : 0] : NAN;
         }
     }
 }
@@ -1012,98 +1268,162 @@ __device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t
 template <int OP>
 __global__ __launch_bounds__(64) void k_locus_close(const int32_t *__restrict__ rec_flags,
                                                     const double *__restrict__ rec,
-                                                    const double *__restrict__ tcoef, int32_t *__restrict__ n_out,
+                                                    const double *__restrict__ tcoef,
+                                                    const int64_t *__restrict__ second,
+                                                    const unsigned long long *__restrict__ second_count,
+                                                    int32_t *__restrict__ n_out,
                                                     int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
                                                     double *__restrict__ stat_out, double *__restrict__ pv_out,
                                                     const LocusParams P) {
-    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inr = l < P.L;
-    const int n = P.n, k = P.k;
-    const int64_t slot = unit_slot(inr ? l : P.L - 1, P.pshift);
-    const size_t rb = rec_base(slot);
-    const int hdr = rec_flags[slot];
-    const bool alive = inr && (hdr & FLAG_ALIVE) != 0;
-    const int nk = (hdr >> H_NK_SHIFT) & 7;
-    const int ordbits = hdr >> H_ORD_SHIFT;
+    // only the loci the streaming pass listed: everything else was closed there
+    const int64_t cnt = (int64_t)*second_count;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t l = second[e];
+        const int n = P.n, k = P.k;
+        const int64_t slot = unit_slot(l, P.pshift);
+        const size_t rb = rec_base(slot);
+        const int hdr = rec_flags[slot];
+        const bool alive = (hdr & FLAG_ALIVE) != 0;
+        const int nk = (hdr >> H_NK_SHIFT) & 7;
+        const int ordbits = hdr >> H_ORD_SHIFT;
 
-    if (OP == OP_CHISQ) {
-        if (!inr) return;
-        // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
+        if (OP == OP_CHISQ) {
+            // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
 #pragma unroll
-        for (int r = 0; r < PG_MAX_OUT; ++r) ids_out[l * PG_MAX_OUT + r] = (r < nk) ? ((ordbits >> (3 * r)) & 7) : -1;
-        const double chi2 = alive ? rec[rb] : NAN;
-        const double df = (double)(n * nk) - 1.0;
-        n_out[l] = alive ? nk : 0;
-        stat_out[l] = chi2;
-        pv_out[l] = alive ? pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)) : NAN;
-        return;
-    }
-
-    if (OP == OP_PEARSON) {
-        if (!inr) return;
-        // gwas/correlation_test.rs:94-126: all surviving alleles but the LAST, unsorted
-        const int nout = alive ? (nk >= 2 ? nk - 1 : nk) : 0;
-        n_out[l] = nout;
-#pragma unroll
-        for (int r = 0; r < PG_MAX_OUT; ++r) {
-            const bool on = r < nout;
-            const int f0 = 3 * k + r * (1 + 3 * k);
-            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * r)) & 7) : -1;
-            mf_out[l * PG_MAX_OUT + r] = on ? rec[rb + (size_t)f0 * 64] / (double)n : NAN; // x.mean(), :119
-#pragma unroll
-            for (int tt = 0; tt < MAXK; ++tt) {
-                if (tt >= k) continue;
-                double rr = NAN, pp = NAN;
-                if (on) {
-                    const double sy = rec[rb + (size_t)(3 * tt) * 64], syy = rec[rb + (size_t)(3 * tt + 1) * 64],
-                                 m = rec[rb + (size_t)(3 * tt + 2) * 64];
-                    const double sx = rec[rb + (size_t)(f0 + 1 + 3 * tt) * 64], sxx = rec[rb + (size_t)(f0 + 2 + 3 * tt) * 64],
-                                 sxy = rec[rb + (size_t)(f0 + 3 + 3 * tt) * 64];
-                    const double cxy = sxy - sx * sy / m;
-                    const double cxx = sxx - sx * sx / m;
-                    const double cyy = syy - sy * sy / m;
-                    const double r0 = cxy / (sqrt(cxx) * sqrt(cyy));      // :50-52
-                    if (isnan(r0)) { rr = NAN; pp = NAN; }                // :53-56
-                    else {
-                        const double sden = (1.0 - r0 * r0) / ((double)n - 2.0); // :57
-                        if (sden <= 0.0) { rr = r0; pp = PG_EPS; }         // :58-61
-                        else {
-                            const double tstat = r0 / sqrt(sden);
-                            pp = (n > 2) ? pg_t_two_sided_p(fabs(tstat), P.tdf, tcoef, P.ntcoef) : NAN;
-                            rr = round(r0 * 1e7) / 1e7; // sensible_round(r, 7), :70 (half away from zero)
-                        }
-                    }
-                }
-                stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = rr;
-                pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
-            }
+            for (int r = 0; r < PG_MAX_OUT; ++r) ids_out[l * PG_MAX_OUT + r] = (r < nk) ? ((ordbits >> (3 * r)) & 7) : -1;
+            const double chi2 = alive ? rec[rb] : NAN;
+            const double df = (double)(n * nk) - 1.0;
+            n_out[l] = alive ? nk : 0;
+            stat_out[l] = chi2;
+            pv_out[l] = alive ? pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)) : NAN;
+            continue;
         }
-        return;
-    }
 
-    // ---------------- OP_OLS ----------------------------------------------------------------------
-    const int pn = alive ? nk : 0;
-    if (inr && pn < 2) { // not emitted: ols.rs:215-237
-        if (P.t0 == 0) {
-            n_out[l] = 0;
-#pragma unroll
-            for (int r = 0; r < PG_MAX_OUT; ++r) { ids_out[l * PG_MAX_OUT + r] = -1; mf_out[l * PG_MAX_OUT + r] = NAN; }
-        }
-        for (int tt = 0; tt < k; ++tt)
+        if (OP == OP_PEARSON) {
+            // gwas/correlation_test.rs:94-126: all surviving alleles but the LAST, unsorted
+            const int nout = alive ? (nk >= 2 ? nk - 1 : nk) : 0;
+            n_out[l] = nout;
 #pragma unroll
             for (int r = 0; r < PG_MAX_OUT; ++r) {
-                stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
-                pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
+                const bool on = r < nout;
+                const int f0 = 3 * k + r * (1 + 3 * k);
+                ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * r)) & 7) : -1;
+                mf_out[l * PG_MAX_OUT + r] = on ? rec[rb + (size_t)f0 * 64] / (double)n : NAN; // x.mean(), :119
+#pragma unroll
+                for (int tt = 0; tt < MAXK; ++tt) {
+                    if (tt >= k) continue;
+                    double rr = NAN, pp = NAN;
+                    if (on)
+                        pearson_close(rec[rb + (size_t)(f0 + 1 + 3 * tt) * 64], rec[rb + (size_t)(f0 + 2 + 3 * tt) * 64],
+                                      rec[rb + (size_t)(f0 + 3 + 3 * tt) * 64], rec[rb + (size_t)(3 * tt) * 64],
+                                      rec[rb + (size_t)(3 * tt + 1) * 64], rec[rb + (size_t)(3 * tt + 2) * 64], n, P, tcoef, rr, pp);
+                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = rr;
+                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
+                }
             }
+            continue;
+        }
+
+        // ---------------- OP_OLS ----------------------------------------------------------------------
+        const int pn = alive ? nk : 0;
+        if (pn < 2) { // not emitted: ols.rs:215-237
+            if (P.t0 == 0) {
+                n_out[l] = 0;
+#pragma unroll
+                for (int r = 0; r < PG_MAX_OUT; ++r) { ids_out[l * PG_MAX_OUT + r] = -1; mf_out[l * PG_MAX_OUT + r] = NAN; }
+            }
+            for (int tt = 0; tt < k; ++tt)
+#pragma unroll
+                for (int r = 0; r < PG_MAX_OUT; ++r) {
+                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
+                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
+                }
+        }
+        static_for<2, NA + 1>([&](auto pc) {
+            constexpr int PNc = decltype(pc)::value;
+            if (pn == PNc)
+                ols_close<PNc>(rec, rb, k, ordbits, alive, tcoef, n_out, ids_out, mf_out, stat_out, pv_out, l, P);
+        });
     }
-    static_for<2, NA + 1>([&](auto pc) {
-        constexpr int PNc = decltype(pc)::value;
-        if (inr && pn == PNc)
-            ols_close<PNc>(rec, rb, k, ordbits, alive, tcoef, n_out, ids_out, mf_out, stat_out, pv_out, l, P);
-    });
 }
 
 // ---------------------------------------------------------------------------------------------
+// The passes of one launch group (a trait pair, or the loader's plan): the streaming pass over every locus, then the second
+// pass + closing of the loci it listed (both leave at once when the list is empty).
+inline int stream_period(int n) { // loci per lane: the smallest count whose bytes are whole 128-byte lines
+    int period = 1;
+    while ((((int64_t)n * 24 * period) & 127) != 0) period *= 2;
+    return period;
+}
+
+struct StreamWs { // device pointers into the context's workspace
+    double *table;              // n x TW: w_i, y_i0, ... for the streaming pass
+    double *Y;                  // n x MAXK for the second pass
+    double *tcoef;
+    double *rec;                // records of the second pass, one per locus (touched only for listed loci)
+    int64_t *second;
+    unsigned long long *second_count;
+    int32_t *flags;
+};
+
+template <int OP>
+int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, const StreamOut &O, const LocusParams &P, int kg, bool rns) {
+    const int n = P.n;
+    const int64_t L = P.L;
+    const int M = stream_period(n);
+    const int TW = (OP == OP_OLS || OP == OP_PEARSON) ? 1 + kg : 1;
+    const int recb = (OP == OP_LOAD) ? 4 : 16 + 16 * kg;
+    const int staged = (size_t)64 * M * recb <= (size_t)ST_STAGE ? 1 : 0;
+    const size_t shmem = (size_t)LO_WAVES * (ST_SLOTB + ST_STAGE) + sizeof(double) * (size_t)TW * n;
+    PG_CHECK(ctx, shmem <= 160 * 1024, "locus op: too many pools (%d) for the pool table in LDS", n);
+    const int64_t nunits = (L + (int64_t)64 * M - 1) / ((int64_t)64 * M);
+    const int64_t blocks = (nunits + LO_WAVES - 1) / LO_WAVES;
+    const int64_t cap = (int64_t)ctx->cus * LO_BLOCKS_DEF; // the resident blocks: one long sequence of units per wave
+    const int grid = (int)(blocks < cap ? blocks : cap);
+    auto pick = [&]() -> const void * {
+        if (OP == OP_OLS && kg == 2)
+            return rns ? (const void *)k_locus_stream<OP, true, (OP == OP_OLS ? 2 : 1)> : (const void *)k_locus_stream<OP, false, (OP == OP_OLS ? 2 : 1)>;
+        return rns ? (const void *)k_locus_stream<OP, true, 1> : (const void *)k_locus_stream<OP, false, 1>;
+    };
+    const void *kstream = pick();
+    PG_HIP(ctx, hipFuncSetAttribute(kstream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    PG_HIP(ctx, hipMemsetAsync(W.second_count, 0, 8, ctx->stream));
+    {
+        const double *a1 = W.table, *a2 = W.tcoef;
+        int32_t *a3 = W.flags;
+        int64_t *a4 = W.second;
+        unsigned long long *a5 = W.second_count;
+        int mm = M, st = staged;
+        void *args[] = {(void *)&counts_dev, &a1, &a2, &a3, &a4, &a5, (void *)&O, (void *)&P, &mm, &st};
+        PG_HIP(ctx, hipLaunchKernel(kstream, dim3(grid), dim3(LO_THREADS), args, shmem, ctx->stream));
+    }
+    // the listed loci: sums over the SURVIVING alleles from the counts, then the closing arithmetic from the records
+    const bool p16 = ((int64_t)n * 24) % 16 == 0;
+    auto pick_second = [&]() -> const void * {
+        if (OP == OP_OLS && kg == 2)
+            return p16 ? (const void *)k_locus_second<OP, 16, (OP == OP_OLS ? 2 : 1)> : (const void *)k_locus_second<OP, 8, (OP == OP_OLS ? 2 : 1)>;
+        return p16 ? (const void *)k_locus_second<OP, 16, 1> : (const void *)k_locus_second<OP, 8, 1>;
+    };
+    const void *ksecond = pick_second();
+    const size_t shmem2 = (size_t)LO_WAVES * LO_TILEB + (size_t)LO_WAVES * 64 * sizeof(int64_t);
+    PG_HIP(ctx, hipFuncSetAttribute(ksecond, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+    {
+        const double *a2 = W.Y;
+        int32_t *b0 = W.flags;
+        double *recp = W.rec;
+        const int64_t *b1 = W.second;
+        const unsigned long long *b2 = W.second_count;
+        void *args2[] = {(void *)&counts_dev, &a2, &b0, &recp, &b1, &b2, (void *)&P};
+        const int64_t tiles_cap = (int64_t)ctx->cus * 2;
+        PG_HIP(ctx, hipLaunchKernel(ksecond, dim3((unsigned)tiles_cap), dim3(LO_THREADS), args2, shmem2, ctx->stream));
+    }
+    if (OP != OP_LOAD)
+        hipLaunchKernelGGL(k_locus_close<(OP == OP_LOAD ? OP_OLS : OP)>, dim3((unsigned)(ctx->cus * 4)), dim3(64), 0, ctx->stream, W.flags, W.rec,
+                           W.tcoef, W.second, W.second_count, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
+    PG_HIP(ctx, hipGetLastError());
+    return PG_OK;
+}
+
 template <int OP>
 int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, int n,
                  const double *pool_sizes, const pg_filter *flt, const double *Y, int k,
@@ -1126,64 +1446,37 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     for (int i = 0; i < n; ++i) w[i] = pool_sizes[i] / total;
     const int df = (OP == OP_OLS) ? n - 1 : n - 2; // ols.rs:139 / correlation_test.rs:65
     std::vector<double> tc = pg_tdist_coef(df < 1 ? 1 : df);
-    const size_t side = ((size_t)n + (size_t)n * MAXK + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
-    // rows whose start has the same offset inside a 128-byte line are `period` apart (see k_locus_first)
-    int period = 1;
-    while ((((int64_t)n * 24 * period) & 127) != 0) period *= 2;
-    PG_CHECK(ctx, (int64_t)64 * period * n * 24 < ((int64_t)1 << 31), "locus op: too many pools (%d) for one batch row group", n);
-    const int64_t nunits = ((L + 64 * (int64_t)period - 1) / (64 * (int64_t)period)) * period;
-    const size_t recd = (size_t)nunits * 64 * REC_DOUBLES; // unit-major: 64 slots per unit
-    // workspace: [w | Y | tcoef] [records] [second-pass list: L x i64] [its length: u64] [per-unit masks: u64] [flags: i32 per slot]
-    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 8 + 8 * (size_t)nunits +
-                        sizeof(int32_t) * (size_t)nunits * 64;
+    const int M = stream_period(n);
+    PG_CHECK(ctx, (int64_t)64 * M * n * 24 < ((int64_t)1 << 31), "locus op: too many pools (%d) for one unit of loci", n);
+    // workspace: [table n x 3 | Y n x MAXK | tcoef] [records of the second pass] [its list: L x i64] [its length: u64] [flags: i32 per locus]
+    const size_t side = ((size_t)n * 3 + (size_t)n * MAXK + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
+    const size_t slots = (size_t)((L + 63) / 64) * 64;
+    const size_t recd = slots * REC_DOUBLES;
+    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 8 + sizeof(int32_t) * slots;
     int rc = pg_ws_reserve(ctx, need);
     if (rc) return rc;
-    double *wd = static_cast<double *>(ctx->ws);
-    double *Ydev = wd + n;
-    double *tcd = Ydev + (size_t)n * MAXK;
-    double *recp = wd + side;
-    int64_t *second = reinterpret_cast<int64_t *>(recp + recd);
-    unsigned long long *second_count = reinterpret_cast<unsigned long long *>(second + L);
-    unsigned long long *unit_again = second_count + 1;
-    int32_t *recf = reinterpret_cast<int32_t *>(unit_again + nunits);
-    PG_HIP(ctx, hipMemcpyAsync(wd, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    StreamWs W;
+    W.table = static_cast<double *>(ctx->ws);
+    W.Y = W.table + (size_t)n * 3;
+    W.tcoef = W.Y + (size_t)n * MAXK;
+    W.rec = W.table + side;
+    W.second = reinterpret_cast<int64_t *>(W.rec + recd);
+    W.second_count = reinterpret_cast<unsigned long long *>(W.second + L);
+    W.flags = reinterpret_cast<int32_t *>(W.second_count + 1);
     if (!tc.empty())
-        PG_HIP(ctx, hipMemcpyAsync(tcd, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
-    const int cus = ctx->cus;
-    const int64_t ntiles = (L + 63) / 64;
-    int64_t blocks = (ntiles + LO_WAVES - 1) / LO_WAVES;
-#ifndef LO_GRID_PER_CU
-#define LO_GRID_PER_CU LO_BLOCKS_DEF
-#endif
-    const int64_t cap = (int64_t)cus * LO_GRID_PER_CU; // = the resident blocks (2 waves/SIMD): one long item sequence per wave
-    const int grid = (int)(blocks < cap ? blocks : cap);
-    const size_t shmem = (size_t)LO_WAVES * LN_TILEB;
-    const size_t shmem2 = (size_t)LO_WAVES * LO_TILEB + (size_t)LO_WAVES * 64 * sizeof(int64_t);
-    const bool p16 = ((int64_t)n * 24) % 16 == 0;
+        PG_HIP(ctx, hipMemcpyAsync(W.tcoef, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
     const bool rns = flt->remove_ns != 0;
-    auto pick_first = [&](int kg) -> const void * {
-        auto sel = [&](auto kc) -> const void * {
-            constexpr int KC = decltype(kc)::value;
-            return rns ? (const void *)k_locus_first<OP, true, KC> : (const void *)k_locus_first<OP, false, KC>;
-        };
-        if (OP == OP_CHISQ || kg == 1) return sel(std::integral_constant<int, 1>{});
-        return sel(std::integral_constant<int, (OP == OP_CHISQ ? 1 : 2)>{});
-    };
-    auto pick_second = [&](int kg) -> const void * {
-        if (OP == OP_CHISQ || kg == 1)
-            return p16 ? (const void *)k_locus_second<OP, 16, 1> : (const void *)k_locus_second<OP, 8, 1>;
-        return p16 ? (const void *)k_locus_second<OP, 16, (OP == OP_CHISQ ? 1 : 2)>
-                   : (const void *)k_locus_second<OP, 8, (OP == OP_CHISQ ? 1 : 2)>;
-    };
-
-    std::vector<double> Yd((size_t)n * MAXK);
-    for (int t0 = 0; t0 < k; t0 += MAXK) { // the filter passes are recomputed per trait pair
-        const int kg = (k - t0) < MAXK ? (k - t0) : MAXK;
+    const StreamOut O{n_out, ids, mf, stat, pv};
+    // pearson_corr takes one trait per launch (its sums per trait and allele do not fit two traits at two waves per SIMD)
+    const int kstep = (OP == OP_OLS) ? MAXK : 1;
+    std::vector<double> Yd((size_t)n * MAXK), tab((size_t)n * 3);
+    for (int t0 = 0; t0 < k; t0 += kstep) { // the filter passes are recomputed per launch group
+        const int kg = (k - t0) < kstep ? (k - t0) : kstep;
         LocusParams P;
         std::memset(&P, 0, sizeof P);
         P.L = L; P.n = n; P.k = kg; P.k_total = k; P.t0 = t0;
         P.remove_ns = flt->remove_ns ? 1 : 0;
-        P.pshift = __builtin_ctz((unsigned)period);
+        P.pshift = 0; // records and flags are indexed by the locus
         P.min_cov = (double)flt->min_coverage_depth;
         P.maf = flt->min_allele_frequency;
         P.max_miss = flt->max_missingness_rate;
@@ -1213,30 +1506,18 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
                 for (int i = 0; i < n; ++i) Yd[(size_t)i * kg + t] = Y[(size_t)i * k + t0 + t] - sh;
             }
         }
-        PG_HIP(ctx, hipMemcpyAsync(Ydev, Yd.data(), sizeof(double) * n * MAXK, hipMemcpyHostToDevice, ctx->stream));
-        const void *kfirst = pick_first(kg), *ksecond = pick_second(kg);
-        PG_HIP(ctx, hipFuncSetAttribute(kfirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        PG_HIP(ctx, hipFuncSetAttribute(ksecond, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
-        PG_HIP(ctx, hipMemsetAsync(second_count, 0, 8, ctx->stream));
-        pg_prof_begin(ctx, kid);
-        {
-            const uint32_t *a0 = counts_dev;
-            const double *a1 = wd, *a2 = Ydev;
-            void *args1[] = {&a0, &a1, &a2, &recf, &recp, &unit_again, &P, &period};
-            PG_HIP(ctx, hipLaunchKernel(kfirst, dim3(grid), dim3(LO_THREADS), args1, shmem, ctx->stream));
-            hipLaunchKernelGGL(k_locus_compact, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, ctx->stream,
-                               unit_again, nunits, period, second, second_count);
-            const int32_t *b0 = recf;
-            const int64_t *b1 = second;
-            const unsigned long long *b2 = second_count;
-            void *args2[] = {&a0, &a2, &b0, &recp, &b1, &b2, &P};
-            PG_HIP(ctx, hipLaunchKernel(ksecond, dim3(grid), dim3(LO_THREADS), args2, shmem2, ctx->stream));
+        const int TW = (OP == OP_OLS || OP == OP_PEARSON) ? 1 + kg : 1;
+        for (int i = 0; i < n; ++i) {
+            tab[(size_t)i * TW] = w[i];
+            for (int t = 0; t + 1 < TW; ++t) tab[(size_t)i * TW + 1 + t] = Yd[(size_t)i * kg + t];
         }
-        hipLaunchKernelGGL(k_locus_close<OP>, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, ctx->stream, recf, recp, tcd,
-                           n_out, ids, mf, stat, pv, P);
+        PG_HIP(ctx, hipMemcpyAsync(W.table, tab.data(), sizeof(double) * n * TW, hipMemcpyHostToDevice, ctx->stream));
+        PG_HIP(ctx, hipMemcpyAsync(W.Y, Yd.data(), sizeof(double) * n * MAXK, hipMemcpyHostToDevice, ctx->stream));
+        pg_prof_begin(ctx, kid);
+        rc = launch_passes<OP>(ctx, counts_dev, W, O, P, kg, rns);
         pg_prof_end(ctx);
-        PG_HIP(ctx, hipGetLastError());
-        PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // Yd is reused by the next trait pair
+        if (rc) return rc;
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // tab / Yd are reused by the next launch group
     }
     return PG_OK;
 }
@@ -1388,19 +1669,17 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     double total = 0.0;
     for (int i = 0; i < n; ++i) total = total + pool_sizes[i];
     for (int i = 0; i < n; ++i) w[i] = pool_sizes[i] / total; // sync.rs:266-268
-    int period = 1;
-    while ((((int64_t)n * 24 * period) & 127) != 0) period *= 2;
-    PG_CHECK(ctx, (int64_t)64 * period * n * 24 < ((int64_t)1 << 31), "load: too many pools (%d) for one batch row group", n);
-    const int64_t nunits = ((L + 64 * (int64_t)period - 1) / (64 * (int64_t)period)) * period;
+    const int M = stream_period(n);
+    PG_CHECK(ctx, (int64_t)64 * M * n * 24 < ((int64_t)1 << 31), "load: too many pools (%d) for one unit of loci", n);
+    const size_t slots = (size_t)((L + 63) / 64) * 64;
     const int64_t nb = (L + 255) / 256;
-    // workspace: [w][flags: i32 per slot][second list: L x i64][its length][unit masks][local: L x i32][blocksum][blockoff][total][pool map]
+    // workspace: [w][flags: i32 per locus][second list: L x i64][its length][local: L x i32][blocksum][blockoff][total][pool map]
     auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t off = 0;
     const size_t o_w = off; off = al16(off + sizeof(double) * n);
-    const size_t o_flags = off; off = al16(off + sizeof(int32_t) * (size_t)nunits * 64);
+    const size_t o_flags = off; off = al16(off + sizeof(int32_t) * slots);
     const size_t o_second = off; off = al16(off + sizeof(int64_t) * (size_t)L);
     const size_t o_count = off; off = al16(off + 8);
-    const size_t o_again = off; off = al16(off + 8 * (size_t)nunits);
     const size_t o_local = off; off = al16(off + sizeof(int32_t) * (size_t)L);
     const size_t o_bsum = off; off = al16(off + 8 * (size_t)nb);
     const size_t o_boff = off; off = al16(off + 8 * (size_t)nb);
@@ -1409,49 +1688,28 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     int rc = pg_ws_reserve(ctx, off);
     if (rc) return rc;
     char *ws = static_cast<char *>(ctx->ws);
-    double *wd = reinterpret_cast<double *>(ws + o_w);
-    int32_t *recf = reinterpret_cast<int32_t *>(ws + o_flags);
-    int64_t *second = reinterpret_cast<int64_t *>(ws + o_second);
-    unsigned long long *second_count = reinterpret_cast<unsigned long long *>(ws + o_count);
-    unsigned long long *unit_again = reinterpret_cast<unsigned long long *>(ws + o_again);
+    StreamWs W;
+    W.table = reinterpret_cast<double *>(ws + o_w);
+    W.Y = nullptr; W.tcoef = nullptr; W.rec = nullptr;
+    W.flags = reinterpret_cast<int32_t *>(ws + o_flags);
+    W.second = reinterpret_cast<int64_t *>(ws + o_second);
+    W.second_count = reinterpret_cast<unsigned long long *>(ws + o_count);
+    int32_t *recf = W.flags;
     int32_t *local = reinterpret_cast<int32_t *>(ws + o_local);
     int64_t *bsum = reinterpret_cast<int64_t *>(ws + o_bsum), *boff = reinterpret_cast<int64_t *>(ws + o_boff);
     int64_t *tot_dev = reinterpret_cast<int64_t *>(ws + o_total);
-    PG_HIP(ctx, hipMemcpyAsync(wd, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-    PG_HIP(ctx, hipMemsetAsync(second_count, 0, 8, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(W.table, w.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     LocusParams P;
     std::memset(&P, 0, sizeof P);
     P.L = L; P.n = n; P.k = 1; P.k_total = 1; P.t0 = 0;
     P.remove_ns = flt->remove_ns ? 1 : 0;
-    P.pshift = __builtin_ctz((unsigned)period);
+    P.pshift = 0; // flags are indexed by the locus
     P.sort_desc = keep_p_minus_1 ? 1 : 0;
     P.min_cov = (double)flt->min_coverage_depth;
     P.maf = flt->min_allele_frequency;
     P.max_miss = flt->max_missingness_rate;
-    const bool p16 = ((int64_t)n * 24) % 16 == 0;
-    const bool rns = flt->remove_ns != 0;
-    const void *kfirst = rns ? (const void *)k_locus_first<OP_LOAD, true, 1> : (const void *)k_locus_first<OP_LOAD, false, 1>;
-    const void *ksecond = p16 ? (const void *)k_locus_second<OP_LOAD, 16, 1> : (const void *)k_locus_second<OP_LOAD, 8, 1>;
-    const size_t shmem = (size_t)LO_WAVES * LN_TILEB;
-    const size_t shmem2 = (size_t)LO_WAVES * LO_TILEB + (size_t)LO_WAVES * 64 * sizeof(int64_t);
-    PG_HIP(ctx, hipFuncSetAttribute(kfirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PG_HIP(ctx, hipFuncSetAttribute(ksecond, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
-    const int64_t blocks = ((L + 63) / 64 + LO_WAVES - 1) / LO_WAVES;
-    const int64_t cap = (int64_t)ctx->cus * 2;
-    const int grid = (int)(blocks < cap ? blocks : cap);
-    {
-        const uint32_t *a0 = counts_dev;
-        const double *a1 = wd, *a2 = nullptr;
-        double *recp = nullptr;
-        void *args1[] = {&a0, &a1, &a2, &recf, &recp, &unit_again, &P, &period};
-        PG_HIP(ctx, hipLaunchKernel(kfirst, dim3(grid), dim3(LO_THREADS), args1, shmem, ctx->stream));
-        hipLaunchKernelGGL(k_locus_compact, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, ctx->stream, unit_again,
-                           nunits, period, second, second_count);
-        const int64_t *b1 = second;
-        const unsigned long long *b2 = second_count;
-        void *args2[] = {&a0, &a2, &recf, &recp, &b1, &b2, &P};
-        PG_HIP(ctx, hipLaunchKernel(ksecond, dim3(grid), dim3(LO_THREADS), args2, shmem2, ctx->stream));
-    }
+    rc = launch_passes<OP_LOAD>(ctx, counts_dev, W, StreamOut{nullptr, nullptr, nullptr, nullptr, nullptr}, P, 1, flt->remove_ns != 0);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_load_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, recf, order_dev, L, P.pshift,
                        P.sort_desc, local, bsum);
     hipLaunchKernelGGL(k_load_scan, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb, boff, tot_dev);
@@ -1462,7 +1720,7 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     *p_out = tot;
     ctx->load_valid = true;
     ctx->load_counts = counts_dev; ctx->load_order = order_dev;
-    ctx->load_L = L; ctx->load_total = tot; ctx->load_nunits = nunits;
+    ctx->load_L = L; ctx->load_total = tot; ctx->load_nunits = 0;
     ctx->load_n = n; ctx->load_kpm1 = P.sort_desc; ctx->load_pshift = P.pshift;
     ctx->load_off_flags = o_flags; ctx->load_off_local = o_local; ctx->load_off_blockoff = o_boff;
     ctx->load_off_poolmap = o_pmap;
