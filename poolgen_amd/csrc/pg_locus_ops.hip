@@ -632,21 +632,23 @@ constexpr int ST_STAGE = 8192;      // LDS bytes per wave for the results of a u
 template <int OP, int NJ, int K>
 struct Acc { // running sums of one locus, every candidate allele in play; everything accumulated sequentially in pool order
     double q[NJ], cs[NJ];
-    double dd[NJ];        // OLS: sum f^2; CHISQ: sum f^2 / rowsum
-    double xy[NJ * K];    // OLS: sum f y; PEARSON: sum x y over complete pairs
-    double px[NJ * K], pxx[NJ * K], py[K], pyy[K], pn[K], shx[NJ];
-    double total, mincov;
+    double dd[NJ];        // OLS, CHISQ: sum f^2
+    double xy[NJ * K];    // OLS: sum f y
+    // PEARSON: sums of x = z - z(first complete pool), z = sum_j j f_j, over the complete pairs (see the kernel's header)
+    double px[K], pxx[K], pxy[K], py[K], pyy[K], pn[K], shz;
+    uint32_t mincov, orm; // smallest coverage of a pool; OR of every count seen
     int n_missing;
     bool shset;
     __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { q[j] = 0.0; cs[j] = 0.0; dd[j] = 0.0; shx[j] = 0.0; }
+        for (int j = 0; j < NJ; ++j) { q[j] = 0.0; cs[j] = 0.0; dd[j] = 0.0; }
 #pragma unroll
-        for (int j = 0; j < NJ * K; ++j) { xy[j] = 0.0; px[j] = 0.0; pxx[j] = 0.0; }
+        for (int j = 0; j < NJ * K; ++j) xy[j] = 0.0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) { py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
-        total = 0.0;
-        mincov = INFINITY;
+        for (int j = 0; j < K; ++j) { px[j] = 0.0; pxx[j] = 0.0; pxy[j] = 0.0; py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
+        shz = 0.0;
+        mincov = 0xffffffffu;
+        orm = 0u;
         n_missing = 0;
         shset = false;
     }
@@ -739,6 +741,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
     int fh = 0;          // bit 0 alive | 1..6 surviving alleles | 7 again | 8..10 nk | 11 poisoned | 12..14 id of the closed allele | 15.. kept mask by slot
     bool fin_pending = false;
     int fin_i = 0;       // which of the lane's M loci it is
+    uint32_t orm_unit = 0; // OR of every count this lane has seen
     int pi = 0, iloc = 0;
     uint2_t cy0 = {0u, 0u}, cy1 = {0u, 0u}; // the last 16 bytes of the previous line
 
@@ -756,13 +759,14 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             // non-negative terms do not cancel
             dropped_with_reads = dropped_with_reads || (!kpj && A.cs[j] != 0.0);
         }
-        bool alive = !(A.mincov < P.min_cov);                                        // sync.rs:227
+        bool alive = !((double)A.mincov < P.min_cov);                                // sync.rs:227
         alive = alive && nk >= 2;                                                    // sync.rs:284
         alive = alive && A.n_missing != n;                                           // sync.rs:293
         alive = alive && !(((double)A.n_missing / (double)n) > P.max_miss);          // sync.rs:297
         const bool again = alive && dropped_with_reads;
+        orm_unit |= A.orm;
         int idc = 0;
-        if (OP == OP_OLS || OP == OP_PEARSON) {
+        if constexpr (OP == OP_OLS || OP == OP_PEARSON) {
             // the two survivors of a biallelic locus: slots sa < sb
             int sa = 0, sb = 0, seen = 0;
 #pragma unroll
@@ -781,20 +785,18 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
 #pragma unroll
             for (int j = 0; j < NJ; ++j) idc = (sc == j) ? aj(j) : idc;
             fv[0] = pickn<NJ>(A.cs, sc);
-            if (OP == OP_OLS) {
+            if constexpr (OP == OP_OLS) {
                 fv[1] = pickn<NJ>(A.dd, sc);
 #pragma unroll
                 for (int t = 0; t < K; ++t) fv[2 + t] = pick_trait<NJ, K>(A.xy, sc, t);
             } else {
-                fv[1] = pick_trait<NJ, K>(A.px, sc, 0);
-                fv[2] = pick_trait<NJ, K>(A.pxx, sc, 0);
-                fv[3] = pick_trait<NJ, K>(A.xy, sc, 0);
+                fv[1] = A.px[0]; fv[2] = A.pxx[0]; fv[3] = A.pxy[0];
                 fv[4] = A.py[0]; fv[5] = A.pyy[0]; fv[6] = A.pn[0];
             }
-        } else if (OP == OP_CHISQ) {
+        } else if constexpr (OP == OP_CHISQ) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) { fv[j] = A.cs[j]; fv[NJ + j] = A.dd[j]; }
-            fv[2 * NJ] = A.total;
+            fv[2 * NJ] = (double)(n - A.n_missing);
         } else {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fv[j] = A.cs[j];
@@ -816,21 +818,32 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
     auto pool = [&](const uint2_t &wa, const uint2_t &wb, const uint2_t &wd, const TabRow &tr, auto chkc) {
         constexpr bool CHK = decltype(chkc)::value;
         const uint32_t c0[6] = {wa.x, wa.y, wb.x, wb.y, wd.x, wd.y};
-        double cd[NJ], f[NJ];
+#ifdef LS_EXP_NOCOMPUTE
+        if (c0[0] == 0xdeadbeefu && tr.w == 1.5) A.q[0] += (double)(c0[1] + c0[2] + c0[3] + c0[4] + c0[5]);
+        if (CHK) { if (++pi == n) { pi = 0; boundary(); fin_i = iloc++; fin_pending = true; A.clear(); } }
+        return;
+#endif
+        uint32_t ci[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) cd[j] = (double)c0[aj(j)];
-        double rs = cd[0]; // row sum over the alleles in play, in column order (sync.rs:217-222 / :170-175); 0 + c0 = c0 exactly
+        for (int j = 0; j < NJ; ++j) ci[j] = c0[aj(j)];
+        // coverage of the pool over the alleles in play (sync.rs:217-222 / :170-175), in integers: the reference adds the counts as
+        // f64, exact below 2^53, so any order and any exact arithmetic gives its value -- as long as the 32-bit sum does not wrap,
+        // which `orm` (every count < 2^29, checked at the end of the unit) guarantees
+        uint32_t rsi = ci[0];
+        uint32_t orv = ci[0];
 #pragma unroll
-        for (int j = 1; j < NJ; ++j) rs = rs + cd[j];
-        const bool rowok = rs != 0.0;
+        for (int j = 1; j < NJ; ++j) { rsi += ci[j]; orv |= ci[j]; }
+        A.orm |= orv;
+        const bool rowok = rsi != 0u;
+        A.mincov = rsi < A.mincov ? rsi : A.mincov;          // sync.rs:223-227
+        A.n_missing += rowok ? 0 : 1;
         // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0, divided by 1) and the pool
         // is counted in n_missing, which poisons / skips what NaN would
-        const double rsd = fmax(rs, 1.0);
+        const double rsd = (double)(rsi > 1u ? rsi : 1u);
         const double rinv = recip_for_div(rsd);
+        double f[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) f[j] = div_by(cd[j], rsd, rinv);
-        A.mincov = fmin(A.mincov, rs);                       // sync.rs:223-227
-        A.n_missing += rowok ? 0 : 1;
+        for (int j = 0; j < NJ; ++j) f[j] = div_by((double)ci[j], rsd, rinv);
         const double wi = tr.w;
         // q += f * w_i with separate multiply and add; NaN frequencies contribute 0 (sync.rs:258-271)
 #pragma unroll
@@ -847,37 +860,32 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 for (int j = 0; j < NJ; ++j) A.xy[j * K + tt] = fma(f[j], y, A.xy[j * K + tt]);
             }
         } else if (OP == OP_PEARSON) {
-            if (rowok && !A.shset) {
+            // ONE regressor for every allele: z = sum_j j f_j.  This pass only closes loci with two surviving alleles a < b whose
+            // other alleles have no reads at all: there f_a + f_b = 1 in every covered pool, z = b - (b - a) f_a, and the
+            // correlation of f_a with y is minus that of z (correlation_test.rs:36-52 is invariant under x -> c0 + c1 x).
+            double z = f[1];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) A.shx[j] = f[j];
-                A.shset = true;
-            }
+            for (int j = 2; j < NJ; ++j) z = fma((double)j, f[j], z);
+            if (rowok && !A.shset) { A.shz = z; A.shset = true; } // shift by the first covered pool's value: small numbers in the sums
 #pragma unroll
             for (int tt = 0; tt < K; ++tt) {
                 const double y = tr.y[tt];             // shifted by its first valid value on the host
                 const bool ok = rowok && !isnan(y);    // pairwise complete (correlation_test.rs:22-26)
                 const double ye = ok ? y : 0.0;        // an incomplete pair contributes exact zeros instead of being skipped
+                const double x = ok ? z - A.shz : 0.0;
                 A.py[tt] = A.py[tt] + ye;
                 A.pyy[tt] = fma(ye, ye, A.pyy[tt]);
                 A.pn[tt] = A.pn[tt] + (ok ? 1.0 : 0.0);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const double x = ok ? f[j] - A.shx[j] : 0.0;
-                    const int e = j * K + tt;
-                    A.px[e] = A.px[e] + x;
-                    A.pxx[e] = fma(x, x, A.pxx[e]);
-                    A.xy[e] = fma(x, ye, A.xy[e]);
-                }
+                A.px[tt] = A.px[tt] + x;
+                A.pxx[tt] = fma(x, x, A.pxx[tt]);
+                A.pxy[tt] = fma(x, ye, A.pxy[tt]);
             }
-        } else if (OP == OP_CHISQ) { // chi2 = total * (sum_j A_j / cs_j - 1), A_j = sum_i f_ij^2 / rowsum_i
-            double rsum = 0.0;
+        } else if (OP == OP_CHISQ) {
+            // chi2 = total * (sum_j A_j / cs_j - 1) with A_j = sum_i f_ij^2 / rowsum_i and total = sum_i rowsum_i (tables/chisq_test.rs:15-31
+            // regrouped).  The row sum of a covered pool's frequencies is 1 to an ulp, so A_j = sum f^2 and total = the covered pools,
+            // within a few ulp of the reference's value (statistics are compared at 1e-10)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) rsum = rsum + f[j]; // row sum of the frequencies (~1)
-            A.total = A.total + rsum;
-            const double rsd2 = rowok ? rsum : 1.0;
-            const double ri = recip_for_div(rsd2);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) A.dd[j] = A.dd[j] + div_by(f[j] * f[j], rsd2, ri);
+            for (int j = 0; j < NJ; ++j) A.dd[j] = fma(f[j], f[j], A.dd[j]);
         }
         // the locus' last pool: decide, keep what the closing needs (it runs at the end of the turn) and start the next locus
         if constexpr (CHK) {
@@ -904,6 +912,9 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
     };
     // the operator's output arrays of locus l from one result
     auto store_result = [&](int64_t l, int nout, int idsp, double mf, const double (&st)[K], const double (&pv)[K]) {
+#ifdef LS_EXP_NOSTORE // (timing experiments only: tools/exp_locus.sh)
+        if (nout != 12345) return;
+#endif
         const int nk = (idsp >> 16) & 7;
         if (OP == OP_CHISQ) {
             O.n_out[l] = nout;
@@ -980,7 +991,11 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
         double mf = NAN, st[K], pv[K];
 #pragma unroll
         for (int t = 0; t < K; ++t) { st[t] = NAN; pv[t] = NAN; }
+#ifdef LS_EXP_NOCLOSE
+        const bool simple = alive && !deferred && nk == 12345;
+#else
         const bool simple = alive && !deferred;
+#endif
         if (OP == OP_CHISQ) {
             // every surviving allele is listed (column order), alive or not (the row of the locus)
             int r = 0;
@@ -1024,7 +1039,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                     nout = 1;
                     idsp = (fh >> 12) & 7;
                     mf = (fv[0] + pz) / (double)n; // x.mean(), :119: the plain mean is NaN with an uncovered pool
-                    st[0] = rr; pv[0] = pp;
+                    st[0] = -rr; pv[0] = pp;       // the sums are those of z = b - (b - a) f_a: the correlation changes sign
                 }
             }
         }
@@ -1079,6 +1094,10 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 }
             }
             if (staged) flush_unit(cur_u);
+            if (__any((orm_unit >> 29) != 0u)) {
+                if (lane == 0) atomicOr(second_count + 1, 1ull);
+                orm_unit = 0;
+            }
         }
         return;
     }
@@ -1137,22 +1156,156 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
         for (int T = 0; T < nturn; ++T) {
             turn(std::true_type{});
             if (fin_pending) { // (at most one locus ends per turn: n >= 16 pools, checked by the host)
+#ifndef LS_EXP_NOFINISH
                 finish(cur_u);
+#endif
                 fin_pending = false;
             }
         }
+#ifndef LS_EXP_NOFLUSH
         if (staged) flush_unit(cur_u);
+#endif
+        if (__any((orm_unit >> 29) != 0u)) { // a count the 32-bit coverage sums cannot take: the host reports it
+            if (lane == 0) atomicOr(second_count + 1, 1ull);
+            orm_unit = 0;
+        }
         cur_u += wstride;
     }
+}
+
+// ---- closing arithmetic of a locus of the second pass' list, from the compact record (see emit_record) -----
+template <int PN>
+__device__ __forceinline__ void ols_close(const double *rec, size_t rb, int k, int ordbits, bool alive,
+                                          const double *__restrict__ tcoef, int32_t *__restrict__ n_out,
+                                          int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
+                                          double *__restrict__ stat_out, double *__restrict__ pv_out, int64_t l,
+                                          const LocusParams &P) {
+    constexpr int D = PN - 1;
+    const int n = P.n;
+    const int kk = k; // 1 or 2 traits in this launch: the record was laid out with K = k
+    double cs[D], xxs[D][D], xy[D][MAXK];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int f0 = d * (1 + kk) + d * (d + 1) / 2;
+        cs[d] = rec[rb + (size_t)f0 * 64];
+#pragma unroll
+        for (int t = 0; t < MAXK; ++t) xy[d][t] = (t < kk) ? rec[rb + (size_t)(f0 + 1 + t) * 64] : 0.0;
+#pragma unroll
+        for (int c = 0; c <= d; ++c) {
+            const double v = rec[rb + (size_t)(f0 + 1 + kk + c) * 64];
+            xxs[d][c] = v;
+            xxs[c][d] = v;
+        }
+    }
+    bool singular;
+    double bo[MAXK][D], po[MAXK][D];
+    ols_solve<PN>(cs, xxs, xy, kk, P, tcoef, singular, bo, po);
+    const bool ok = alive && !singular; // Err -> the whole locus is dropped (ols.rs:250-253)
+    if (P.t0 == 0) {
+        n_out[l] = ok ? D : 0;
+#pragma unroll
+        for (int r = 0; r < PG_MAX_OUT; ++r) {
+            const bool on = ok && r < D;
+            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * (r + 1))) & 7) : -1;
+            mf_out[l * PG_MAX_OUT + r] = on ? cs[r < D ? r : 0] / (double)n : NAN; // ols.rs:266
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < MAXK; ++tt) {
+        if (tt >= k) continue;
+#pragma unroll
+        for (int r = 0; r < PG_MAX_OUT; ++r) {
+            const bool on = ok && r < D;
+            stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? bo[tt][r < D ? r : 0] : NAN;
+            pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? po[tt][r < D ? r : 0] : NAN;
+        }
+    }
+}
+
+template <int OP>
+__device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_flags,
+                                            const double *rec, const double *__restrict__ tcoef,
+                                            int32_t *__restrict__ n_out, int32_t *__restrict__ ids_out,
+                                            double *__restrict__ mf_out, double *__restrict__ stat_out,
+                                            double *__restrict__ pv_out, const LocusParams &P) {
+    // (only the loci the streaming pass listed come here: everything else was closed there)
+    do {
+        const int n = P.n, k = P.k;
+        const int64_t slot = unit_slot(l, P.pshift);
+        const size_t rb = rec_base(slot);
+        const int hdr = rec_flags[slot];
+        const bool alive = (hdr & FLAG_ALIVE) != 0;
+        const int nk = (hdr >> H_NK_SHIFT) & 7;
+        const int ordbits = hdr >> H_ORD_SHIFT;
+
+        if (OP == OP_CHISQ) {
+            // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
+#pragma unroll
+            for (int r = 0; r < PG_MAX_OUT; ++r) ids_out[l * PG_MAX_OUT + r] = (r < nk) ? ((ordbits >> (3 * r)) & 7) : -1;
+            const double chi2 = alive ? rec[rb] : NAN;
+            const double df = (double)(n * nk) - 1.0;
+            n_out[l] = alive ? nk : 0;
+            stat_out[l] = chi2;
+            pv_out[l] = alive ? pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)) : NAN;
+            break;
+        }
+
+        if (OP == OP_PEARSON) {
+            // gwas/correlation_test.rs:94-126: all surviving alleles but the LAST, unsorted
+            const int nout = alive ? (nk >= 2 ? nk - 1 : nk) : 0;
+            n_out[l] = nout;
+#pragma unroll
+            for (int r = 0; r < PG_MAX_OUT; ++r) {
+                const bool on = r < nout;
+                const int f0 = 3 * k + r * (1 + 3 * k);
+                ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * r)) & 7) : -1;
+                mf_out[l * PG_MAX_OUT + r] = on ? rec[rb + (size_t)f0 * 64] / (double)n : NAN; // x.mean(), :119
+#pragma unroll
+                for (int tt = 0; tt < MAXK; ++tt) {
+                    if (tt >= k) continue;
+                    double rr = NAN, pp = NAN;
+                    if (on)
+                        pearson_close(rec[rb + (size_t)(f0 + 1 + 3 * tt) * 64], rec[rb + (size_t)(f0 + 2 + 3 * tt) * 64],
+                                      rec[rb + (size_t)(f0 + 3 + 3 * tt) * 64], rec[rb + (size_t)(3 * tt) * 64],
+                                      rec[rb + (size_t)(3 * tt + 1) * 64], rec[rb + (size_t)(3 * tt + 2) * 64], n, P, tcoef, rr, pp);
+                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = rr;
+                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
+                }
+            }
+            break;
+        }
+
+        // ---------------- OP_OLS ----------------------------------------------------------------------
+        const int pn = alive ? nk : 0;
+        if (pn < 2) { // not emitted: ols.rs:215-237
+            if (P.t0 == 0) {
+                n_out[l] = 0;
+#pragma unroll
+                for (int r = 0; r < PG_MAX_OUT; ++r) { ids_out[l * PG_MAX_OUT + r] = -1; mf_out[l * PG_MAX_OUT + r] = NAN; }
+            }
+            for (int tt = 0; tt < k; ++tt)
+#pragma unroll
+                for (int r = 0; r < PG_MAX_OUT; ++r) {
+                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
+                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
+                }
+        }
+        static_for<2, NA + 1>([&](auto pc) {
+            constexpr int PNc = decltype(pc)::value;
+            if (pn == PNc)
+                ols_close<PNc>(rec, rb, k, ordbits, alive, tcoef, n_out, ids_out, mf_out, stat_out, pv_out, l, P);
+        });
+    } while (false);
 }
 
 // ---- second pass: only the loci the first pass listed ----------------------------------------------
 // One lane per listed locus (rows gathered through the list), sums over the SURVIVING alleles only.
 template <int OP, int PB, int K>
 __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
-    const uint32_t *__restrict__ counts, const double *__restrict__ Y, int32_t *__restrict__ rec_flags,
-    double *__restrict__ rec, const int64_t *__restrict__ second,
-    const unsigned long long *__restrict__ second_count, const LocusParams P) {
+    const uint32_t *__restrict__ counts, const double *__restrict__ Y, int32_t *rec_flags,
+    double *rec, const int64_t *__restrict__ second,
+    const unsigned long long *__restrict__ second_count, const double *__restrict__ tcoef, const StreamOut O,
+    const LocusParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1213,139 +1366,14 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
             __builtin_amdgcn_wave_barrier();
         }
         emit_record<OP, NA, K>(A, n_missing > 0, keep, true, false, e < cnt, rec_flags, rec, slot, aj, P.sort_desc != 0);
-    }
-}
-
-// ---- closing kernel: one thread per locus of the second pass' list, from the compact record (see emit_record) -----
-template <int PN>
-__device__ __forceinline__ void ols_close(const double *__restrict__ rec, size_t rb, int k, int ordbits, bool alive,
-                                          const double *__restrict__ tcoef, int32_t *__restrict__ n_out,
-                                          int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
-                                          double *__restrict__ stat_out, double *__restrict__ pv_out, int64_t l,
-                                          const LocusParams &P) {
-    constexpr int D = PN - 1;
-    const int n = P.n;
-    const int kk = k; // 1 or 2 traits in this launch: the record was laid out with K = k
-    double cs[D], xxs[D][D], xy[D][MAXK];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int f0 = d * (1 + kk) + d * (d + 1) / 2;
-        cs[d] = rec[rb + (size_t)f0 * 64];
-#pragma unroll
-        for (int t = 0; t < MAXK; ++t) xy[d][t] = (t < kk) ? rec[rb + (size_t)(f0 + 1 + t) * 64] : 0.0;
-#pragma unroll
-        for (int c = 0; c <= d; ++c) {
-            const double v = rec[rb + (size_t)(f0 + 1 + kk + c) * 64];
-            xxs[d][c] = v;
-            xxs[c][d] = v;
-        }
-    }
-    bool singular;
-    double bo[MAXK][D], po[MAXK][D];
-    ols_solve<PN>(cs, xxs, xy, kk, P, tcoef, singular, bo, po);
-    const bool ok = alive && !singular; // Err -> the whole locus is dropped (ols.rs:250-253)
-    if (P.t0 == 0) {
-        n_out[l] = ok ? D : 0;
-#pragma unroll
-        for (int r = 0; r < PG_MAX_OUT; ++r) {
-            const bool on = ok && r < D;
-            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * (r + 1))) & 7) : -1;
-            mf_out[l * PG_MAX_OUT + r] = on ? cs[r < D ? r : 0] / (double)n : NAN; // ols.rs:266
-        }
-    }
-#pragma unroll
-    for (int tt = 0; tt < MAXK; ++tt) {
-        if (tt >= k) continue;
-#pragma unroll
-        for (int r = 0; r < PG_MAX_OUT; ++r) {
-            const bool on = ok && r < D;
-            stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? bo[tt][r < D ? r : 0] : NAN;
-            pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? po[tt][r < D ? r : 0] : NAN;
+        if (OP != OP_LOAD) {
+            // close the locus from the record just written (same lane; the fence orders its loads behind its stores)
+            __threadfence();
+            if (e < cnt) close_locus<(OP == OP_LOAD ? OP_OLS : OP)>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
         }
     }
 }
 
-template <int OP>
-__global__ __launch_bounds__(64) void k_locus_close(const int32_t *__restrict__ rec_flags,
-                                                    const double *__restrict__ rec,
-                                                    const double *__restrict__ tcoef,
-                                                    const int64_t *__restrict__ second,
-                                                    const unsigned long long *__restrict__ second_count,
-                                                    int32_t *__restrict__ n_out,
-                                                    int32_t *__restrict__ ids_out, double *__restrict__ mf_out,
-                                                    double *__restrict__ stat_out, double *__restrict__ pv_out,
-                                                    const LocusParams P) {
-    // only the loci the streaming pass listed: everything else was closed there
-    const int64_t cnt = (int64_t)*second_count;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t l = second[e];
-        const int n = P.n, k = P.k;
-        const int64_t slot = unit_slot(l, P.pshift);
-        const size_t rb = rec_base(slot);
-        const int hdr = rec_flags[slot];
-        const bool alive = (hdr & FLAG_ALIVE) != 0;
-        const int nk = (hdr >> H_NK_SHIFT) & 7;
-        const int ordbits = hdr >> H_ORD_SHIFT;
-
-        if (OP == OP_CHISQ) {
-            // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
-#pragma unroll
-            for (int r = 0; r < PG_MAX_OUT; ++r) ids_out[l * PG_MAX_OUT + r] = (r < nk) ? ((ordbits >> (3 * r)) & 7) : -1;
-            const double chi2 = alive ? rec[rb] : NAN;
-            const double df = (double)(n * nk) - 1.0;
-            n_out[l] = alive ? nk : 0;
-            stat_out[l] = chi2;
-            pv_out[l] = alive ? pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)) : NAN;
-            continue;
-        }
-
-        if (OP == OP_PEARSON) {
-            // gwas/correlation_test.rs:94-126: all surviving alleles but the LAST, unsorted
-            const int nout = alive ? (nk >= 2 ? nk - 1 : nk) : 0;
-            n_out[l] = nout;
-#pragma unroll
-            for (int r = 0; r < PG_MAX_OUT; ++r) {
-                const bool on = r < nout;
-                const int f0 = 3 * k + r * (1 + 3 * k);
-                ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * r)) & 7) : -1;
-                mf_out[l * PG_MAX_OUT + r] = on ? rec[rb + (size_t)f0 * 64] / (double)n : NAN; // x.mean(), :119
-#pragma unroll
-                for (int tt = 0; tt < MAXK; ++tt) {
-                    if (tt >= k) continue;
-                    double rr = NAN, pp = NAN;
-                    if (on)
-                        pearson_close(rec[rb + (size_t)(f0 + 1 + 3 * tt) * 64], rec[rb + (size_t)(f0 + 2 + 3 * tt) * 64],
-                                      rec[rb + (size_t)(f0 + 3 + 3 * tt) * 64], rec[rb + (size_t)(3 * tt) * 64],
-                                      rec[rb + (size_t)(3 * tt + 1) * 64], rec[rb + (size_t)(3 * tt + 2) * 64], n, P, tcoef, rr, pp);
-                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = rr;
-                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
-                }
-            }
-            continue;
-        }
-
-        // ---------------- OP_OLS ----------------------------------------------------------------------
-        const int pn = alive ? nk : 0;
-        if (pn < 2) { // not emitted: ols.rs:215-237
-            if (P.t0 == 0) {
-                n_out[l] = 0;
-#pragma unroll
-                for (int r = 0; r < PG_MAX_OUT; ++r) { ids_out[l * PG_MAX_OUT + r] = -1; mf_out[l * PG_MAX_OUT + r] = NAN; }
-            }
-            for (int tt = 0; tt < k; ++tt)
-#pragma unroll
-                for (int r = 0; r < PG_MAX_OUT; ++r) {
-                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
-                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
-                }
-        }
-        static_for<2, NA + 1>([&](auto pc) {
-            constexpr int PNc = decltype(pc)::value;
-            if (pn == PNc)
-                ols_close<PNc>(rec, rb, k, ordbits, alive, tcoef, n_out, ids_out, mf_out, stat_out, pv_out, l, P);
-        });
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // The passes of one launch group (a trait pair, or the loader's plan): the streaming pass over every locus, then the second
@@ -1387,7 +1415,7 @@ int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, co
     };
     const void *kstream = pick();
     PG_HIP(ctx, hipFuncSetAttribute(kstream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PG_HIP(ctx, hipMemsetAsync(W.second_count, 0, 8, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(W.second_count, 0, 16, ctx->stream)); // the list's length, and the streaming pass' complaint flag
     {
         const double *a1 = W.table, *a2 = W.tcoef;
         int32_t *a3 = W.flags;
@@ -1397,7 +1425,7 @@ int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, co
         void *args[] = {(void *)&counts_dev, &a1, &a2, &a3, &a4, &a5, (void *)&O, (void *)&P, &mm, &st};
         PG_HIP(ctx, hipLaunchKernel(kstream, dim3(grid), dim3(LO_THREADS), args, shmem, ctx->stream));
     }
-    // the listed loci: sums over the SURVIVING alleles from the counts, then the closing arithmetic from the records
+    // the listed loci, ONE launch: sums over the SURVIVING alleles from the counts, then the closing arithmetic from the record
     const bool p16 = ((int64_t)n * 24) % 16 == 0;
     auto pick_second = [&]() -> const void * {
         if (OP == OP_OLS && kg == 2)
@@ -1413,13 +1441,11 @@ int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, co
         double *recp = W.rec;
         const int64_t *b1 = W.second;
         const unsigned long long *b2 = W.second_count;
-        void *args2[] = {(void *)&counts_dev, &a2, &b0, &recp, &b1, &b2, (void *)&P};
+        const double *b3 = W.tcoef;
+        void *args2[] = {(void *)&counts_dev, &a2, &b0, &recp, &b1, &b2, &b3, (void *)&O, (void *)&P};
         const int64_t tiles_cap = (int64_t)ctx->cus * 2;
         PG_HIP(ctx, hipLaunchKernel(ksecond, dim3((unsigned)tiles_cap), dim3(LO_THREADS), args2, shmem2, ctx->stream));
     }
-    if (OP != OP_LOAD)
-        hipLaunchKernelGGL(k_locus_close<(OP == OP_LOAD ? OP_OLS : OP)>, dim3((unsigned)(ctx->cus * 4)), dim3(64), 0, ctx->stream, W.flags, W.rec,
-                           W.tcoef, W.second, W.second_count, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
     PG_HIP(ctx, hipGetLastError());
     return PG_OK;
 }
@@ -1452,7 +1478,7 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     const size_t side = ((size_t)n * 3 + (size_t)n * MAXK + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
     const size_t slots = (size_t)((L + 63) / 64) * 64;
     const size_t recd = slots * REC_DOUBLES;
-    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 8 + sizeof(int32_t) * slots;
+    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 16 + sizeof(int32_t) * slots;
     int rc = pg_ws_reserve(ctx, need);
     if (rc) return rc;
     StreamWs W;
@@ -1462,7 +1488,7 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     W.rec = W.table + side;
     W.second = reinterpret_cast<int64_t *>(W.rec + recd);
     W.second_count = reinterpret_cast<unsigned long long *>(W.second + L);
-    W.flags = reinterpret_cast<int32_t *>(W.second_count + 1);
+    W.flags = reinterpret_cast<int32_t *>(W.second_count + 2);
     if (!tc.empty())
         PG_HIP(ctx, hipMemcpyAsync(W.tcoef, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
     const bool rns = flt->remove_ns != 0;
@@ -1517,7 +1543,10 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
         rc = launch_passes<OP>(ctx, counts_dev, W, O, P, kg, rns);
         pg_prof_end(ctx);
         if (rc) return rc;
+        unsigned long long complaint = 0;
+        PG_HIP(ctx, hipMemcpyAsync(&complaint, W.second_count + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
         PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // tab / Yd are reused by the next launch group
+        PG_CHECK(ctx, complaint == 0, "locus op: a count of 2^29 (536 870 912) reads or more: beyond what the streaming pass sums exactly");
     }
     return PG_OK;
 }
@@ -1679,7 +1708,7 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     const size_t o_w = off; off = al16(off + sizeof(double) * n);
     const size_t o_flags = off; off = al16(off + sizeof(int32_t) * slots);
     const size_t o_second = off; off = al16(off + sizeof(int64_t) * (size_t)L);
-    const size_t o_count = off; off = al16(off + 8);
+    const size_t o_count = off; off = al16(off + 16);
     const size_t o_local = off; off = al16(off + sizeof(int32_t) * (size_t)L);
     const size_t o_bsum = off; off = al16(off + 8 * (size_t)nb);
     const size_t o_boff = off; off = al16(off + 8 * (size_t)nb);
@@ -1715,8 +1744,11 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     hipLaunchKernelGGL(k_load_scan, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb, boff, tot_dev);
     PG_HIP(ctx, hipGetLastError());
     int64_t tot = 0;
+    unsigned long long complaint = 0;
     PG_HIP(ctx, hipMemcpyAsync(&tot, tot_dev, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(&complaint, W.second_count + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PG_CHECK(ctx, complaint == 0, "load: a count of 2^29 (536 870 912) reads or more: beyond what the streaming pass sums exactly");
     *p_out = tot;
     ctx->load_valid = true;
     ctx->load_counts = counts_dev; ctx->load_order = order_dev;

@@ -9,7 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from poolgen_amd import Engine, Filter, synth
 
 def timeit(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+    fn(); fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize()
@@ -27,8 +27,9 @@ def main():
     for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(counts, ps, f, Y), "ols_iter"),
                           ("pearson_corr", lambda: eng.correlation(counts, ps, f, Y), "pearson"),
                           ("chisq_test", lambda: eng.chisq(counts, ps, f), "chisq")):
+        fn(); fn(); fn()
         eng.profile_reset()
-        dt = timeit(fn)
+        dt = timeit(fn, reps=20)
         ms, cnt = eng.profile_get(kid)
         kms = ms / max(cnt, 1)
         print(json.dumps({"op": name, "pools": n, "loci": L, "wall_ms": dt * 1e3, "kernel_ms": kms,
