@@ -719,7 +719,11 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 reinterpret_cast<char *>(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 8; ++i) // the two halves of a row group's line in consecutive instructions
+#ifdef LS_EXP_NTLOAD
+                SR[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vb[i >> 1] + (uint32_t)(i & 1) * 64u, 0, 2);
+#else
                 SR[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vb[i >> 1] + (uint32_t)(i & 1) * 64u, 0, 0);
+#endif
             if (++pre_h >= nh) { pre_h = 0; pre_u += wstride; }
         }
     };
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 ordbits |= ((slotmask >> j) & 1) ? (aj(j) << (3 * r)) : 0;
             }
             const int hdr = (alive ? FLAG_ALIVE : 0) | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT) | (ordbits << H_ORD_SHIFT);
-            if (staged) *reinterpret_cast<int32_t *>(stage + (size_t)(lane * M + fin_i) * 4) = hdr;
+            if (staged & 1) *reinterpret_cast<int32_t *>(stage + (size_t)(lane * M + fin_i) * 4) = hdr;
             else if (valid) rec_flags[l] = hdr;
         } else if (deferred) {
             rec_flags[l] = FLAG_ALIVE | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT); // the second pass wants the surviving alleles
@@ -1044,30 +1048,115 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             }
         }
         // a deferred locus gets the "dropped" pattern here; k_locus_close overwrites it later in the stream
-        if (staged) put_result(lane * M + fin_i, nout, idsp, mf, st, pv);
+        if (staged & 1) put_result(lane * M + fin_i, nout, idsp, mf, st, pv);
         else if (valid) store_result(l, nout, idsp, mf, st, pv);
     };
 
-    // the unit's results as contiguous runs: lane -> locus round * 64 + lane of the unit
+    // the unit's results leave as contiguous runs: the loci of a unit are consecutive, so every output array has ONE contiguous
+    // region per unit, written in 16-byte pieces by consecutive lanes (piece -> its elements -> (locus, slot) -> the staged result).
+    // Per-lane stores of a locus' own 4 .. 40 bytes (the layout is locus-major with PG_MAX_OUT slots, of which a closed locus
+    // fills one) reached memory as partial lines: 87 us per million loci at 100 pools, a fifth of the pass.
+    const bool coalesced = (staged & 2) != 0; // the host checked: 16-byte aligned arrays, every trait of the call in this launch
     auto flush_unit = [&](int64_t unit) {
         __builtin_amdgcn_wave_barrier();
-        for (int r = 0; r < M; ++r) {
-            const int idx = r * 64 + lane;
-            const int64_t l = unit * lpu + idx;
-            if (l < L) {
-                if (OP == OP_LOAD) rec_flags[l] = *reinterpret_cast<const int32_t *>(stage + (size_t)idx * 4);
-                else {
-                    const char *rp = stage + (size_t)idx * RECB;
-                    const uint2_t h = *reinterpret_cast<const uint2_t *>(rp);
-                    double st[K], pv[K];
+#ifdef LS_EXP_SMALLOUT // (timing experiment: every unit writes the first unit's region -- the stores stay, the memory traffic goes)
+        const int64_t l0 = 0;
+        const int nv = (int)lpu;
+#else
+        const int64_t l0 = unit * lpu;
+        const int nv = (int)((L - l0) < lpu ? (L - l0) : lpu); // loci of this unit that exist
+#endif
+        if (OP == OP_LOAD) {
+            for (int idx = lane; idx < nv; idx += 64) rec_flags[l0 + idx] = *reinterpret_cast<const int32_t *>(stage + (size_t)idx * 4);
+        } else if (!coalesced) {
+            for (int idx = lane; idx < nv; idx += 64) {
+                const char *rp = stage + (size_t)idx * RECB;
+                const uint2_t h = *reinterpret_cast<const uint2_t *>(rp);
+                double st[K], pv[K];
 #pragma unroll
-                    for (int t = 0; t < K; ++t) {
-                        st[t] = *reinterpret_cast<const double *>(rp + 16 + 16 * t);
-                        pv[t] = *reinterpret_cast<const double *>(rp + 24 + 16 * t);
-                    }
-                    store_result(l, (int)h.x, (int)h.y, *reinterpret_cast<const double *>(rp + 8), st, pv);
+                for (int t = 0; t < K; ++t) {
+                    st[t] = *reinterpret_cast<const double *>(rp + 16 + 16 * t);
+                    pv[t] = *reinterpret_cast<const double *>(rp + 24 + 16 * t);
                 }
+                store_result(l0 + idx, (int)h.x, (int)h.y, *reinterpret_cast<const double *>(rp + 8), st, pv);
             }
+        } else {
+#ifndef LS_EXP_NOSTORE
+            // one array: EPL elements per locus, element (j, sub) = get(j, sub); 16 bytes per lane and store
+            auto emit32 = [&](int32_t *base, auto eplc, auto get) {
+                constexpr int EPL = decltype(eplc)::value;
+                const int ne = nv * EPL;
+                int32_t *dst = base + l0 * EPL;
+                for (int c = lane; c * 4 < ne; c += 64) {
+                    int v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = c * 4 + u;
+                        const int j = e / EPL;
+                        v[u] = get(j < nv ? j : nv - 1, e - j * EPL);
+                    }
+#ifndef LS_EXP_PLAINSTORE // results are written once and not read by this launch: non-temporal (measured: -25 .. -35 us per million loci)
+                    if (c * 4 + 3 < ne) __builtin_nontemporal_store(uint4_t{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]}, reinterpret_cast<uint4_t *>(dst + c * 4));
+#else
+                    if (c * 4 + 3 < ne) *reinterpret_cast<uint4_t *>(dst + c * 4) = uint4_t{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+#endif
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (c * 4 + u < ne) dst[c * 4 + u] = v[u];
+                    }
+                }
+            };
+            auto emit64 = [&](double *base, auto eplc, auto get) {
+                constexpr int EPL = decltype(eplc)::value;
+                const int ne = nv * EPL;
+                double *dst = base + l0 * EPL;
+                for (int c = lane; c * 2 < ne; c += 64) {
+                    double v[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int e = c * 2 + u;
+                        const int j = e / EPL;
+                        v[u] = get(j < nv ? j : nv - 1, e - j * EPL);
+                    }
+#ifndef LS_EXP_PLAINSTORE
+                    typedef double d2v __attribute__((ext_vector_type(2)));
+                    if (c * 2 + 1 < ne) __builtin_nontemporal_store(d2v{v[0], v[1]}, reinterpret_cast<d2v *>(dst + c * 2));
+#else
+                    if (c * 2 + 1 < ne) *reinterpret_cast<double2 *>(dst + c * 2) = double2{v[0], v[1]};
+#endif
+                    else dst[c * 2] = v[0];
+                }
+            };
+            auto hdr_of = [&](int j) { return *reinterpret_cast<const uint2_t *>(stage + (size_t)j * RECB); };
+            auto dbl_of = [&](int j, int off) { return *reinterpret_cast<const double *>(stage + (size_t)j * RECB + off); };
+            if (OP == OP_CHISQ) {
+                emit32(O.n_out, std::integral_constant<int, 1>{}, [&](int j, int) { return (int)hdr_of(j).x; });
+                emit32(O.ids, std::integral_constant<int, PG_MAX_OUT>{}, [&](int j, int r) {
+                    const int idsp = (int)hdr_of(j).y;
+                    return r < ((idsp >> 16) & 7) ? ((idsp >> (3 * r)) & 7) : -1;
+                });
+                emit64(O.stat, std::integral_constant<int, 1>{}, [&](int j, int) { return dbl_of(j, 16); });
+                emit64(O.pv, std::integral_constant<int, 1>{}, [&](int j, int) { return dbl_of(j, 24); });
+            } else {
+                if (P.t0 == 0 || OP == OP_PEARSON) {
+                    emit32(O.n_out, std::integral_constant<int, 1>{}, [&](int j, int) { return (int)hdr_of(j).x; });
+                    emit32(O.ids, std::integral_constant<int, PG_MAX_OUT>{}, [&](int j, int r) {
+                        const uint2_t h = hdr_of(j);
+                        return r < (int)h.x ? (int)(h.y & 7u) : -1; // (only single-output loci are closed in this pass)
+                    });
+                    emit64(O.mf, std::integral_constant<int, PG_MAX_OUT>{}, [&](int j, int r) { return r < (int)hdr_of(j).x ? dbl_of(j, 8) : NAN; });
+                }
+                // [locus][slot][trait], every trait of the call in this launch (k_total == K, t0 == 0)
+                emit64(O.stat, std::integral_constant<int, PG_MAX_OUT * K>{}, [&](int j, int sub) {
+                    const int r = sub / K, t = sub - r * K;
+                    return r < (int)hdr_of(j).x ? dbl_of(j, 16 + 16 * t) : NAN;
+                });
+                emit64(O.pv, std::integral_constant<int, PG_MAX_OUT * K>{}, [&](int j, int sub) {
+                    const int r = sub / K, t = sub - r * K;
+                    return r < (int)hdr_of(j).x ? dbl_of(j, 24 + 16 * t) : NAN;
+                });
+            }
+#endif
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -1093,7 +1182,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                     fin_pending = false;
                 }
             }
-            if (staged) flush_unit(cur_u);
+            if (staged & 1) flush_unit(cur_u);
             if (__any((orm_unit >> 29) != 0u)) {
                 if (lane == 0) atomicOr(second_count + 1, 1ull);
                 orm_unit = 0;
@@ -1163,7 +1252,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             }
         }
 #ifndef LS_EXP_NOFLUSH
-        if (staged) flush_unit(cur_u);
+        if (staged & 1) flush_unit(cur_u);
 #endif
         if (__any((orm_unit >> 29) != 0u)) { // a count the 32-bit coverage sums cannot take: the host reports it
             if (lane == 0) atomicOr(second_count + 1, 1ull);
@@ -1401,7 +1490,11 @@ int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, co
     const int M = stream_period(n);
     const int TW = (OP == OP_OLS || OP == OP_PEARSON) ? 1 + kg : 1;
     const int recb = (OP == OP_LOAD) ? 4 : 16 + 16 * kg;
-    const int staged = (size_t)64 * M * recb <= (size_t)ST_STAGE ? 1 : 0;
+    int staged = (size_t)64 * M * recb <= (size_t)ST_STAGE ? 1 : 0; // bit 0: results staged per unit in LDS; bit 1: written as 16-byte pieces
+    if (staged && OP != OP_LOAD) {
+        auto al16 = [](const void *q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        if (P.k_total == kg && P.t0 == 0 && al16(O.n_out) && al16(O.ids) && al16(O.mf) && al16(O.stat) && al16(O.pv)) staged |= 2;
+    }
     const size_t shmem = (size_t)LO_WAVES * (ST_SLOTB + ST_STAGE) + sizeof(double) * (size_t)TW * n;
     PG_CHECK(ctx, shmem <= 160 * 1024, "locus op: too many pools (%d) for the pool table in LDS", n);
     const int64_t nunits = (L + (int64_t)64 * M - 1) / ((int64_t)64 * M);

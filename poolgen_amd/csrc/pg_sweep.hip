@@ -1588,11 +1588,42 @@ extern "C" int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
     PG_CHECK(ctx, G_dev && Y && row_idx && beta_dev && p > 0 && n >= 1 && k >= 1 && n_rows >= 1 && n_rows <= n,
              "gp_ols: bad arguments");
     PG_CHECK(ctx, ld >= n && (ld % 2) == 0, "gp_ols: ld must be even and >= n");
-    if ((int64_t)n >= p + 1)
-        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: tall design (n >= 1 + p) is not a GPU problem");
     if (k > 8) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "gp_ols: at most 8 traits per call");
     for (int a = 0; a < n_rows; ++a) PG_CHECK(ctx, row_idx[a] >= 0 && row_idx[a] < n, "gp_ols: row index out of range");
     PG_HIP(ctx, hipSetDevice(ctx->device));
+    if ((int64_t)n >= p + 1) {
+        // The tall branch (gp/ols.rs:72-99, taken when x.nrows() >= x.ncols(): at most n - 1 loci, i.e. the reference's own 5 x 3
+        // test, never a pool-seq matrix): b = pinv(X'X over the training rows) X' y.  (1 + p)^2 <= n^2 numbers: the host's,
+        // not a GPU problem.  pinv as in the wide branch (helpers.rs:463-482).
+        const int P = (int)p + 1;
+        std::vector<double> Gh((size_t)p * ld);
+        PG_HIP(ctx, hipMemcpyAsync(Gh.data(), G_dev, sizeof(double) * (size_t)p * ld, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        auto X = [&](int64_t i, int c) { return c == 0 ? 1.0 : Gh[(size_t)(c - 1) * ld + i]; };
+        std::vector<double> xtx((size_t)P * P), pinv((size_t)P * P), T((size_t)P * n_rows), b((size_t)P * k);
+        for (int a = 0; a < P; ++a)
+            for (int c = 0; c < P; ++c) {
+                double x = 0.0;
+                for (int i = 0; i < n_rows; ++i) x += X(row_idx[i], a) * X(row_idx[i], c);
+                xtx[(size_t)a * P + c] = x;
+            }
+        if (pg_pinv_sym(xtx.data(), P, pinv.data()) != 0) return pg_fail(ctx, PG_ERR_INVALID, "gp_ols: pinv failed");
+        for (int a = 0; a < P; ++a) // (pinv X') y, in the reference's order of products
+            for (int i = 0; i < n_rows; ++i) {
+                double x = 0.0;
+                for (int c = 0; c < P; ++c) x += pinv[(size_t)a * P + c] * X(row_idx[i], c);
+                T[(size_t)a * n_rows + i] = x;
+            }
+        for (int a = 0; a < P; ++a)
+            for (int j = 0; j < k; ++j) {
+                double x = 0.0;
+                for (int i = 0; i < n_rows; ++i) x += T[(size_t)a * n_rows + i] * Y[(size_t)row_idx[i] * k + j];
+                b[(size_t)a * k + j] = x;
+            }
+        PG_HIP(ctx, hipMemcpyAsync(beta_dev, b.data(), sizeof(double) * (size_t)P * k, hipMemcpyHostToDevice, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // b is stack-owned
+        return PG_OK;
+    }
     std::vector<double> full((size_t)n * n);
     if (XXt_host_or_null) {
         std::memcpy(full.data(), XXt_host_or_null, sizeof(double) * n * n);

@@ -52,11 +52,19 @@ def report(tag, gpu, orc):
     print(f"\n[{tag}]\n    |GPU    - exact|: {f(gpu)}" + (f"\n    |oracle - exact|: {f(orc)}" if orc is not None else ""))
 
 
-def assert_close(got, ex, pf, what):
+def assert_close(got, ex, pf, what, big_rtol=RTOL):
+    """1e-10 with a SCALE-FREE floor: |db| <= RTOL |b| + RTOL max|b| (a coefficient far below the largest one of the run is
+    compared on the scale of the run, as the GP tests do), and -- asserted, not only printed -- the relative error of the
+    entries that are not small (|b| > 1e-6 max|b|) stays below `big_rtol`: 1e-10 when the covariates are handed in; the
+    bound a whole-chain test passes is written at its call."""
     b, v, p = got
     assert np.array_equal(np.isnan(b), np.isnan(ex["beta"])), what + " NaN pattern"
-    assert np.allclose(b, ex["beta"], rtol=RTOL, atol=1e-10), what + " beta"
-    assert np.allclose(v, ex["var"], rtol=RTOL, atol=1e-13), what + " var"
+    scale = float(np.nanmax(np.abs(ex["beta"])))
+    assert np.allclose(b, ex["beta"], rtol=RTOL, atol=RTOL * scale), what + " beta"
+    big = np.abs(ex["beta"]) > 1e-6 * scale
+    rel_big = float(np.max(np.abs(b - ex["beta"])[big] / np.abs(ex["beta"])[big]))
+    assert rel_big <= big_rtol, what + f" beta: relative error {rel_big:.2e} of the entries above 1e-6 max|beta|"
+    assert np.allclose(v, ex["var"], rtol=RTOL, atol=RTOL * float(np.nanmax(np.abs(ex["var"])))), what + " var"
     assert np.max(np.abs(p - pf)) <= PTOL, what + " pval"
     assert np.max(np.abs(p - ex["pval"])) <= 1e-6, what + " pval against the exact tail (statrs' own quantisation)"
 
@@ -112,7 +120,10 @@ def test_full_path_against_binary128(engine, oracle, exact, n, p, x, force_m, ca
     with capsys.disabled():
         report(f"full path n={n} p={p} x={x} m={m}", errs(got, ex, pf), errs((ref["beta"], ref["var"], ref["pval"]), ex, pf))
     assert ref["m"] == m
-    assert_close(got, ex, pf, f"full path n={n} m={m}")
+    # the whole chain: the product's own eigenvectors (fp64 Householder + QL) become covariates, and [1 | v1 ..] with v1 ~ 1/sqrt(n)
+    # has cond 1e6 .. 1e7: a perturbation of 1e-16 in the eigenvectors moves a coefficient by cond * 1e-16 of ITS size.  Measured
+    # on MI355X: 1.6e-9 .. 5.9e-9 relative on the entries above 1e-6 max|beta| (absolute 2e-13 .. 2e-12); asserted at 2e-8.
+    assert_close(got, ex, pf, f"full path n={n} m={m}", big_rtol=2e-8)
 
 
 @pytest.mark.parametrize("n,p,k,rows", [(24, 3000, 1, None), (60, 5000, 2, "odd"), (200, 2500, 3, "fold")])

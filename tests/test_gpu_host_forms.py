@@ -53,13 +53,13 @@ def test_ols_kinship_host_buffers(native, ctx, oracle, exact, p, n, k, x, force_
     if m.value == 0:
         ok = np.isfinite(ref["beta"])
         assert np.array_equal(np.isnan(beta), ~ok)
-        assert np.allclose(beta[ok], ref["beta"][ok], rtol=1e-10, atol=1e-10)
-        assert np.allclose(var[ok], ref["var"][ok], rtol=1e-10, atol=1e-13)
+        assert np.allclose(beta[ok], ref["beta"][ok], rtol=1e-10, atol=1e-10 * float(np.max(np.abs(ref["beta"][ok]))))
+        assert np.allclose(var[ok], ref["var"][ok], rtol=1e-10, atol=1e-10 * float(np.max(np.abs(ref["var"][ok]))))
         assert np.max(np.abs(pv[ok] - ref["pval"][ok])) <= 1e-10
     else:   # covariate fits: the reference point is the binary128 chain (tests/test_gpu_exact.py)
         ex = exact.ols_with_covariate(G, Y, x, force_m=force_m, n=n)
         assert ex["m"] == m.value
-        assert_close((beta, var, pv), ex, formula_p(oracle, ex, n), f"host path p={p} n={n} m={m.value}")
+        assert_close((beta, var, pv), ex, formula_p(oracle, ex, n), f"host path p={p} n={n} m={m.value}", big_rtol=2e-8)  # whole chain
 
 
 def test_ols_kinship_host_rejects_bad_arguments(native, ctx):
