@@ -433,16 +433,24 @@ def worker(args):
         kin_flops = 2.0 * n * n * p_local                   # reference computes the full product
         kin_tflops = kin_flops / (kin_avg * 1e-3) / 1e12 if kin_avg > 0 else 0.0
         traffic_db = {}
+        traffic_state = "none"
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
                 if tj.get("workload") == f"{n}x{p_local}":
                     traffic_db = tj
+                    import hashlib
+                    h = hashlib.sha256()
+                    csrc = ROOT / "poolgen_amd" / "csrc"
+                    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))):
+                        h.update(f.read_bytes())
+                    traffic_state = "measured on these kernel sources" if tj.get("kernel_sources_sha256") == h.hexdigest() else \
+                        "STALE: the kernel sources have changed since the counter passes (tools/r03_profile.sh re-measures)"
             except Exception:
                 traffic_db = {}
         traffic_note = ("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command "
-                        "(counters cannot be read from inside the process); file profiles/pmc_traffic.json, see its 'source'")
+                        "(counters cannot be read from inside the process); file profiles/pmc_traffic.json, see its 'source'; " + traffic_state)
         tiles = (n + 15) // 16
         # MFMA work the kernel EXECUTES (upper triangle, padding and the redundant parts of the diagonal tiles included);
         # USEFUL = the n (n + 1) / 2 distinct products of the triangle
@@ -465,6 +473,7 @@ def worker(args):
                 "algorithmic_note": "2 n^2 p / time (SURVEY 8d: the reference forms the full product); exceeds the peak because only "
                                     "one triangle is computed -- not a utilisation",
                 "traffic": traffic_db.get("kinship_hbm_bytes_per_launch"), "traffic_note": traffic_note,
+                "traffic_stale": traffic_state.startswith("STALE"),
                 "avg_ms": kin_avg, "launches": kin_n}
         rec = {
             "metric": "loci/sec ols_iter_with_kinship, 200 pools x 10M loci",
@@ -507,6 +516,11 @@ def worker(args):
             rs["traffic"] = rs["two_pass"]["traffic"]
             rec["roofline_sweep"] = rs
         if secondary:
+            co = secondary.get("count_operators", {})
+            for op, key in (("ols_iter", "ols_iter_stream_hbm_bytes_per_launch"), ("pearson_corr", "pearson_stream_hbm_bytes_per_launch"),
+                            ("chisq_test", "chisq_stream_hbm_bytes_per_launch")):
+                if op in co and int(args.secondary_loci) == 1_000_000:
+                    co[op]["traffic"] = traffic_db.get(key)
             rec["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             s = min(args.cpu_sample, p_local)
