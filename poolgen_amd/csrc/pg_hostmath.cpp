@@ -11,6 +11,50 @@
 
 namespace {
 
+// The two inner loops of the Householder reduction, in a wide-vector and a baseline build chosen once at run time (the
+// library is built for plain x86-64; the n x n step between the GPU passes is on the critical path of every m >= 1 step).
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#define PG_HOST_AVX2 __attribute__((target("avx2,fma")))
+#else
+#define PG_HOST_AVX2
+#endif
+// row j of the lower triangle: p_j += row[0..j) . u[0..j) + row[j] u_j;  p[0..j) += row[0..j) u_j
+template <int DUMMY>
+static inline void symv_row_body(const double *__restrict__ row, const double *__restrict__ u, double *__restrict__ p, int j) {
+    const double uj = u[j];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= j; k += 4) {
+        s0 += row[k] * u[k]; s1 += row[k + 1] * u[k + 1]; s2 += row[k + 2] * u[k + 2]; s3 += row[k + 3] * u[k + 3];
+        p[k] += row[k] * uj; p[k + 1] += row[k + 1] * uj; p[k + 2] += row[k + 2] * uj; p[k + 3] += row[k + 3] * uj;
+    }
+    for (; k < j; ++k) { s0 += row[k] * u[k]; p[k] += row[k] * uj; }
+    p[j] += ((s0 + s1) + (s2 + s3)) + row[j] * uj;
+}
+static void symv_row_base(const double *row, const double *u, double *p, int j) { symv_row_body<0>(row, u, p, j); }
+PG_HOST_AVX2 static void symv_row_avx2(const double *row, const double *u, double *p, int j) { symv_row_body<1>(row, u, p, j); }
+// row j of the rank-2 update of the lower triangle: row[0..j] -= uj q[0..j] + qj u[0..j]
+template <int DUMMY>
+static inline void rank2_row_body(double *__restrict__ row, const double *__restrict__ u, const double *__restrict__ q, double uj, double qj, int j) {
+    for (int k = 0; k <= j; ++k) row[k] -= (uj * q[k] + qj * u[k]);
+}
+static void rank2_row_base(double *row, const double *u, const double *q, double uj, double qj, int j) { rank2_row_body<0>(row, u, q, uj, qj, j); }
+PG_HOST_AVX2 static void rank2_row_avx2(double *row, const double *u, const double *q, double uj, double qj, int j) { rank2_row_body<1>(row, u, q, uj, qj, j); }
+static bool host_has_avx2() {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+    static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    return yes;
+#else
+    return false;
+#endif
+}
+static inline void symv_row(const double *row, const double *u, double *p, int j) {
+    if (host_has_avx2()) symv_row_avx2(row, u, p, j); else symv_row_base(row, u, p, j);
+}
+static inline void rank2_row(double *row, const double *u, const double *q, double uj, double qj, int j) {
+    if (host_has_avx2()) rank2_row_avx2(row, u, q, uj, qj, j); else rank2_row_base(row, u, q, uj, qj, j);
+}
+
 // Householder reduction of a symmetric matrix to tridiagonal form.  On exit (want_q) `a` holds
 // the orthogonal transformation, d the diagonal, e the sub-diagonal (e[0] = 0).
 void tridiagonalise(std::vector<double> &a, int n, std::vector<double> &d, std::vector<double> &e,
@@ -36,19 +80,38 @@ void tridiagonalise(std::vector<double> &a, int n, std::vector<double> &d, std::
                 h -= f * g;
                 A(i, l) = f - g;
                 f = 0.0;
-                for (int j = 0; j <= l; ++j) {
-                    if (want_q) A(j, i) = A(i, j) / h;
-                    g = 0.0;
-                    for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
-                    for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
-                    e[j] = g / h;
-                    f += e[j] * A(i, j);
+                if (want_q) {
+                    for (int j = 0; j <= l; ++j) {
+                        A(j, i) = A(i, j) / h;
+                        g = 0.0;
+                        for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
+                        for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
+                        e[j] = g / h;
+                        f += e[j] * A(i, j);
+                    }
+                } else {
+                    // p = A u over the leading block from its LOWER triangle, row by row: row j gives the dot product of its
+                    // sub-diagonal part with u (into p_j) and, by symmetry, its multiples of u_j (into p_0 .. p_{j-1}) -- unit
+                    // stride both ways (the column walk of the form above, A(k, j) for k > j, is what the solve spent its time in)
+                    const double *u = &A(i, 0);
+                    for (int j = 0; j <= l; ++j) e[j] = 0.0;
+                    for (int j = 0; j <= l; ++j) symv_row(&A(j, 0), u, e.data(), j);
+                    for (int j = 0; j <= l; ++j) {
+                        e[j] /= h;
+                        f += e[j] * u[j];
+                    }
                 }
                 const double hh = f / (h + h);
-                for (int j = 0; j <= l; ++j) {
-                    f = A(i, j);
-                    e[j] = g = e[j] - hh * f;
-                    for (int k = 0; k <= j; ++k) A(j, k) -= (f * e[k] + g * A(i, k));
+                if (want_q) {
+                    for (int j = 0; j <= l; ++j) {
+                        f = A(i, j);
+                        e[j] = g = e[j] - hh * f;
+                        for (int k = 0; k <= j; ++k) A(j, k) -= (f * e[k] + g * A(i, k));
+                    }
+                } else {
+                    const double *u = &A(i, 0);
+                    for (int j = 0; j <= l; ++j) e[j] -= hh * u[j];
+                    for (int j = 0; j <= l; ++j) rank2_row(&A(j, 0), u, e.data(), u[j], e[j], j);
                 }
             }
         } else {
@@ -110,14 +173,14 @@ int ql_implicit(std::vector<double> &d, std::vector<double> &e, int n, std::vect
             if (m != l) {
                 if (iter++ == 200) return -1;
                 double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                double r = std::hypot(g, 1.0);
+                double r = std::sqrt(g * g + 1.0); // (no overflow to guard against: g is a ratio of kinship-sized numbers, and |g| > 1e150 would be an error upstream)
                 g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
                 double s = 1.0, c = 1.0, p = 0.0;
                 int i;
                 for (i = m - 1; i >= l; --i) {
                     double f = s * e[i];
                     const double b = c * e[i];
-                    e[i + 1] = (r = std::hypot(f, g));
+                    e[i + 1] = (r = std::sqrt(f * f + g * g)); // std::hypot costs more than the rest of the rotation
                     if (r == 0.0) {
                         d[i + 1] -= p;
                         e[m] = 0.0;

@@ -179,6 +179,20 @@ def test_sweep_random_shapes(engine, oracle):
         ref = oracle.ols_with_covariate(Gh, Y, covariate=C, n=n) if m else oracle.ols_with_covariate(Gh, Y, force_m=0)
         cmp_fit(got, ref, f"case {case}: n={n} ld={ld} k={k} m={m} p={p} off={off}")
 
+@pytest.mark.parametrize("forced", ["POOLGEN_SWEEP_V1", "POOLGEN_SWEEP_V2"])
+def test_lane_per_locus_sweep_kernels_as_shipped(engine, oracle, forced, monkeypatch):
+    """The default dispatch takes the matrix-core kernel for every shape the tests above use from 33 pools up; the two
+    lane-per-locus kernels stay in the product for shapes it does not fit (more than ~1200 pools: the B table exceeds the
+    LDS; more than 48 columns) and for short rows.  Forced through the library's own switch, both run the geometry cases
+    (mid-chunk locus boundaries, paired stores, clamped prefetch, padding columns, slab offsets) and the random shapes."""
+    monkeypatch.setenv(forced, "1")
+    for args in [(1, 8, 8, 0), (7, 5, 6, 0), (129, 37, 40, 0), (1000, 200, 208, 0), (4097, 100, 100, 0), (777, 200, 200, 3),
+                 (513, 100, 100, 1), (2049, 50, 50, 5), (300, 33, 34, 7), (640, 201, 202, 0), (63, 200, 200, 1), (65, 100, 124, 0),
+                 (17, 500, 500, 2), (4100, 68, 70, 0)]:
+        test_sweep_row_geometries(engine, oracle, *args)
+    test_sweep_random_shapes(engine, oracle)
+
+
 
 def test_full_path_rule_picks_covariates(engine, oracle, exact):
     from test_gpu_exact import assert_close, formula_p
