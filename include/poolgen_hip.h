@@ -124,7 +124,9 @@ int pg_ols_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, c
  * argmin 0.8, start simplex of base/helpers.rs:132-146, <= 1000 iterations), ve = sigma^2, v_b = ve [(X'X)^-1]_last,
  * t = b / v_b as written (:175), p = 2 (1 - T_{n-1}(|t|)).  PARITY UNPINNED: the reference has no test of this path and the
  * solver's source is not in its tree; the published algorithm is restated (here and, literally, in the oracle) and the two
- * agree at the solver's resolution (~1e-6), not at 1e-10.  At most 2 kinship covariates (4 design columns), k <= 4 traits.
+ * agree at the solver's resolution (~1e-6), not at 1e-10.  Up to 8 kinship covariates (10 design columns: what the eigen rule can
+ * hand the sweep as well), k <= 4 traits.  With 3 and more covariates the 1000-iteration cap ends the simplex before it has
+ * converged, in the reference as here (tests/test_gpu_mle.py).
  * beta/var/pval: p x k on the device. */
 int pg_mle_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y, int k,
                        double var_explained, int force_m, int *m_out, double *K_out, double *beta_dev, double *var_dev,

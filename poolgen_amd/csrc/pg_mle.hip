@@ -18,15 +18,23 @@
 #include "pg_common.h"
 #include "pg_stats_device.h"
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
 
-constexpr int MLE_MAXP = 4;
+constexpr int MLE_MAXP = 4;       // design columns of the register kernel (m <= 2)
+constexpr int MLE_MAXP_LDS = 10;  // ... of the kernel whose simplex lives in LDS (m <= 8, the sweep's own limit on kinship covariates)
 
 struct MleShared {          // what all columns share: Z = [1 | C]
     double ztz[(MLE_MAXP - 1) * (MLE_MAXP - 1)];
     double zty[(MLE_MAXP - 1) * 4]; // [a][trait]
+    double yty[4];
+    int n, m1, k, tdf, ntcoef;
+};
+struct MleSharedBig {       // the same for up to MLE_MAXP_LDS design columns (lives in device memory: indexed at run time)
+    double ztz[(MLE_MAXP_LDS - 1) * (MLE_MAXP_LDS - 1)]; // row-major m1 x m1
+    double zty[(MLE_MAXP_LDS - 1) * 4];                  // [a][trait]
     double yty[4];
     int n, m1, k, tdf, ntcoef;
 };
@@ -192,6 +200,189 @@ __global__ __launch_bounds__(64) void k_mle_nm(const double *__restrict__ sums /
     beta[cell] = bo; var[cell] = vo; pval[cell] = po;
 }
 
+// ---- the same solver for 5 .. 10 design columns (m = 3 .. 8): the simplex -- P + 2 vertices of P + 1 numbers -- no longer fits the
+// register file, so the vertices and their costs live in LDS (lane-interleaved: conflict-free), and instead of moving vertices the
+// sort permutes a rank -> vertex table held in one 64-bit register (4 bits per rank).  Every sum runs in rank order, i.e. the
+// arithmetic is that of the register kernel / of the oracle's restatement on physically sorted vertices.
+__device__ __forceinline__ int mle_nib(unsigned long long o, int r) { return (int)((o >> (4 * r)) & 15ull); }
+__device__ __forceinline__ unsigned long long mle_swap(unsigned long long o, int r) { // ranks r - 1 and r trade places
+    const unsigned long long a = (o >> (4 * (r - 1))) & 15ull, b = (o >> (4 * r)) & 15ull;
+    o &= ~(0xffull << (4 * (r - 1)));
+    return o | (b << (4 * (r - 1))) | (a << (4 * r));
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void k_mle_nm_lds(const double *__restrict__ sums, const double *__restrict__ gg,
+                                                   const double *__restrict__ tcoef, int64_t p, const MleSharedBig *__restrict__ Hd,
+                                                   double *__restrict__ beta, double *__restrict__ var, double *__restrict__ pval) {
+    constexpr int D = P + 1, V = D + 1, Z1 = P - 1;
+    extern __shared__ double mle_lds[];
+    const int lane = threadIdx.x;
+    auto SX = [&](int v, int d) -> double & { return mle_lds[(size_t)(v * D + d) * 64 + lane]; };
+    auto CO = [&](int v) -> double & { return mle_lds[(size_t)(V * D + v) * 64 + lane]; };
+    const int K = Hd->k, n = Hd->n;
+    const int64_t cell0 = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = cell0 < p * K;
+    const int64_t cell = live ? cell0 : p * K - 1; // (idle lanes shadow the last cell: no divergent exits around the LDS traffic)
+    const int64_t l = cell / K;
+    const int j = (int)(cell - l * K);
+    const int ncol = Hd->m1 + K;
+    double zg[Z1], xyz[Z1];
+#pragma unroll
+    for (int r = 0; r < Z1; ++r) { zg[r] = sums[l * ncol + r]; xyz[r] = Hd->zty[r * 4 + j]; }
+    const double ggv = gg[l], xyg = sums[l * ncol + Hd->m1 + j], yy = Hd->yty[j];
+    const double *__restrict__ ztz = Hd->ztz;
+
+    auto cost_of = [&](const double (&par)[D]) { // mle_cost<P> with A = [[Z'Z, Z'g], [g'Z, g'g]], same order of operations
+        const double sigma2 = mle_bound(par[0]);
+        double q = 0.0, lsum = 0.0;
+#pragma unroll
+        for (int r = 0; r < Z1; ++r) {
+            double ab = 0.0;
+#pragma unroll
+            for (int c = 0; c < Z1; ++c) ab = fma(ztz[r * Z1 + c], par[1 + c], ab);
+            ab = fma(zg[r], par[P], ab);
+            q = fma(par[1 + r], ab, q);
+            lsum = fma(par[1 + r], xyz[r], lsum);
+        }
+        {
+            double ab = 0.0;
+#pragma unroll
+            for (int c = 0; c < Z1; ++c) ab = fma(zg[c], par[1 + c], ab);
+            ab = fma(ggv, par[P], ab);
+            q = fma(par[P], ab, q);
+            lsum = fma(par[P], xyg, lsum);
+        }
+        double ss = yy - 2.0 * lsum + q;
+        ss = ss < 0.0 ? 0.0 : ss;
+        return ((double)n / 2.00) * log(2.00 * 3.14159265358979323846 * sigma2) + (1.00 / sigma2) * ss;
+    };
+    auto load_vertex = [&](int v, double (&x)[D]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = SX(v, d);
+    };
+    auto store_vertex = [&](int v, const double (&x)[D]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) SX(v, d) = x[d];
+    };
+    // ---- start simplex (helpers.rs:132-146): ones, 1.5 on the diagonal --------------------------------------------------------
+    unsigned long long ord = 0;
+    for (int i = 0; i < V; ++i) {
+        double x[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = (i == d) ? 1.5 : 1.0;
+        store_vertex(i, x);
+        CO(i) = cost_of(x);
+        ord |= (unsigned long long)i << (4 * i);
+    }
+    // stable insertion sort of the ranks by cost; `from`: the ranks below it are already in order
+    auto sort_ranks = [&](int from) {
+        for (int a = from; a < V; ++a)
+            for (int b = a; b >= 1; --b) {
+                const bool sw = CO(mle_nib(ord, b - 1)) > CO(mle_nib(ord, b));
+                ord = sw ? mle_swap(ord, b) : ord;
+            }
+    };
+    sort_ranks(1);
+    for (int it = 0; it < 1000; ++it) { // max_iters(1_000), mle.rs:98
+        double mean = 0.0, sd = 0.0;
+        for (int i = 0; i < V; ++i) mean += CO(mle_nib(ord, i));
+        mean /= (double)V;
+        for (int i = 0; i < V; ++i) { const double c = CO(mle_nib(ord, i)); sd = fma(c - mean, c - mean, sd); }
+        sd = sqrt(sd / ((double)V - 1.0));
+        if (__all(sd < PG_EPS)) break;          // (a lane that has converged keeps stepping with its wave: its simplex has collapsed
+        const bool done = sd < PG_EPS;          //  to cost differences below EPSILON, but it must not move any more: guarded below)
+        double x0[D], xr[D], xt[D], xw[D];
+        const int vw = mle_nib(ord, V - 1), vb = mle_nib(ord, 0);
+        load_vertex(vw, xw);
+        {
+            double x[D];
+            load_vertex(vb, x0);
+            for (int i = 1; i < V - 1; ++i) {
+                load_vertex(mle_nib(ord, i), x);
+#pragma unroll
+                for (int d = 0; d < D; ++d) x0[d] += x[d];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            x0[d] = x0[d] * (1.0 / ((double)V - 1.0));
+            xr[d] = x0[d] + (x0[d] - xw[d]);
+        }
+        const double cr = cost_of(xr);
+        const double c_best = CO(vb), c_second = CO(mle_nib(ord, V - 2)), c_worst = CO(vw);
+        if (done) continue;
+        bool shrink = false;
+        if (cr < c_second && cr >= c_best) { // reflection
+            store_vertex(vw, xr);
+            CO(vw) = cr;
+        } else if (cr < c_best) { // expansion
+#pragma unroll
+            for (int d = 0; d < D; ++d) xt[d] = x0[d] + (xr[d] - x0[d]) * 2.0;
+            const double ce = cost_of(xt);
+            if (ce < cr) { store_vertex(vw, xt); CO(vw) = ce; }
+            else { store_vertex(vw, xr); CO(vw) = cr; }
+        } else { // contraction, else shrink
+#pragma unroll
+            for (int d = 0; d < D; ++d) xt[d] = x0[d] + (xw[d] - x0[d]) * 0.5;
+            const double cc = cost_of(xt);
+            if (cc < c_worst) { store_vertex(vw, xt); CO(vw) = cc; }
+            else shrink = true;
+        }
+        if (shrink) {
+            double xb[D], x[D];
+            load_vertex(vb, xb);
+            for (int i = 1; i < V; ++i) {
+                const int v = mle_nib(ord, i);
+                load_vertex(v, x);
+#pragma unroll
+                for (int d = 0; d < D; ++d) x[d] = xb[d] + (x[d] - xb[d]) * 0.5;
+                store_vertex(v, x);
+                CO(v) = cost_of(x);
+            }
+            sort_ranks(1);
+        } else {
+            sort_ranks(V - 1); // only the replaced vertex is out of place
+        }
+    }
+    // ---- closing arithmetic (mle.rs:112-113, :120-150, :166-186) ------------------------------------------------------------
+    double xbest[D];
+    load_vertex(mle_nib(ord, 0), xbest);
+    const double ve = mle_bound(xbest[0]);
+    const double b = xbest[P];
+    // [(X'X)^-1]_(last,last) by elimination of the leading P - 1 columns; the matrix takes the simplex' place in LDS
+    __builtin_amdgcn_wave_barrier();
+    auto M = [&](int r, int c) -> double & { return mle_lds[(size_t)(r * P + c) * 64 + lane]; };
+    for (int r = 0; r < Z1; ++r) {
+        for (int c = 0; c < Z1; ++c) M(r, c) = ztz[r * Z1 + c];
+        M(r, P - 1) = zg[r < Z1 ? r : 0];
+        M(P - 1, r) = zg[r < Z1 ? r : 0];
+    }
+    M(P - 1, P - 1) = ggv;
+    bool singular = false;
+    for (int q = 0; q < P - 1; ++q) {
+        const double piv = M(q, q);
+        if (piv == 0.0) singular = true;
+        const double inv = 1.0 / piv;
+        for (int r = q + 1; r < P; ++r) {
+            const double f = M(r, q) * inv;
+            for (int c = q + 1; c < P; ++c) M(r, c) = fma(-f, M(q, c), M(r, c));
+        }
+    }
+    const double schur = M(P - 1, P - 1);
+    singular = singular || !(schur > 1e-12 * ggv);
+    double bo = NAN, vo = NAN, po = NAN;
+    if (!singular) {
+        const double vb2 = ve / schur;
+        const double t = b / vb2;
+        bo = b; vo = vb2;
+        if (isinf(t)) po = 0.0;
+        else if (isnan(t)) po = 1.0;
+        else po = pg_t_two_sided_p(fabs(t), Hd->tdf, tcoef, Hd->ntcoef);
+    }
+    if (live) { beta[cell] = bo; var[cell] = vo; pval[cell] = po; }
+}
+
 } // namespace
 
 extern "C" int pg_mle_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y, int k,
@@ -224,8 +415,8 @@ extern "C" int pg_mle_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
     }
     if (m_out) *m_out = m;
     if (K_out) std::memcpy(K_out, Kh.data(), sizeof(double) * n * n);
-    if (m + 2 > MLE_MAXP)
-        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "mle_kinship: n_eigenvecs = %d; the simplex kernel carries at most %d design columns", m, MLE_MAXP);
+    if (m + 2 > MLE_MAXP_LDS)
+        return pg_fail(ctx, PG_ERR_UNSUPPORTED, "mle_kinship: n_eigenvecs = %d; the simplex kernels carry at most %d design columns", m, MLE_MAXP_LDS);
     if (m + 2 >= n) return pg_fail(ctx, PG_ERR_UNSUPPORTED, "mle_kinship: no residual degrees of freedom");
     if (m > 0) {
         V.resize((size_t)n * m);
@@ -235,7 +426,12 @@ extern "C" int pg_mle_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
     const int m1 = m + 1, ncol = m1 + k;
     std::vector<double> Z((size_t)n * ncol);
     MleShared H;
+    MleSharedBig HB;
     std::memset(&H, 0, sizeof H);
+    std::memset(&HB, 0, sizeof HB);
+    // POOLGEN_MLE_LDS=1 sends the small designs through the LDS kernel too: same arithmetic in the same order, so the results must be
+    // bit-identical to the register kernel's (tests/test_gpu_mle.py) -- the check that pins the LDS kernel's bookkeeping
+    const bool big = m + 2 > MLE_MAXP || std::getenv("POOLGEN_MLE_LDS") != nullptr;
     for (int i = 0; i < n; ++i) {
         Z[(size_t)i * ncol] = 1.0;
         for (int a = 0; a < m; ++a) Z[(size_t)i * ncol + 1 + a] = V[(size_t)i * m + a];
@@ -245,20 +441,22 @@ extern "C" int pg_mle_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
         for (int b = 0; b < m1; ++b) {
             double s = 0.0;
             for (int i = 0; i < n; ++i) s += Z[(size_t)i * ncol + a] * Z[(size_t)i * ncol + b];
-            H.ztz[a * m1 + b] = s;
+            if (big) HB.ztz[a * m1 + b] = s; else H.ztz[a * m1 + b] = s;
         }
         for (int j = 0; j < k; ++j) {
             double s = 0.0;
             for (int i = 0; i < n; ++i) s += Z[(size_t)i * ncol + a] * Y[(size_t)i * k + j];
-            H.zty[a * 4 + j] = s;
+            if (big) HB.zty[a * 4 + j] = s; else H.zty[a * 4 + j] = s;
         }
     }
     for (int j = 0; j < k; ++j) {
         double s = 0.0;
         for (int i = 0; i < n; ++i) s += Y[(size_t)i * k + j] * Y[(size_t)i * k + j];
         H.yty[j] = s;
+        HB.yty[j] = s;
     }
     H.n = n; H.m1 = m1; H.k = k;
+    HB.n = n; HB.m1 = m1; HB.k = k;
     double *sums = nullptr, *gg = nullptr;
     if (hipMalloc((void **)&sums, sizeof(double) * (size_t)p * ncol) != hipSuccess || hipMalloc((void **)&gg, sizeof(double) * (size_t)p) != hipSuccess) {
         (void)hipFree(sums);
@@ -279,16 +477,34 @@ extern "C" int pg_mle_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
             ctx->tcoef_len = (int)tc.size();
         }
         H.tdf = ctx->tcoef_df; H.ntcoef = ctx->tcoef_len;
+        HB.tdf = ctx->tcoef_df; HB.ntcoef = ctx->tcoef_len;
     }
     if (!rc) {
         const int64_t cells = p * k;
         const unsigned grid = (unsigned)((cells + 63) / 64);
-        switch (m + 2) {
+        MleSharedBig *HBd = nullptr;
+        if (big) {
+            if (hipMalloc((void **)&HBd, sizeof HB) != hipSuccess || hipMemcpyAsync(HBd, &HB, sizeof HB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = pg_fail(ctx, PG_ERR_HIP, "mle_kinship: upload of the shared statistics failed");
+        }
+#define PG_MLE_LDS(PV)                                                                                                              \
+    case PV: {                                                                                                                     \
+        const size_t lds = sizeof(double) * 64 * ((size_t)(PV + 2) * (PV + 1) + (PV + 2));                                        \
+        if (hipFuncSetAttribute((const void *)k_mle_nm_lds<PV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            rc = pg_fail(ctx, PG_ERR_HIP, "mle_kinship: LDS attribute");                                                           \
+        else hipLaunchKernelGGL(k_mle_nm_lds<PV>, dim3(grid), dim3(64), lds, ctx->stream, sums, gg, ctx->tcoef_dev, p, HBd, beta_dev, var_dev, pval_dev); \
+    } break;
+        if (!rc && big) switch (m + 2) {
+        PG_MLE_LDS(2) PG_MLE_LDS(3) PG_MLE_LDS(4) PG_MLE_LDS(5) PG_MLE_LDS(6) PG_MLE_LDS(7) PG_MLE_LDS(8) PG_MLE_LDS(9) PG_MLE_LDS(10)
+        }
+        else if (!rc) switch (m + 2) {
         case 2: hipLaunchKernelGGL(k_mle_nm<2>, dim3(grid), dim3(64), 0, ctx->stream, sums, gg, ctx->tcoef_dev, p, H, beta_dev, var_dev, pval_dev); break;
         case 3: hipLaunchKernelGGL(k_mle_nm<3>, dim3(grid), dim3(64), 0, ctx->stream, sums, gg, ctx->tcoef_dev, p, H, beta_dev, var_dev, pval_dev); break;
         default: hipLaunchKernelGGL(k_mle_nm<4>, dim3(grid), dim3(64), 0, ctx->stream, sums, gg, ctx->tcoef_dev, p, H, beta_dev, var_dev, pval_dev); break;
         }
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = pg_fail(ctx, PG_ERR_HIP, "mle_kinship: simplex kernel failed");
+#undef PG_MLE_LDS
+        if (!rc && (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = pg_fail(ctx, PG_ERR_HIP, "mle_kinship: simplex kernel failed");
+        if (HBd) (void)hipFree(HBd);
     }
     (void)hipFree(sums);
     (void)hipFree(gg);

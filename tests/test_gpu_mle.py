@@ -62,6 +62,47 @@ def test_mle_against_the_oracle_and_the_analytic_optimum(engine, oracle, n, p, k
     assert np.max(np.abs(pv - want)) <= 1e-10
 
 
+@pytest.mark.parametrize("n,p,k,force_m", [(60, 300, 2, 0), (40, 200, 1, 1), (120, 200, 1, 2)])
+def test_lds_simplex_is_the_register_simplex(engine, n, p, k, force_m, monkeypatch):
+    """m = 3 .. 8 (5 .. 10 design columns) run a kernel whose simplex lives in LDS behind a rank -> vertex table.  Forced onto the
+    small designs the register kernel also takes, it must return the SAME BITS: same solver, same order of every sum."""
+    G, Y = make(p, n, 77, k)
+    a = engine.mle_with_covariate(G, Y, 0.75, force_m=force_m, n=n)
+    monkeypatch.setenv("POOLGEN_MLE_LDS", "1")
+    b = engine.mle_with_covariate(G, Y, 0.75, force_m=force_m, n=n)
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.equal(x, y) or (torch.isnan(x) == torch.isnan(y)).all() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
+
+
+@pytest.mark.parametrize("n,p,force_m", [(100, 200, 3), (200, 150, 5), (150, 120, 8)])
+def test_mle_with_many_covariates(engine, oracle, n, p, force_m, capsys):
+    """The reference's design is n x (2 + n_eigenvecs) (mle.rs:376) for whatever the eigen rule yields; -x 0.99 on real data gives
+    3 and more.  With 5 .. 10 coefficients plus sigma^2 the 1000-iteration cap (mle.rs:98) ends the simplex long before it has
+    converged -- for the oracle's literal restatement exactly as for the GPU: measured on MI355X, the worst cell stands 0.12 / 2.3 /
+    4.0 times the largest coefficient away from the optimum for m = 3 / 5 / 8 in the oracle and 0.14 / 3.2 / 4.1 on the GPU.  What
+    the reference prints for such designs is where ITS simplex happens to stand; what can be held here is: a finite result for
+    every cell, the closing arithmetic as written, and both restatements of the solver stopping equally far out (worst-cell
+    distances within a factor of 3 of each other)."""
+    G, Y = make(p, n, 303, 1)
+    Gh = G.cpu().numpy()
+    m, K, beta, var, pv = engine.mle_with_covariate(G, Y, 0.75, force_m=force_m, n=n)
+    beta, var, pv = beta.cpu().numpy(), var.cpu().numpy(), pv.cpu().numpy()
+    assert m == force_m and np.isfinite(beta).all() and np.isfinite(var).all() and (var > 0).all()
+    w, Vv = np.linalg.eigh(K)
+    C = Vv[:, ::-1][:, :m].copy()
+    ref = oracle.mle_with_covariate(Gh, Y, covariate=C, force_m=m, n=n, threads=8)
+    ols = oracle.ols_with_covariate(Gh, Y, covariate=C, n=n)
+    scale = np.abs(ols["beta"]).max()
+    d_g = np.abs(beta - ols["beta"]).max() / scale
+    d_o = np.abs(ref["beta"] - ols["beta"]).max() / scale
+    with capsys.disabled():
+        print(f"\n[mle n={n} p={p} m={m}] beta / max|beta|: |GPU - optimum| {d_g:.1e}  |oracle - optimum| {d_o:.1e}")
+    assert d_g <= 3 * max(d_o, 1e-6) and d_o <= 3 * max(d_g, 1e-6)
+    t = np.abs(beta / var)
+    want = np.array([2.0 * (1.0 - oracle.lib.orc_students_t_cdf(float(x), float(n - 1))) for x in t.reshape(-1)]).reshape(t.shape)
+    assert np.max(np.abs(pv - want)) <= 1e-10
+
+
 def test_cli_mle_iter_with_kinship(tmp_path):
     out = tmp_path / "mle.csv"
     r = subprocess.run([str(CLI), "mle_iter_with_kinship", "-f", str(GOLD / "test.sync"), "-p", str(GOLD / "test.csv"), "--phen-value-col", "2,3",
