@@ -370,3 +370,77 @@ int exq_gp_ols(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, 
     free(A); free(inv); free(z);
     return rc;
 }
+
+/* gp::ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199) in binary128, signature of orc_gp_proxy.  The inputs of the
+ * arithmetic are what the reference holds in fp64: the centred columns x_c = x - mean (column means over the FIRST n_rows rows,
+ * :124-129, formed and subtracted in fp64 as written; the last locus left out, :115).  From there on everything is binary128:
+ * X_c X_c^T over the training rows, its leading eigenvector (cyclic Jacobi), and per locus the third coefficient of
+ * y ~ [1 | PC1 | x_j] -- the exact solution where the 3 x 3 normal matrix has full rank, the minimum-norm solution
+ * (LAPACK gelsd's) where x_j is constant over the training rows: with x_j = c 1 the solutions are
+ * (a0 - c t, a1, t) for the fit y ~ a0 + a1 PC1, and the shortest has t = c a0 / (1 + c^2).  b: P x k. */
+int exq_gp_proxy(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k, const int64_t *row_idx, int nr,
+                 double *b, int n_threads) {
+    (void)n;
+    const int nt = exq_threads(n_threads);
+    const int64_t pc = P - 1;
+    double *xc = (double *)malloc(sizeof(double) * (size_t)nr * (pc > 0 ? pc : 1));
+    for (int64_t j = 0; j < pc; j++) {
+        double mean = 0.0;
+        for (int i_ = 0; i_ < nr; i_++) mean += Xt[j * ld + i_];
+        mean = mean / (double)nr;
+        for (int a = 0; a < nr; a++) xc[(size_t)a * pc + j] = Xt[j * ld + row_idx[a]] - mean;
+    }
+    q_t *A = (q_t *)malloc(sizeof(q_t) * nr * nr), *V = (q_t *)malloc(sizeof(q_t) * nr * nr), *ev = (q_t *)malloc(sizeof(q_t) * nr);
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+    for (int a = 0; a < nr; a++)
+        for (int c = a; c < nr; c++) {
+            q_t s = 0.0Q;
+            for (int64_t j = 0; j < pc; j++) s += (q_t)xc[(size_t)a * pc + j] * (q_t)xc[(size_t)c * pc + j];
+            A[(size_t)a * nr + c] = s;
+            A[(size_t)c * nr + a] = s;
+        }
+    exq_jacobi(A, nr, V, ev);
+    q_t *e1 = (q_t *)malloc(sizeof(q_t) * nr);
+    for (int a = 0; a < nr; a++) e1[a] = V[(size_t)a * nr + 0];
+    /* y ~ a0 + a1 PC1 (for the constant-locus branch), and the trait means (:170-172) */
+    q_t s11 = 0.0Q, s1e = 0.0Q, see = 0.0Q;
+    for (int a = 0; a < nr; a++) { s11 += 1.0Q; s1e += e1[a]; see += e1[a] * e1[a]; }
+    for (int j_ = 0; j_ < k; j_++) {
+        q_t m = 0.0Q;
+        for (int a = 0; a < nr; a++) m += (q_t)Y[row_idx[a] * k + j_];
+        b[j_] = (double)(m / (q_t)nr);
+    }
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int64_t j = 1; j < P; j++) {
+        int constant = 1;
+        const double x0 = Xt[j * ld + row_idx[0]];
+        for (int a = 1; a < nr; a++)
+            if (Xt[j * ld + row_idx[a]] != x0) { constant = 0; break; }
+        q_t M[9] = {0}, Mi[9];
+        for (int a = 0; a < nr; a++) {
+            const q_t xs[3] = {1.0Q, e1[a], (q_t)Xt[j * ld + row_idx[a]]};
+            for (int u = 0; u < 3; u++)
+                for (int v = 0; v < 3; v++) M[u * 3 + v] += xs[u] * xs[v];
+        }
+        for (int j_ = 0; j_ < k; j_++) {
+            q_t r0 = 0.0Q, r1 = 0.0Q, r2 = 0.0Q;
+            for (int a = 0; a < nr; a++) {
+                const q_t y = (q_t)Y[row_idx[a] * k + j_];
+                r0 += y; r1 += e1[a] * y; r2 += (q_t)Xt[j * ld + row_idx[a]] * y;
+            }
+            if (constant) {
+                const q_t det = s11 * see - s1e * s1e;
+                const q_t a0 = (see * r0 - s1e * r1) / det;
+                const q_t c = (q_t)x0;
+                b[j * k + j_] = (double)(c * a0 / (1.0Q + c * c));
+            } else {
+                q_t Mc[9];
+                memcpy(Mc, M, sizeof Mc);
+                if (exq_inverse(Mc, 3, Mi) != 0) { b[j * k + j_] = NAN; continue; }
+                b[j * k + j_] = (double)(Mi[6] * r0 + Mi[7] * r1 + Mi[8] * r2);
+            }
+        }
+    }
+    free(xc); free(A); free(V); free(ev); free(e1);
+    return 0;
+}

@@ -1454,6 +1454,9 @@ int orc_gp_proxy(const double *Xt, int64_t P, int n, int64_t ld, const double *Y
 typedef int (*orc_gp_ols_fn)(const double *, int64_t, int, int64_t, const double *, int, const int64_t *, int, double *, int);
 static orc_gp_ols_fn orc_gp_ols_hook = NULL;
 void orc_set_gp_ols_hook(void *fn) { orc_gp_ols_hook = (orc_gp_ols_fn)fn; }
+/* the same for the proxy coefficients of the *_with_iterative_proxy_norms models (exq_gp_proxy has orc_gp_proxy's signature) */
+static orc_gp_ols_fn orc_gp_proxy_hook = NULL;
+void orc_set_gp_proxy_hook(void *fn) { orc_gp_proxy_hook = (orc_gp_ols_fn)fn; }
 static int path_gp_ols(const double *Xt, int64_t P, int n, int64_t ld, const double *Y, int k, const int64_t *row_idx,
                        int n_rows, double *beta, int n_threads) {
     return (orc_gp_ols_hook ? orc_gp_ols_hook : orc_gp_ols)(Xt, P, n, ld, Y, k, row_idx, n_rows, beta, n_threads);
@@ -1478,7 +1481,7 @@ int orc_penalised_path_general(const double *Xt, int64_t P, int n, int64_t ld, c
     double *b_hat = (double *)malloc(sizeof(double) * P * k * 3);
     double *b_new = b_hat + P * k;
     double *b_proxy = b_new + P * k;
-    if (iterative) orc_gp_proxy(Xt, P, n, ld, Y, k, row_idx, n_rows, b_proxy, n_threads);
+    if (iterative) (orc_gp_proxy_hook ? orc_gp_proxy_hook : orc_gp_proxy)(Xt, P, n, ld, Y, k, row_idx, n_rows, b_proxy, n_threads);
     int64_t *itr = (int64_t *)malloc(sizeof(int64_t) * n_rows * 2);
     int64_t *iva = itr + n_rows;
     for (int rep = 0; rep < r; rep++)

@@ -385,6 +385,7 @@ class Exact:
         lib.exq_sym_eig.argtypes = [vp, i, vp, vp]
         lib.exq_kinship_covariates.argtypes = [vp, i64, i, i64, d, i, vp, vp, vp, i]
         lib.exq_gp_ols.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i]
+        lib.exq_gp_proxy.argtypes = [vp, i64, i, i64, vp, i, vp, i, vp, i]
 
     def t_two_sided_p(self, t_abs, df):
         return self.lib.exq_t_two_sided_p(float(t_abs), int(df))
@@ -447,12 +448,29 @@ class Exact:
         rc = self.lib.exq_gp_ols(Xt.ctypes.data, P, n, ld, Y.ctypes.data, Y.shape[1], ri.ctypes.data, len(ri), beta.ctypes.data, threads)
         return rc, beta
 
+    def gp_proxy(self, Xt, Y, row_idx, n=None, threads=0):
+        """gp::ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199) in binary128 -> P x k"""
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        P, ld = Xt.shape
+        n = ld if n is None else n
+        Y = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        ri = np.ascontiguousarray(row_idx, dtype=np.int64)
+        b = np.empty((P, Y.shape[1]))
+        rc = self.lib.exq_gp_proxy(Xt.ctypes.data, P, n, ld, Y.ctypes.data, Y.shape[1], ri.ctypes.data, len(ri), b.ctypes.data, threads)
+        assert rc == 0, rc
+        return b
+
     def install_into_oracle(self, oracle, on=True):
-        """the oracle's penalised path then takes its fold fits from exq_gp_ols (everything downstream stays the oracle's)"""
+        """the oracle's penalised path then takes its fold fits from exq_gp_ols and its proxy coefficients from exq_gp_proxy
+        (everything downstream stays the oracle's)"""
         fn = C.cast(self.lib.exq_gp_ols, C.c_void_p) if on else C.c_void_p(None)
         oracle.lib.orc_set_gp_ols_hook.argtypes = [C.c_void_p]
         oracle.lib.orc_set_gp_ols_hook.restype = None
         oracle.lib.orc_set_gp_ols_hook(fn)
+        fn2 = C.cast(self.lib.exq_gp_proxy, C.c_void_p) if on else C.c_void_p(None)
+        oracle.lib.orc_set_gp_proxy_hook.argtypes = [C.c_void_p]
+        oracle.lib.orc_set_gp_proxy_hook.restype = None
+        oracle.lib.orc_set_gp_proxy_hook(fn2)
 
 
 _ORACLE = None

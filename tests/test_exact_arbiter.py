@@ -130,3 +130,53 @@ def test_intercept_only_fits_agree_three_ways(oracle, exact):
     ref = oracle.ols_with_covariate(G, Y, force_m=0)
     assert np.allclose(ref["beta"], ex["beta"], rtol=1e-10, atol=1e-12)
     assert np.max(np.abs(ref["pval"] - ex["pval"])) < 1e-11
+
+
+def test_gp_proxy_against_mpmath(oracle, exact):
+    """The binary128 restatement of gp::ols_iterative_with_kinship_pca_covariate (gp/ols.rs:104-199), pinned against mpmath at 50
+    digits on a case mpmath finishes in seconds: the quirky kinship (last locus left out, means over the FIRST n_rows pools),
+    its leading eigenvector, the third coefficient of y ~ [1 | PC1 | x_j], the minimum-norm value for a constant locus -- and the
+    literal oracle's distance from it, reported."""
+    mp.mp.dps = 50
+    n, P, k = 14, 9, 2
+    rng = np.random.default_rng(8)
+    Xt = np.vstack([np.ones((1, n)), rng.uniform(0.05, 0.95, size=(P - 1, n))])
+    Xt[4, :] = 0.375                                   # a locus constant over the pools
+    Y = rng.normal(size=(n, k))
+    idx = np.array([i for i in range(n) if i % 5 != 2])
+    nr = len(idx)
+    got = exact.gp_proxy(Xt, Y, idx, n=n)
+    # mpmath: the centred columns exactly as the reference forms them in fp64, everything after that at 50 digits
+    pc = P - 1
+    xc = np.empty((nr, pc))
+    for j in range(pc):
+        mean = 0.0
+        for i_ in range(nr):
+            mean += Xt[j, i_]
+        mean = mean / nr
+        xc[:, j] = Xt[j, idx] - mean
+    A = mp.matrix(nr, nr)
+    for a in range(nr):
+        for c in range(nr):
+            A[a, c] = mp.fsum(mp.mpf(float(xc[a, j])) * mp.mpf(float(xc[c, j])) for j in range(pc))
+    E, Q = mp.eigsy(A)
+    lead = max(range(nr), key=lambda i: E[i])
+    e1 = [Q[a, lead] for a in range(nr)]
+    for j_ in range(k):
+        assert abs(got[0, j_] - float(mp.fsum(mp.mpf(float(Y[i, j_])) for i in idx) / nr)) <= 1e-15
+    for j in range(1, P):
+        X = mp.matrix(nr, 3)
+        for a in range(nr):
+            X[a, 0] = 1; X[a, 1] = e1[a]; X[a, 2] = mp.mpf(float(Xt[j, idx[a]]))
+        for j_ in range(k):
+            yv = mp.matrix([mp.mpf(float(Y[i, j_])) for i in idx])
+            if j == 4:                                 # constant column: minimum-norm least squares
+                X2 = X[:, 0:2]
+                a01 = mp.lu_solve(X2.T * X2, X2.T * yv)
+                c = mp.mpf(0.375)
+                want = c * a01[0] / (1 + c * c)
+            else:
+                want = mp.lu_solve(X.T * X, X.T * yv)[2]
+            assert abs(got[j, j_] - float(want)) <= 1e-13 * max(1.0, abs(float(want))), (j, j_, got[j, j_], float(want))
+    lit = oracle.gp_proxy(Xt, Y, idx, n=n)
+    assert np.allclose(lit, got, rtol=1e-7, atol=1e-9 * np.abs(got).max())
