@@ -59,7 +59,7 @@ def test_ols_kinship_host_buffers(native, ctx, oracle, exact, p, n, k, x, force_
     else:   # covariate fits: the reference point is the binary128 chain (tests/test_gpu_exact.py)
         ex = exact.ols_with_covariate(G, Y, x, force_m=force_m, n=n)
         assert ex["m"] == m.value
-        assert_close((beta, var, pv), ex, formula_p(oracle, ex, n), f"host path p={p} n={n} m={m.value}", big_rtol=2e-8)  # whole chain
+        assert_close((beta, var, pv), ex, formula_p(oracle, ex, n), f"host path p={p} n={n} m={m.value}", big_rtol=1e-7)  # whole chain
 
 
 def test_ols_kinship_host_rejects_bad_arguments(native, ctx):
