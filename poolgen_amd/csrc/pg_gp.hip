@@ -224,27 +224,60 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
     const bool on = c >= 0;
     const int f = on ? c / k : 0;
     const double *gp = G + (inr ? pool : 0);
+    // The table's inputs must not cost a memory round trip per chunk between the two barriers: the folds' masses sit in
+    // LDS for the whole launch, and the first PF_NI items of a thread (all of them at the shipped shapes) get the next
+    // chunk's coefficients while this chunk is accumulated.
+    constexpr int PF_NI = 2, FMW = 2 * GP_LMAX + 1;
+    double *masses = Bs + (size_t)chunk * F * LS; // [F][FMW]: { nmax, sub_scale[], add_scale[] } of this trait's columns
+    for (int i = threadIdx.x; i < F * FMW; i += blockDim.x) {
+        const int ff = i / FMW, w = i - ff * FMW;
+        const FoldMasses *src = FM + (ff * k + j);
+        masses[i] = w == 0 ? src->nmax : (w <= GP_LMAX ? src->sub_scale[w - 1] : src->add_scale[w - 1 - GP_LMAX]);
+    }
+    double bn[PF_NI], xn[PF_NI];
+    auto fetch = [&](int64_t lc2) {
+        const int m2 = (int)min((int64_t)chunk, l1 - lc2);
+#pragma unroll
+        for (int q = 0; q < PF_NI; ++q) {
+            const int item = threadIdx.x + q * blockDim.x;
+            bn[q] = 0.0; xn[q] = 0.0;
+            if (item < m2 * F) {
+                const int ff = item / m2, ll = item - ff * m2; // bf is column-major: consecutive threads, consecutive loci
+                bn[q] = bf[(size_t)(ff * k + j) * p + lc2 + ll];
+                if (X.b) xn[q] = X.b[(lc2 + ll + 1) * X.k + X.j];
+            }
+        }
+    };
+    if (l0 < l1) fetch(l0);
     for (int64_t lc = l0; lc < l1; lc += chunk) {
         const int m = (int)min((int64_t)chunk, l1 - lc);
         __syncthreads();
-        for (int item = threadIdx.x; item < m * F; item += blockDim.x) {
-            const int ff = item / m, ll = item - ff * m; // bf is column-major: consecutive threads, consecutive loci
-            const int64_t l = lc + ll;
-            const int col = ff * k + j;
-            const FoldMasses fm = FM[col];
-            const double b = bf[(size_t)col * p + l];
+        auto table_row = [&](int item, double b, double bx) {
+            const int ff = item / m, ll = item - ff * m;
+            const double *fm = masses + ff * FMW;
             const double nrm = gp_norm(b, P0.alpha);
-            const double sc = (X.b ? gp_norm(X.b[(l + 1) * X.k + X.j], P0.alpha) : nrm) / fm.nmax;
+            const double sc = (X.b ? gp_norm(bx, P0.alpha) : nrm) / fm[0];
             const bool pos = b >= 0.0;
             const double pen = pos ? (((b - nrm) < 0.0) ? 0.0 : b - nrm) : (((b + nrm) > 0.0) ? 0.0 : b + nrm);
             double *o = Bs + (size_t)(ll * F + ff) * LS;
 #pragma unroll
             for (int i = 0; i < LP; ++i) {
-                const double dep = pos ? b + fm.sub_scale[i] * nrm : b - fm.add_scale[i] * nrm;
+                const double dep = pos ? b + fm[1 + i] * nrm : b - fm[1 + GP_LMAX + i] * nrm;
                 o[i] = (sc < P0.lambda[i]) ? pen : dep;
             }
+        };
+#pragma unroll
+        for (int q = 0; q < PF_NI; ++q) {
+            const int item = threadIdx.x + q * blockDim.x;
+            if (item < m * F) table_row(item, bn[q], xn[q]);
+        }
+        for (int item = threadIdx.x + PF_NI * blockDim.x; item < m * F; item += blockDim.x) {
+            const int ff = item / m, ll = item - ff * m;
+            const int64_t l = lc + ll;
+            table_row(item, bf[(size_t)(ff * k + j) * p + l], X.b ? X.b[(l + 1) * X.k + X.j] : 0.0);
         }
         __syncthreads();
+        if (lc + chunk < l1) fetch(lc + chunk);
         if (on) {
             const double *bs = Bs + (size_t)f * LS;
             constexpr int U = 8; // loads of G in flight per thread
@@ -650,10 +683,11 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 if (hipMemcpyAsync(colof_dev, colof.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                     return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
                 const int LP = (P0.L + 1) & ~1;
-                const int chunk = std::max(4, std::min(64, (int)(49152 / (sizeof(double) * n_folds * (LP + 2)))));
+                const size_t masses_b = sizeof(double) * n_folds * (2 * GP_LMAX + 1);
+                const int chunk = std::max(4, std::min(64, (int)((49152 - masses_b) / (sizeof(double) * n_folds * (LP + 2)))));
                 const int bthreads = n > 256 ? 512 : 256; // the coefficient stage is shared by all waves of a block
                 const dim3 grid(nblk2, (n + bthreads - 1) / bthreads);
-                const size_t lds = sizeof(double) * chunk * n_folds * (LP + 2);
+                const size_t lds = sizeof(double) * chunk * n_folds * (LP + 2) + masses_b;
                 const Proxy X{proxy_dev, k, j};
                 pg_prof_begin(ctx, PG_K_GP_PREDICT);
 #define PG_PREDICT_FOLDS(LPV)                                                                                              \

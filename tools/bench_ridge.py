@@ -23,7 +23,8 @@ for it in range(2):
     beta, lam, perf = eng.gp_ridge(G, Y, rows, fold_of, folds, n=n)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-x_ms, x_n = eng.profile_get("gp_xxt"); b_ms, b_n = eng.profile_get("gp_beta")
+x_ms, x_n = eng.profile_get("gp_xxt"); b_ms, b_n = eng.profile_get("gp_beta"); q_ms, q_n = eng.profile_get("gp_predict")
 print(json.dumps({"op": "gp_ridge", "pools": n, "loci": p, "reps": reps, "folds": folds, "wall_s": dt, "lambda": lam.tolist(),
-                  "xxt_ms_total": x_ms, "xxt_launches": x_n, "beta_ms_total": b_ms, "beta_launches": b_n,
+                  "xxt_ms_total": x_ms, "xxt_launches": x_n, "beta_ms_total": b_ms, "beta_launches": b_n, "predict_ms_total": q_ms, "predict_launches": q_n,
+                  "predict_frac_of_8TBs": (8.0 * n * p * q_n / (q_ms * 1e-3) / 8e12) if q_ms else None,
                   "passes_over_G_equivalent_GBps": (2 * reps * folds + 2) * 8.0 * n * p / dt / 1e9}))
