@@ -706,6 +706,7 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     P.split = (P.merged && P.nb == 2) ? 2 : 1;                                               // nb == 2: all 136 tiles, 68 + 68
     const int npairs = (P.merged ? P.nb * (P.nb - 1) / 2 : P.nb * (P.nb + 1) / 2) * P.split;
     int nslab = cus / npairs;
+    if (const char *e = std::getenv("POOLGEN_KIN_SLAB_MULT")) nslab *= std::max(1, std::atoi(e)); // experiments: workgroups per CU
     if (nslab < 1) nslab = 1;
     const int64_t max_slabs = (p + KIN_KC - 1) / KIN_KC;
     if (nslab > max_slabs) nslab = (int)max_slabs;
