@@ -1,20 +1,22 @@
 #!/bin/bash
 # Round-3 evidence for the bench line, all from ONE command line (python3 bench.py [flags]) on one MI355X box:
-#   1. the bench JSON itself                                   -> gpurun_out/r03_bench.json
-#   2. rocprofv3 --kernel-trace --stats of the same command    -> gpurun_out/r03_kernel_stats.csv (our kernels' rows)
+#   1. the bench JSON itself                                   -> gpurun_out/${TAG}_bench.json
+#   2. rocprofv3 --kernel-trace --stats of the same command    -> gpurun_out/${TAG}_kernel_stats.csv (our kernels' rows)
 #   3. rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy), one counter group per pass, --kernel-trace only
-#                                                             -> gpurun_out/r03_pmc_summary.txt, gpurun_out/r03_pmc_traffic.json
+#                                                             -> gpurun_out/${TAG}_pmc_summary.txt, gpurun_out/${TAG}_pmc_traffic.json
 # Copy the four files into profiles/ afterwards (profiles/pmc_traffic.json is what bench.py reads for `traffic`; it carries the
 # hash of the kernel sources it was measured on, and bench.py says "stale" when the sources have changed since).
 # New against r02_profile.sh: the two sweep legs (m = 0 two-pass, forced m = 8) are told apart by dispatch order instead of
 # sharing one per-kernel mean, and the secondary legs (count operators, ridge passes) are in the same passes.
+# The bench JSON is taken LAST, with the fresh counter file already in place, so that its `traffic` fields are this box's own.
+# usage: tools/r03_profile.sh [tag]   (files gpurun_out/<tag>_*; default r03_b)
+TAG=${1:-r03_b}; export TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-python3 bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; echo "bench rc=$?"
-rm -rf gpurun_out/r03_prof && mkdir -p gpurun_out/r03_prof
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03_prof -- python3 bench.py --no-cpu-baseline > gpurun_out/r03_prof.log 2>&1; echo "rocprof rc=$?"
-f=$(find gpurun_out/r03_prof -name "*kernel_stats.csv" | head -1)
-python3 - "$f" > gpurun_out/r03_kernel_stats.csv <<'PY'
+rm -rf gpurun_out/${TAG}_prof && mkdir -p gpurun_out/${TAG}_prof
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --no-cpu-baseline > gpurun_out/${TAG}_prof.log 2>&1; echo "rocprof rc=$?"
+f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1)
+python3 - "$f" > gpurun_out/${TAG}_kernel_stats.csv <<'PY'
 import csv, sys
 rows = list(csv.reader(open(sys.argv[1])))
 w = csv.writer(sys.stdout)
@@ -24,17 +26,17 @@ for r in rows[1:]:
         r[0] = r[0].replace("(anonymous namespace)::", "")
         w.writerow(r)
 PY
-cut -c1-150 gpurun_out/r03_kernel_stats.csv
-rm -rf gpurun_out/r03_prof
-: > gpurun_out/r03_pmc_summary.txt
+cut -c1-150 gpurun_out/${TAG}_kernel_stats.csv
+rm -rf gpurun_out/${TAG}_prof
+: > gpurun_out/${TAG}_pmc_summary.txt
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rm -rf gpurun_out/r03_pmc_$i && mkdir -p gpurun_out/r03_pmc_$i
-  timeout -k 10 500 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/r03_pmc_$i -- python3 bench.py --steps 3 --warmup 1 --sweep-steps 2 --no-cpu-baseline > gpurun_out/r03_pmc_$i.log 2>&1
+  rm -rf gpurun_out/${TAG}_pmc_$i && mkdir -p gpurun_out/${TAG}_pmc_$i
+  timeout -k 10 500 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_$i -- python3 bench.py --steps 3 --warmup 1 --sweep-steps 2 --no-cpu-baseline > gpurun_out/${TAG}_pmc_$i.log 2>&1
   echo "pmc pass $i ($ctrs) rc=$?"
-  f=$(find gpurun_out/r03_pmc_$i -name "*counter_collection.csv" | head -1)
-  python3 - "$f" >> gpurun_out/r03_pmc_summary.txt <<'PY'
+  f=$(find gpurun_out/${TAG}_pmc_$i -name "*counter_collection.csv" | head -1)
+  python3 - "$f" >> gpurun_out/${TAG}_pmc_summary.txt <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
@@ -52,13 +54,15 @@ for k, d in sorted(acc.items()):
             print(f"{(k + ' [leg two_pass]')[:44]:44s} {c:28s} n={h:3d} mean={sum(v[:h])/h:.6g}")
             print(f"{(k + ' [leg m8]')[:44]:44s} {c:28s} n={h:3d} mean={sum(v[h:])/h:.6g}")
 PY
-  rm -rf gpurun_out/r03_pmc_$i
+  rm -rf gpurun_out/${TAG}_pmc_$i
 done
 python3 - <<'PY'
 import hashlib, json, re
 from pathlib import Path
 vals = {}
-for line in open("gpurun_out/r03_pmc_summary.txt"):
+import os
+TAG = os.environ["TAG"]
+for line in open(f"gpurun_out/{TAG}_pmc_summary.txt"):
     m = re.match(r"(.{44})\s(\S+)\s+n=\s*(\d+)\s+mean=(\S+)", line)
     if m: vals[(m.group(1).strip(), m.group(2))] = float(m.group(4))
 def find(prefix, ctr):
@@ -72,9 +76,9 @@ src = hashlib.sha256()
 for p in sorted(list(Path("poolgen_amd/csrc").glob("*.hip")) + list(Path("poolgen_amd/csrc").glob("*.h"))):
     src.update(p.read_bytes())
 out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --sweep-steps 2 --no-cpu-baseline` "
-                   "(tools/r03_profile.sh; per-kernel means in r03_pmc_summary.txt): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 being the "
+                   "(tools/r03_profile.sh; per-kernel means in the `source` file): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 being the "
                    "gfx950 wide-read correction of MI355X_MICROARCH.md.  The sweep legs are separated by dispatch order.",
-       "source": "profiles/r03_pmc_summary.txt", "workload": "200x10000000", "kernel_sources_sha256": src.hexdigest(),
+       "source": f"profiles/{TAG}_pmc_summary.txt", "workload": "200x10000000", "kernel_sources_sha256": src.hexdigest(),
        "kinship_hbm_bytes_per_launch": hbm("k_kinship_syrk<true, true, 3>"),
        "kinship_two_pass_hbm_bytes_per_launch": hbm("k_kinship_syrk<false, true, 3>"),
        "sweep_two_pass_hbm_bytes_per_launch": hbm("k_ols_sweep_mfma<5, 3, 1, 0> [leg two_pass]"),
@@ -85,7 +89,17 @@ out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc passes of `python3
        "ridge_predict_hbm_bytes_per_launch": hbm("k_gp_predict_folds")}
 mf, ga = find("k_kinship_syrk<true, true, 3>", "SQ_VALU_MFMA_BUSY_CYCLES"), find("k_kinship_syrk<true, true, 3>", "GRBM_GUI_ACTIVE")
 if mf and ga: out["kinship_mfma_busy_frac"] = mf / 1024.0 / (ga / 8.0)
-json.dump(out, open("gpurun_out/r03_pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/{TAG}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-cat gpurun_out/r03_pmc_summary.txt
+cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
+python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
+python3 -c "
+import json; d = json.load(open('gpurun_out/${TAG}_bench.json'))
+print('step %.3f ms' % d['ms_per_step'], 'roofline', d['roofline']['frac'], 'traffic', d['roofline']['traffic'], 'stale' if d['roofline'].get('traffic_stale') else 'fresh')
+for leg in ('two_pass', 'm8'): print(leg, d['roofline_sweep'][leg]['avg_ms'], d['roofline_sweep'][leg]['frac'], d['roofline_sweep'][leg]['ms_per_step'])
+s = d['secondary']
+for op in ('ols_iter', 'pearson_corr', 'chisq_test'): print(op, s['count_operators'][op]['kernel_ms'], s['count_operators'][op]['frac'])
+for op in ('coefficient_pass', 'prediction_pass'): print(op, s['ridge'][op]['kernel_ms'], s['ridge'][op]['frac'])
+print('ridge wall', s['ridge']['wall_s'])
+"
