@@ -164,7 +164,8 @@ int pg_ols_kinship_sharded_dev(pg_ctx *ctx, const double *G_dev, int64_t p_local
  * Sync-derived per-locus operators.  The reference calls these once per text line through
  * ChunkyReadAnalyseWrite::read_analyse_write (base/structs_and_traits.rs:245-265,
  * base/sync.rs:864, :674); here one call handles a batch of L parsed loci.
- * counts: L x n x 6 uint32, locus-major, sync column order A,T,C,G,N,D (base/sync.rs:134).
+ * counts: L x n x 6 uint32, locus-major, sync column order A,T,C,G,N,D (base/sync.rs:134); every count below 2^29
+ *   (the streaming pass sums coverages as integers; a larger count fails the call with PG_ERR_INVALID).
  * pool_sizes: host, n (normalised or not -- only ratios are used, sync.rs:266-268).
  * Outputs are struct-of-arrays with L leading:
  *   n_out[L]            int32  rows emitted per trait (0 = locus dropped = None)

@@ -203,6 +203,12 @@ struct FoldMasses { double nmax, sub_scale[GP_LMAX], add_scale[GP_LMAX]; };
 // LP = the path length rounded up to even, a compile-time constant: entries beyond L carry lambda = 0 and zero masses
 // (harmless finite numbers nobody reads), so neither loop needs a guard -- guarded, every FMA became a branch with its
 // own LDS round trip.
+// Bound: the LDS return path -- L / 2 16-byte operand reads per (locus, pool): 96 bytes per element at 12 lambdas, 1.39 ms
+// of LDS time per 2 M loci x 500 pools against 1.46 ms measured (0.685 of the HBM peak).  A matrix-core form (pools
+// regrouped by fold into 16-pool tiles, two LDS reads per 4 loci x 16 pools x 16 lambdas) was built twice, parity green,
+// and is slower: 0.55 with two 8-wave workgroups per CU and one chunk of rows ahead, 0.46 with one 16-wave workgroup and
+// two chunks ahead -- the serial phases of a chunk (stage write, table, barrier, products) outlast its memory time
+// (tools/experiments/).
 template <int LP>
 __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
                                                           int C, const int32_t *__restrict__ colof,

@@ -9,12 +9,11 @@
 // allele frequency q_j = sum_i f_ij * w_i must be accumulated sequentially over pools in pool
 // order with separate multiply and add (this file is compiled with -ffp-contract=off) to decide
 // q < maf exactly like the reference, and a lane walking its own locus does exactly that.
-// Coalescing comes from a wave-private LDS transposition: per stage 64 loci x 8 pools (192 B
-// each) are fetched as contiguous 16-byte (or 8-byte when n is odd) pieces and written to a
-// 208-byte-pitch tile which every lane then reads row-wise.
-// Two passes over a locus' counts: pass 1 = coverage + q_j (which alleles survive), pass 2 =
-// frequencies over the SURVIVING alleles (row sums change) and the operator's sums.  The
-// regression / correlation / chi-square arithmetic closes per lane from those sums.
+// Every locus' counts are read ONCE by k_locus_stream (a lane streams whole 128-byte lines of its own loci through a
+// wave-private LDS ring, see there), which decides the filter, takes the operator's sums speculatively with every
+// candidate allele in play and closes biallelic loci in place; only loci whose dropped alleles carry reads, or (ols_iter,
+// pearson_corr) that keep three or more alleles, are listed for k_locus_second, which redoes them from the counts over
+// the SURVIVING alleles (row sums change) and closes them.  The helpers below up to `Sums` serve that second pass.
 #include "pg_common.h"
 #include "pg_stats_device.h"
 #include <cmath>
@@ -614,17 +613,25 @@ __device__ __forceinline__ void pearson_close(double sx, double sxx, double sxy,
 //  * A stream starts on a pool, so a ring turn of three lines = 384 bytes = 16 pools is unrolled with every LDS offset an
 //    immediate (a batch that does not start on a 128-byte boundary is read in windows that straddle two lines: correct,
 //    slower); w_i and y_i come from a table in LDS (one broadcast read per pool) instead of scalar loads whose wait also
-//    waited for the LDS.  With that the arithmetic of a pool (filter + the
-//    operator's sums, ~60 fp64 instructions) hides completely behind the loads at two waves per SIMD: the pass runs at the
-//    rate of its request pattern (64 rows x 128 bytes per step and wave: 5.4 .. 5.9 TB/s by row length).
+//    waited for the LDS.  A line of the 64 streams is 8 buffer loads of 16 rows x 64 bytes (the two halves of a row
+//    group's line in consecutive instructions), one line ahead of the one being consumed; the descriptor of every line ends
+//    with the batch, so the last lines need no clamping.  The pass runs at the rate of this request pattern, which is the
+//    same with LDS-DMA or register staging, 2 .. 4 waves per SIMD and any ring depth (tools/mb_locus_dma.hip: 5.4 .. 5.95
+//    TB/s by row length): 128 bytes per row and step is the best step (64: 4.8, 32: 3.6, 256: 5.0 TB/s).
 //  * Speculation as before: the operator's sums are taken with every candidate allele in play; they ARE the reference's
 //    when every allele the filter drops has no reads (the common case).  New: only what a biallelic fit needs is summed
-//    (per allele sum f, sum f^2, sum f y -- not the 15 cross products), and such a fit is CLOSED IN PLACE when its last pool
-//    has passed (ols_solve<2> / pearson_close / the chi-square tail) -- no record stream, no closing kernel.  Loci that drop
-//    an allele with reads, or (ols_iter, pearson_corr) keep three or more alleles, go to a dense list (one returning atomic
-//    per unit that has any) for k_locus_second + k_locus_close, which redo them from the counts.
-//  * Results are staged per unit in LDS (16 + 16 K bytes per locus) and written at the unit's end as contiguous runs: the
-//    per-lane stores of a locus-strided layout reached HBM as partial lines and cost 130 us per million loci.
+//    (per allele sum f, sum f^2, sum f y -- not the 15 cross products; pearson_corr: ONE regressor z = sum_j j f_j, whose
+//    correlation is minus that of the first surviving allele on a biallelic locus; chisq_test: no row-sum division, the
+//    total is n - n_missing), and such a fit is CLOSED IN PLACE when its last pool has passed (ols_solve<2> /
+//    pearson_close / the chi-square tail) -- no record stream, no closing kernel.  Loci that drop an allele with reads, or
+//    (ols_iter, pearson_corr) keep three or more alleles, go to a dense list (one returning atomic per unit that has any)
+//    for k_locus_second, which redoes them from the counts and closes them itself.
+//  * Results are staged per unit in LDS and leave at the unit's end as contiguous 16-byte non-temporal stores (a unit is a
+//    contiguous run of loci): per-lane stores of a locus-strided layout reached HBM as partial lines and cost 130 us per
+//    million loci; cached stores another 25 .. 35 us.
+//  * Coverage sums are integer sums; a count of 2^29 or more anywhere in the batch raises a flag and the call fails with
+//    PG_ERR_INVALID (the sums of 6 x such counts would leave 32 bits) -- the text parser cannot produce one (u32 counts of
+//    a sequencing depth).
 constexpr int ST_SLOTB = 64 * 128;  // LDS bytes of a wave's line slot: [16 rows x 64 B per load instruction][4 row groups x 2 halves]
 constexpr int ST_PPT = 16;          // pools per ring turn of 3 lines
 constexpr int ST_STAGE = 8192;      // LDS bytes per wave for the results of a unit
