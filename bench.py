@@ -85,9 +85,9 @@ def secondary_legs(eng, dev, args, torch, np):
     ps = np.full(n1, 20.0)
     flt = Filter()
     ops = {}
-    for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(counts, ps, flt, Y1), "ols_iter"),
-                          ("pearson_corr", lambda: eng.correlation(counts, ps, flt, Y1), "pearson"),
-                          ("chisq_test", lambda: eng.chisq(counts, ps, flt), "chisq")):
+    for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(counts, ps, flt, Y1, raw=True), "ols_iter"),
+                          ("pearson_corr", lambda: eng.correlation(counts, ps, flt, Y1, raw=True), "pearson"),
+                          ("chisq_test", lambda: eng.chisq(counts, ps, flt, raw=True), "chisq")):
         fn(); fn()
         eng.profile_reset()
         reps = 10

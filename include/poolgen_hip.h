@@ -48,8 +48,8 @@ typedef struct {
     double max_missingness_rate;  /* --max-missingness-rate */
 } pg_filter;
 
-/* Per-locus output of the sync-derived batch operators (struct-of-arrays, device or host).
- * PG_MAX_OUT alleles per locus: 6 sync columns minus the one dropped. */
+/* Per-locus output of the sync-derived batch operators (struct-of-arrays, slot-major, device or host; see below).
+ * PG_MAX_OUT alleles (= rows = slots) per locus: 6 sync columns minus the one dropped. */
 #define PG_MAX_OUT 5
 
 /* ---------------------------------------------------------------------------------------
@@ -167,11 +167,15 @@ int pg_ols_kinship_sharded_dev(pg_ctx *ctx, const double *G_dev, int64_t p_local
  * counts: L x n x 6 uint32, locus-major, sync column order A,T,C,G,N,D (base/sync.rs:134); every count below 2^29
  *   (the streaming pass sums coverages as integers; a larger count fails the call with PG_ERR_INVALID).
  * pool_sizes: host, n (normalised or not -- only ratios are used, sync.rs:266-268).
- * Outputs are struct-of-arrays with L leading:
+ * Outputs are struct-of-arrays, SLOT-MAJOR (a locus emits up to PG_MAX_OUT rows = slots):
  *   n_out[L]            int32  rows emitted per trait (0 = locus dropped = None)
- *   allele_ids[L*5]     int32  index into "ATCGND"
- *   mean_freq[L*5]      double
- *   stat[L*5*k], pval[L*5*k] double  ([allele][trait])
+ *   allele_ids[5*L]     int32  index into "ATCGND"; element (slot r, locus l) at r*L + l
+ *   mean_freq[5*L]      double element (r, l) at r*L + l
+ *   stat[5*L*k], pval[5*L*k] double  element (r, l, trait t) at (r*L + l)*k + t
+ * Only the slots r < n_out[l] of a locus are specified (chisq_test: one row per locus whose allele list occupies the
+ * allele_ids slots r < n_out[l]; its stat / pval are plain [L] arrays).  A biallelic locus emits one row and touches slot 0
+ * only: the operators write 32 instead of 144 bytes per locus, and a caller that wants rows copies slot 0 and, where
+ * n_out > 1, the further slots.
  * ------------------------------------------------------------------------------------- */
 /* gwas::ols_iterate (gwas/ols.rs:201-276): stat = beta. */
 int pg_ols_iter_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n,

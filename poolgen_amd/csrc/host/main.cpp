@@ -762,8 +762,9 @@ static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &lap
                 if (R == 1) fputs(header, fo);
             }
             write_rows_parallel(fo, L, threads, [&](int64_t l, std::string &line) {
-                format_locus_rows(mode, sb.chrom(l), sb.pos[l], n_out[l], &ids[(size_t)l * PG_MAX_OUT], &mfq[(size_t)l * PG_MAX_OUT],
-                                  &stat[(size_t)l * per_stat], &pv[(size_t)l * per_stat], k, line);
+                // slot-major arrays: slot i of locus l sits i * L elements after its slot 0
+                const size_t so = mode == 0 ? (size_t)l : (size_t)l * k;
+                format_locus_rows(mode, sb.chrom(l), sb.pos[l], n_out[l], &ids[(size_t)l], &mfq[(size_t)l], &stat[so], &pv[so], k, line, (size_t)L);
             });
         }
         if (fo) fclose(fo);

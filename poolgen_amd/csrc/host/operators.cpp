@@ -6,11 +6,12 @@
 namespace pgh {
 
 void format_locus_rows(int mode, const std::string &chromosome, uint64_t position, int n_out, const int32_t *ids, const double *mean_freq,
-                       const double *stat, const double *pval, int k, std::string &line) {
+                       const double *stat, const double *pval, int k, std::string &line, size_t slot_stride) {
     if (n_out <= 0) return;
+    const size_t S = slot_stride; // the library's arrays are slot-major: slot i of this locus is S elements (S * k for stat / pval) further on
     if (mode == 0) { // chisq_test.rs:37-45
         line += chromosome; line.push_back(','); line += std::to_string(position); line.push_back(',');
-        for (int j = 0; j < n_out && j < PG_MAX_OUT; ++j) line.push_back(ALLELES[ids[j]]);
+        for (int j = 0; j < n_out && j < PG_MAX_OUT; ++j) line.push_back(ALLELES[ids[j * S]]);
         line.push_back(',');
         append_roundup_own(line, stat[0], 6); line.push_back(',');
         append_rust_display(line, pval[0]); line.push_back('\n');
@@ -18,11 +19,11 @@ void format_locus_rows(int mode, const std::string &chromosome, uint64_t positio
     }
     for (int i = 0; i < n_out; ++i)
         for (int j = 0; j < k; ++j) {
-            const size_t e = (size_t)i * k + j;
+            const size_t e = (size_t)i * S * k + j;
             line += chromosome; line.push_back(','); line += std::to_string(position); line.push_back(',');
-            line.push_back(ALLELES[ids[i]]); line.push_back(',');
-            if (mode == 2) append_roundup_own(line, mean_freq[i], 8); // ols.rs:263-271
-            else append_rust_display(line, mean_freq[i]);             // correlation_test.rs:117-124
+            line.push_back(ALLELES[ids[i * S]]); line.push_back(',');
+            if (mode == 2) append_roundup_own(line, mean_freq[i * S], 8); // ols.rs:263-271
+            else append_rust_display(line, mean_freq[i * S]);             // correlation_test.rs:117-124
             line += ",Pheno_"; line += std::to_string(j); line.push_back(',');
             append_roundup_own(line, stat[e], 6); line.push_back(',');
             if (mode == 2) append_roundup_own(line, pval[e], 12);

@@ -39,9 +39,10 @@ struct LocusCountsAndPhenotypes { // structs_and_traits.rs:131-136
 
 // Formats the rows of one locus exactly as the reference's operators do; shared with the CLI's writer.
 // mode 0: chisq (tables/chisq_test.rs:37-45), 1: correlation (gwas/correlation_test.rs:113-127), 2: ols_iterate
-// (gwas/ols.rs:255-275).  n_out <= 0 appends nothing.
+// (gwas/ols.rs:255-275).  n_out <= 0 appends nothing.  The pointers are those of the locus' slot 0 in the library's slot-major
+// arrays (include/poolgen_hip.h), slot_stride = the L of the call that filled them (1 for a single locus).
 void format_locus_rows(int mode, const std::string &chromosome, uint64_t position, int n_out, const int32_t *ids, const double *mean_freq,
-                       const double *stat, const double *pval, int k, std::string &out);
+                       const double *stat, const double *pval, int k, std::string &out, size_t slot_stride = 1);
 
 class Operators {
 public:

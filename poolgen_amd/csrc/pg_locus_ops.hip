@@ -63,6 +63,11 @@ struct LocusParams {
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
+// Output layout (include/poolgen_hip.h): SLOT-MAJOR -- element (slot r, locus l) of allele_ids / mean_freq at r * L + l, of
+// stat / pval at (r * L + l) * k + trait.  A locus that emits one row (the biallelic case) touches slot 0 only, so the streaming
+// pass writes 32 bytes per locus instead of the 144 of a locus-major [L][PG_MAX_OUT] layout (measured: -4 % of the pass).
+#define PG_OIX(l, r) ((size_t)(r) * (size_t)P.L + (size_t)(l))
+
 // ---- staging: HBM -> registers -> wave-private LDS tile ------------------------------------------
 // A locus row of a stage is 192 bytes = 12 pieces of 16 B (24 of 8 B when rows are only 8-byte
 // aligned, and always for the last, partial stage): 48 lanes cover 4 (2) loci per instruction, so that
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
         if (OP == OP_CHISQ) {
             O.n_out[l] = nout;
 #pragma unroll
-            for (int r = 0; r < PG_MAX_OUT; ++r) O.ids[l * PG_MAX_OUT + r] = (r < nk) ? ((idsp >> (3 * r)) & 7) : -1;
+            for (int r = 0; r < PG_MAX_OUT; ++r) O.ids[PG_OIX(l, r)] = (r < nk) ? ((idsp >> (3 * r)) & 7) : -1;
             O.stat[l] = st[0];
             O.pv[l] = pv[0];
             return;
@@ -939,16 +944,16 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             O.n_out[l] = nout;
 #pragma unroll
             for (int r = 0; r < PG_MAX_OUT; ++r) {
-                O.ids[l * PG_MAX_OUT + r] = (r < nout) ? (idsp & 7) : -1; // (only single-output loci are closed in this pass)
-                O.mf[l * PG_MAX_OUT + r] = (r < nout) ? mf : NAN;
+                O.ids[PG_OIX(l, r)] = (r < nout) ? (idsp & 7) : -1; // (only single-output loci are closed in this pass)
+                O.mf[PG_OIX(l, r)] = (r < nout) ? mf : NAN;
             }
         }
 #pragma unroll
         for (int t = 0; t < K; ++t)
 #pragma unroll
             for (int r = 0; r < PG_MAX_OUT; ++r) {
-                O.stat[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + t] = (r < nout) ? st[t] : NAN;
-                O.pv[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + t] = (r < nout) ? pv[t] : NAN;
+                O.stat[PG_OIX(l, r) * P.k_total + P.t0 + t] = (r < nout) ? st[t] : NAN;
+                O.pv[PG_OIX(l, r) * P.k_total + P.t0 + t] = (r < nout) ? pv[t] : NAN;
             }
     };
 
@@ -1061,8 +1066,8 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
 
     // the unit's results leave as contiguous runs: the loci of a unit are consecutive, so every output array has ONE contiguous
     // region per unit, written in 16-byte pieces by consecutive lanes (piece -> its elements -> (locus, slot) -> the staged result).
-    // Per-lane stores of a locus' own 4 .. 40 bytes (the layout is locus-major with PG_MAX_OUT slots, of which a closed locus
-    // fills one) reached memory as partial lines: 87 us per million loci at 100 pools, a fifth of the pass.
+    // Per-lane stores of a locus' own 4 .. 8 bytes would reach memory as partial lines (measured with the former locus-major layout:
+    // 87 us per million loci at 100 pools, a fifth of the pass).
     const bool coalesced = (staged & 2) != 0; // the host checked: 16-byte aligned arrays, every trait of the call in this launch
     auto flush_unit = [&](int64_t unit) {
         __builtin_amdgcn_wave_barrier();
@@ -1094,6 +1099,10 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 constexpr int EPL = decltype(eplc)::value;
                 const int ne = nv * EPL;
                 int32_t *dst = base + l0 * EPL;
+                if (reinterpret_cast<uintptr_t>(dst) & 15) { // a slot array whose start is not on 16 bytes (L not a multiple of 4)
+                    for (int e = lane; e < ne; e += 64) { const int j = e / EPL; dst[e] = get(j, e - j * EPL); }
+                    return;
+                }
                 for (int c = lane; c * 4 < ne; c += 64) {
                     int v[4];
 #pragma unroll
@@ -1117,6 +1126,10 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 constexpr int EPL = decltype(eplc)::value;
                 const int ne = nv * EPL;
                 double *dst = base + l0 * EPL;
+                if (reinterpret_cast<uintptr_t>(dst) & 15) {
+                    for (int e = lane; e < ne; e += 64) { const int j = e / EPL; dst[e] = get(j, e - j * EPL); }
+                    return;
+                }
                 for (int c = lane; c * 2 < ne; c += 64) {
                     double v[2];
 #pragma unroll
@@ -1138,30 +1151,33 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             auto dbl_of = [&](int j, int off) { return *reinterpret_cast<const double *>(stage + (size_t)j * RECB + off); };
             if (OP == OP_CHISQ) {
                 emit32(O.n_out, std::integral_constant<int, 1>{}, [&](int j, int) { return (int)hdr_of(j).x; });
-                emit32(O.ids, std::integral_constant<int, PG_MAX_OUT>{}, [&](int j, int r) {
-                    const int idsp = (int)hdr_of(j).y;
-                    return r < ((idsp >> 16) & 7) ? ((idsp >> (3 * r)) & 7) : -1;
-                });
+                // the surviving alleles of the row: the slots some locus of the unit needs (slots r >= n_out[l] are unspecified)
+                int mx = 0;
+                for (int idx = lane; idx < nv; idx += 64) mx = max(mx, (int)((hdr_of(idx).y >> 16) & 7u));
+                for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+                mx = __builtin_amdgcn_readfirstlane(mx);
+#pragma unroll
+                for (int r = 0; r < PG_MAX_OUT; ++r)
+                    if (r < mx)
+                        emit32(O.ids + (size_t)r * P.L, std::integral_constant<int, 1>{}, [&](int j, int) {
+                            const int idsp = (int)hdr_of(j).y;
+                            return r < ((idsp >> 16) & 7) ? ((idsp >> (3 * r)) & 7) : -1;
+                        });
                 emit64(O.stat, std::integral_constant<int, 1>{}, [&](int j, int) { return dbl_of(j, 16); });
                 emit64(O.pv, std::integral_constant<int, 1>{}, [&](int j, int) { return dbl_of(j, 24); });
             } else {
+                // (only single-output loci are closed in this pass: slot 0 of every array, the other slots are not written)
                 if (P.t0 == 0 || OP == OP_PEARSON) {
                     emit32(O.n_out, std::integral_constant<int, 1>{}, [&](int j, int) { return (int)hdr_of(j).x; });
-                    emit32(O.ids, std::integral_constant<int, PG_MAX_OUT>{}, [&](int j, int r) {
+                    emit32(O.ids, std::integral_constant<int, 1>{}, [&](int j, int) {
                         const uint2_t h = hdr_of(j);
-                        return r < (int)h.x ? (int)(h.y & 7u) : -1; // (only single-output loci are closed in this pass)
+                        return h.x ? (int)(h.y & 7u) : -1;
                     });
-                    emit64(O.mf, std::integral_constant<int, PG_MAX_OUT>{}, [&](int j, int r) { return r < (int)hdr_of(j).x ? dbl_of(j, 8) : NAN; });
+                    emit64(O.mf, std::integral_constant<int, 1>{}, [&](int j, int) { return hdr_of(j).x ? dbl_of(j, 8) : NAN; });
                 }
-                // [locus][slot][trait], every trait of the call in this launch (k_total == K, t0 == 0)
-                emit64(O.stat, std::integral_constant<int, PG_MAX_OUT * K>{}, [&](int j, int sub) {
-                    const int r = sub / K, t = sub - r * K;
-                    return r < (int)hdr_of(j).x ? dbl_of(j, 16 + 16 * t) : NAN;
-                });
-                emit64(O.pv, std::integral_constant<int, PG_MAX_OUT * K>{}, [&](int j, int sub) {
-                    const int r = sub / K, t = sub - r * K;
-                    return r < (int)hdr_of(j).x ? dbl_of(j, 24 + 16 * t) : NAN;
-                });
+                // [slot 0][locus][trait], every trait of the call in this launch (k_total == K, t0 == 0)
+                emit64(O.stat, std::integral_constant<int, K>{}, [&](int j, int t) { return hdr_of(j).x ? dbl_of(j, 16 + 16 * t) : NAN; });
+                emit64(O.pv, std::integral_constant<int, K>{}, [&](int j, int t) { return hdr_of(j).x ? dbl_of(j, 24 + 16 * t) : NAN; });
             }
 #endif
         }
@@ -1302,8 +1318,8 @@ __device__ __forceinline__ void ols_close(const double *rec, size_t rb, int k, i
 #pragma unroll
         for (int r = 0; r < PG_MAX_OUT; ++r) {
             const bool on = ok && r < D;
-            ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * (r + 1))) & 7) : -1;
-            mf_out[l * PG_MAX_OUT + r] = on ? cs[r < D ? r : 0] / (double)n : NAN; // ols.rs:266
+            ids_out[PG_OIX(l, r)] = on ? ((ordbits >> (3 * (r + 1))) & 7) : -1;
+            mf_out[PG_OIX(l, r)] = on ? cs[r < D ? r : 0] / (double)n : NAN; // ols.rs:266
         }
     }
 #pragma unroll
@@ -1312,8 +1328,8 @@ __device__ __forceinline__ void ols_close(const double *rec, size_t rb, int k, i
 #pragma unroll
         for (int r = 0; r < PG_MAX_OUT; ++r) {
             const bool on = ok && r < D;
-            stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? bo[tt][r < D ? r : 0] : NAN;
-            pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = on ? po[tt][r < D ? r : 0] : NAN;
+            stat_out[PG_OIX(l, r) * P.k_total + P.t0 + tt] = on ? bo[tt][r < D ? r : 0] : NAN;
+            pv_out[PG_OIX(l, r) * P.k_total + P.t0 + tt] = on ? po[tt][r < D ? r : 0] : NAN;
         }
     }
 }
@@ -1337,7 +1353,7 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
         if (OP == OP_CHISQ) {
             // tables/chisq_test.rs:15-35 on the frequency table of the surviving alleles
 #pragma unroll
-            for (int r = 0; r < PG_MAX_OUT; ++r) ids_out[l * PG_MAX_OUT + r] = (r < nk) ? ((ordbits >> (3 * r)) & 7) : -1;
+            for (int r = 0; r < PG_MAX_OUT; ++r) ids_out[PG_OIX(l, r)] = (r < nk) ? ((ordbits >> (3 * r)) & 7) : -1;
             const double chi2 = alive ? rec[rb] : NAN;
             const double df = (double)(n * nk) - 1.0;
             n_out[l] = alive ? nk : 0;
@@ -1354,8 +1370,8 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
             for (int r = 0; r < PG_MAX_OUT; ++r) {
                 const bool on = r < nout;
                 const int f0 = 3 * k + r * (1 + 3 * k);
-                ids_out[l * PG_MAX_OUT + r] = on ? ((ordbits >> (3 * r)) & 7) : -1;
-                mf_out[l * PG_MAX_OUT + r] = on ? rec[rb + (size_t)f0 * 64] / (double)n : NAN; // x.mean(), :119
+                ids_out[PG_OIX(l, r)] = on ? ((ordbits >> (3 * r)) & 7) : -1;
+                mf_out[PG_OIX(l, r)] = on ? rec[rb + (size_t)f0 * 64] / (double)n : NAN; // x.mean(), :119
 #pragma unroll
                 for (int tt = 0; tt < MAXK; ++tt) {
                     if (tt >= k) continue;
@@ -1364,8 +1380,8 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
                         pearson_close(rec[rb + (size_t)(f0 + 1 + 3 * tt) * 64], rec[rb + (size_t)(f0 + 2 + 3 * tt) * 64],
                                       rec[rb + (size_t)(f0 + 3 + 3 * tt) * 64], rec[rb + (size_t)(3 * tt) * 64],
                                       rec[rb + (size_t)(3 * tt + 1) * 64], rec[rb + (size_t)(3 * tt + 2) * 64], n, P, tcoef, rr, pp);
-                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = rr;
-                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = pp;
+                    stat_out[PG_OIX(l, r) * P.k_total + P.t0 + tt] = rr;
+                    pv_out[PG_OIX(l, r) * P.k_total + P.t0 + tt] = pp;
                 }
             }
             break;
@@ -1377,13 +1393,13 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
             if (P.t0 == 0) {
                 n_out[l] = 0;
 #pragma unroll
-                for (int r = 0; r < PG_MAX_OUT; ++r) { ids_out[l * PG_MAX_OUT + r] = -1; mf_out[l * PG_MAX_OUT + r] = NAN; }
+                for (int r = 0; r < PG_MAX_OUT; ++r) { ids_out[PG_OIX(l, r)] = -1; mf_out[PG_OIX(l, r)] = NAN; }
             }
             for (int tt = 0; tt < k; ++tt)
 #pragma unroll
                 for (int r = 0; r < PG_MAX_OUT; ++r) {
-                    stat_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
-                    pv_out[(l * PG_MAX_OUT + r) * P.k_total + P.t0 + tt] = NAN;
+                    stat_out[PG_OIX(l, r) * P.k_total + P.t0 + tt] = NAN;
+                    pv_out[PG_OIX(l, r) * P.k_total + P.t0 + tt] = NAN;
                 }
         }
         static_for<2, NA + 1>([&](auto pc) {

@@ -234,7 +234,11 @@ class Engine:
         return m.value, K, out[0], out[1], out[2]
 
     # ---- sync-derived batch operators -------------------------------------------------------
-    def _batch(self, fn, name, counts: torch.Tensor, pool_sizes, flt: Filter, Y):
+    # The library's outputs are SLOT-MAJOR (include/poolgen_hip.h): element (slot r, locus l) of allele_ids / mean_freq at
+    # r * L + l, of stat / pval at (r * L + l) * k + trait; slots r >= n_out[l] are unspecified.  raw=True hands those arrays
+    # out as they are ((5, L) / (5, L, k): what bench.py times); the default returns locus-major (L, 5[, k]) copies with the
+    # unspecified slots filled with -1 / NaN, which is what the parity tests index.
+    def _batch(self, fn, name, counts: torch.Tensor, pool_sizes, flt: Filter, Y, raw: bool = False):
         L, n, six = counts.shape
         assert six == 6
         ps = _host_f64(pool_sizes)
@@ -242,37 +246,45 @@ class Engine:
         k = Yh.shape[1]
         dev = counts.device
         n_out = torch.empty(L, dtype=torch.int32, device=dev)
-        ids = torch.empty((L, 5), dtype=torch.int32, device=dev)
-        mf = torch.empty((L, 5), dtype=torch.float64, device=dev)
-        stat = torch.empty((L, 5, k), dtype=torch.float64, device=dev)
-        pv = torch.empty((L, 5, k), dtype=torch.float64, device=dev)
+        ids = torch.empty((5, L), dtype=torch.int32, device=dev)
+        mf = torch.empty((5, L), dtype=torch.float64, device=dev)
+        stat = torch.empty((5, L, k), dtype=torch.float64, device=dev)
+        pv = torch.empty((5, L, k), dtype=torch.float64, device=dev)
         f = flt.to_c()
         self._check(fn(self._ctx, self._dev(counts, torch.int32), L, n, ps.ctypes.data, C.byref(f),
                        Yh.ctypes.data, k, n_out.data_ptr(), ids.data_ptr(), mf.data_ptr(),
                        stat.data_ptr(), pv.data_ptr()), name)
-        return n_out, ids, mf, stat, pv
+        if raw:
+            return n_out, ids, mf, stat, pv
+        live = torch.arange(5, device=dev)[None, :] < n_out[:, None]
+        nan = torch.tensor(float("nan"), dtype=torch.float64, device=dev)
+        return (n_out, torch.where(live, ids.T, torch.tensor(-1, dtype=torch.int32, device=dev)), torch.where(live, mf.T, nan),
+                torch.where(live[:, :, None], stat.permute(1, 0, 2), nan), torch.where(live[:, :, None], pv.permute(1, 0, 2), nan))
 
-    def ols_iterate(self, counts, pool_sizes, flt: Filter, Y):
+    def ols_iterate(self, counts, pool_sizes, flt: Filter, Y, raw: bool = False):
         return self._batch(self._lib.pg_ols_iter_batch_dev, "pg_ols_iter_batch_dev", counts,
-                           pool_sizes, flt, Y)
+                           pool_sizes, flt, Y, raw)
 
-    def correlation(self, counts, pool_sizes, flt: Filter, Y):
+    def correlation(self, counts, pool_sizes, flt: Filter, Y, raw: bool = False):
         return self._batch(self._lib.pg_pearson_batch_dev, "pg_pearson_batch_dev", counts,
-                           pool_sizes, flt, Y)
+                           pool_sizes, flt, Y, raw)
 
-    def chisq(self, counts, pool_sizes, flt: Filter):
+    def chisq(self, counts, pool_sizes, flt: Filter, raw: bool = False):
         L, n, _ = counts.shape
         ps = _host_f64(pool_sizes)
         dev = counts.device
         n_out = torch.empty(L, dtype=torch.int32, device=dev)
-        ids = torch.empty((L, 5), dtype=torch.int32, device=dev)
+        ids = torch.empty((5, L), dtype=torch.int32, device=dev)   # the surviving alleles of the row in the slots below n_out
         chi2 = torch.empty(L, dtype=torch.float64, device=dev)
         pv = torch.empty(L, dtype=torch.float64, device=dev)
         f = flt.to_c()
         self._check(self._lib.pg_chisq_batch_dev(self._ctx, self._dev(counts, torch.int32), L, n, ps.ctypes.data,
                                                  C.byref(f), n_out.data_ptr(), ids.data_ptr(),
                                                  chi2.data_ptr(), pv.data_ptr()), "pg_chisq_batch_dev")
-        return n_out, ids, chi2, pv
+        if raw:
+            return n_out, ids, chi2, pv
+        live = torch.arange(5, device=dev)[None, :] < n_out[:, None]
+        return n_out, torch.where(live, ids.T, torch.tensor(-1, dtype=torch.int32, device=dev)), chi2, pv
 
     def load_frequencies(self, counts, pool_sizes, flt: Filter, keep_p_minus_1: bool = False, order=None,
                          pool_keep=None, ld: int | None = None, coverages: bool = False):

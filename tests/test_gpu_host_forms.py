@@ -95,8 +95,9 @@ def test_batch_operators_host_buffers(native, ctx, oracle, op):
     ps = np.full(n, 1.0 / n)
     f = PgFilter(1, 0, 5, 0.01, 0.0)
     fo = oracle.filt(True, 5, 0.01, 0.0)
-    n_out = np.full(L, -1, dtype=np.int32); ids = np.full((L, 5), -1, dtype=np.int32)
-    mf = np.full((L, 5), np.nan); stat = np.full((L, 5, k), np.nan); pv = np.full((L, 5, k), np.nan)
+    # the library's layout is slot-major: (slot, locus[, trait]); only the slots below n_out[l] are specified
+    n_out = np.full(L, -1, dtype=np.int32); ids = np.full((5, L), -1, dtype=np.int32)
+    mf = np.full((5, L), np.nan); stat = np.full((5, L, k), np.nan); pv = np.full((5, L, k), np.nan)
     if op == "chisq":
         chi2 = np.full(L, np.nan); p1 = np.full(L, np.nan)
         rc = native.pg_chisq_batch(ctx, counts.ctypes.data, L, n, ps.ctypes.data, C.byref(f), n_out.ctypes.data, ids.ctypes.data,
@@ -113,7 +114,7 @@ def test_batch_operators_host_buffers(native, ctx, oracle, op):
             a, rid, rchi, rp = oracle.chisq_locus(c64, ps, fo)
             assert n_out[l] == a, l
             if a:
-                assert list(ids[l, :a]) == list(rid)
+                assert list(ids[:a, l]) == list(rid)
                 assert (np.isnan(chi2[l]) and np.isnan(rchi)) or abs(chi2[l] - rchi) <= 1e-10 * max(1.0, abs(rchi))
                 assert (np.isnan(p1[l]) and np.isnan(rp)) or abs(p1[l] - rp) <= 1e-10
                 emitted += 1
@@ -124,8 +125,8 @@ def test_batch_operators_host_buffers(native, ctx, oracle, op):
         if na == 0:
             continue
         emitted += 1
-        assert list(ids[l, :na]) == list(ref[1])
-        assert np.array_equal(mf[l, :na], np.array(ref[2]))                 # mean frequencies: bit-exact
+        assert list(ids[:na, l]) == list(ref[1])
+        assert np.array_equal(mf[:na, l], np.array(ref[2]))                 # mean frequencies: bit-exact
         X = None
         if op == "ols_iter":   # rank-deficient designs print noise in the reference: emission pattern only (counted below)
             idf, fc = oracle.filter_locus(c64, ps, fo)
@@ -133,6 +134,6 @@ def test_batch_operators_host_buffers(native, ctx, oracle, op):
             X = np.ones_like(fr); X[:, 1:] = fr[:, 1:]
             if np.linalg.cond(X) > 1e7:
                 continue
-        assert np.allclose(stat[l, :na], ref[3], rtol=1e-10, atol=1e-10, equal_nan=True), l
-        assert np.allclose(pv[l, :na], ref[4], rtol=0, atol=1e-10, equal_nan=True), l
+        assert np.allclose(stat[:na, l], ref[3], rtol=1e-10, atol=1e-10, equal_nan=True), l
+        assert np.allclose(pv[:na, l], ref[4], rtol=0, atol=1e-10, equal_nan=True), l
     assert emitted > L // 3

@@ -24,9 +24,9 @@ def main():
     Y = synth.phenotypes(G, n, k=1)
     ps = np.full(n, 20.0); f = Filter()
     eng.profile(True)
-    for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(counts, ps, f, Y), "ols_iter"),
-                          ("pearson_corr", lambda: eng.correlation(counts, ps, f, Y), "pearson"),
-                          ("chisq_test", lambda: eng.chisq(counts, ps, f), "chisq")):
+    for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(counts, ps, f, Y, raw=True), "ols_iter"),
+                          ("pearson_corr", lambda: eng.correlation(counts, ps, f, Y, raw=True), "pearson"),
+                          ("chisq_test", lambda: eng.chisq(counts, ps, f, raw=True), "chisq")):
         fn(); fn(); fn()
         eng.profile_reset()
         dt = timeit(fn, reps=20)

@@ -14,7 +14,7 @@ for frac in (0.0, 0.05, 0.5, 1.0):
         idx = torch.randperm(L, device="cuda")[:nsel]
         c[idx, 7, 2] = 1          # one read of a third allele in pool 7: dropped by the MAF filter WITH reads -> second pass
     eng.profile(True)
-    for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(c, ps, f, Y), "ols_iter"), ("chisq", lambda: eng.chisq(c, ps, f), "chisq")):
+    for name, fn, kid in (("ols_iter", lambda: eng.ols_iterate(c, ps, f, Y, raw=True), "ols_iter"), ("chisq", lambda: eng.chisq(c, ps, f, raw=True), "chisq")):
         fn(); fn(); eng.profile_reset()
         for _ in range(5): fn()
         ms, cnt = eng.profile_get(kid)
