@@ -52,7 +52,7 @@ struct LocusParams {
     int n, k;        // k = traits handled by this launch (<= MAXK)
     int k_total, t0; // output layout: trait t0 + tt of k_total
     int remove_ns;
-    int pshift;      // log2(period), see k_locus_first / unit_slot
+    int pshift;      // unit_slot's interleave (0 since round 3: records and flags are indexed by the locus itself)
     int sort_desc;   // OP_LOAD: order the surviving alleles by decreasing column sum (--keep-p-minus-1)
     double min_cov, maf, max_miss;
     int tdf, ntcoef;     // t-test degrees of freedom (OLS: n-1, Pearson: n-2)
@@ -172,9 +172,9 @@ __device__ __forceinline__ constexpr int tri(int a, int b) { // a <= b
 
 // record layout (struct-of-arrays: field f of locus l at rec[f * L + l])
 constexpr int REC_DOUBLES = 42; // the largest compact record: pearson, 5 outputs x 2 traits (see emit_record)
-// Records and flags are stored UNIT-MAJOR: the 64 loci a wave of k_locus_first works on (one alignment
-// class of a group of 64 * period rows, see there) are adjacent, field f of slot s at
-// rec[(s / 64) * REC_DOUBLES * 64 + f * 64 + s % 64], so that a wave's stores are whole 512-byte runs.
+// Records (of the second pass) and flags live in groups of 64 slots: field f of slot s at
+// rec[(s / 64) * REC_DOUBLES * 64 + f * 64 + s % 64], so that a wave's stores are whole 512-byte runs.  slot = unit_slot(l, pshift);
+// with pshift = 0 (every caller since round 3) the slot is the locus.
 __device__ __forceinline__ int64_t unit_slot(int64_t l, int pshift) {
     const int64_t g = l >> (6 + pshift);
     const int within = (int)(l - (g << (6 + pshift)));
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 }
             }
         }
-        // a deferred locus gets the "dropped" pattern here; k_locus_close overwrites it later in the stream
+        // a deferred locus gets the "dropped" pattern here; k_locus_second overwrites it later in the stream
         if (staged & 1) put_result(lane * M + fin_i, nout, idsp, mf, st, pv);
         else if (valid) store_result(l, nout, idsp, mf, st, pv);
     };
