@@ -101,3 +101,5 @@ int pg_pinv_solve_sym(const double *A, int n, const double *B, int k, double *X)
 // launchers (defined in the .hip files)
 int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
                       bool add_intercept, int kid, bool allow_fuse = false);
+int pg_launch_kinship_w8(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
+                         bool add_intercept, int kid, bool allow_fuse = false); // 8-wave workgroups (pg_kinship_w8.hip): <= 64 pools

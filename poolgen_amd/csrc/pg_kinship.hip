@@ -664,8 +664,18 @@ __global__ __launch_bounds__(256) void k_kinship_reduce(const double *__restrict
 
 } // namespace
 
-int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
+#ifndef KIN_LAUNCH_NAME
+#define KIN_LAUNCH_NAME pg_launch_kinship
+#endif
+int KIN_LAUNCH_NAME(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, double *S,
                       bool add_intercept, int kid, bool allow_fuse) {
+#if KIN_WAVES_DEF == 16
+    // Up to 64 pools (<= 10 tiles) a 16-wave workgroup leaves most of its waves without a tile: the same kernel built for 8-wave
+    // workgroups (pg_kinship_w8.hip) takes over -- 1.36 -> 1.01 ms per 4 M loci at 48 and 64 pools; from 100 pools on it is no
+    // faster, at 150 slower (profiles/r03_kinship_small_n.log).  POOLGEN_KIN_NO_W8=1: A/B runs.
+    if (n <= 64 && !std::getenv("POOLGEN_KIN_NO_W8")) return pg_launch_kinship_w8(ctx, G, p, n, ld, S, add_intercept, kid, allow_fuse);
+#endif
+
     PG_CHECK(ctx, G && S, "kinship: null pointer");
     PG_CHECK(ctx, p > 0 && n > 0, "kinship: need p > 0 and n > 0 (p=%lld n=%d)", (long long)p, n);
     PG_CHECK(ctx, ld >= n && (ld % 2) == 0, "kinship: ld (%lld) must be even and >= n (%d)",
@@ -841,6 +851,7 @@ int pg_launch_kinship(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld
     return PG_OK;
 }
 
+#ifndef KIN_NO_EXPORTS // (pg_kinship_w8.hip includes this file for its launcher only)
 extern "C" int pg_kinship_partial_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n,
                                       int64_t ld, double *S_dev) {
     if (!ctx) return PG_ERR_INVALID;
@@ -888,3 +899,4 @@ extern "C" int pg_set_phenotypes(pg_ctx *ctx, int n, const double *Y, int k) {
     ctx->ph_n = n; ctx->ph_k = k;
     return PG_OK;
 }
+#endif // KIN_NO_EXPORTS
