@@ -139,6 +139,11 @@ struct KinParams {
     // by linear id; with (slab, pair) = blockIdx.(x, y) the pairs of a slab landed on different XCDs and each pool column came
     // from HBM nb - 1 times: 54 GB for the 20 GB of config 4).  xcd_spx = slabs per XCD in that placement, 0 = plain 2-D grid.
     int xcd_spx, npairs, nslab;
+    // run-time tile tables: a wave skips the slots it has no tile for (28 tiles on 16 waves: 4 of 32 slots; 10 tiles on 8 waves: 6 of
+    // 16) -- their LDS reads and matrix cycles.  4 M loci, ms, without -> with: 32 pools 0.89 -> 0.77, 64: 1.02 -> 0.95, 100: 1.54 ->
+    // 1.43, 150: 2.57 -> 2.36, 250 (merged pair lists): 6.83 -> 5.53.  Off for the weighted pairs (wq_n), whose slab lengths are
+    // balanced on the slot counts (224 and 300 pools: 10-15 % slower with it), and from four blocks on.
+    int skip_dead; // (host side only: selects the kernel instance)
     // Two or three pool blocks without the merged tile lists (n = 209..224, 257..384): the pairs differ in work (a diagonal pair
     // of 8 tile columns has 36 tiles, an off-diagonal one 64, the pairs of a short last block fewer still), so each pair gets its
     // own number of workgroups -- and with it its own slab length -- in proportion to the tile slots its waves run.  With one
@@ -159,7 +164,9 @@ struct KinParams {
 // (lane: pool = lane & 15, locus = lane >> 4) IS the A operand whose four blocks are the four 4-pool groups of that column,
 // a B operand "column group (blk + d) % 4" is the same register rotated by 4 d lanes inside its 16-lane row (DPP, no LDS), and
 // only the 8-pool strip needs reads of its own.  200 pools: 5 200 instead of 5 824 matrix cycles per 4 loci.
-template <bool FUSE, bool SPEC13, int SMALL = 0> // SMALL bits: 1 = diagonal tiles on 4 x 4 blocks, 2 = 8-pool last column (n <= 200) on 4 x 4 blocks
+// SKIP (run-time tile tables only): see KinParams::skip_dead -- a template parameter because even a never-taken branch around an
+// item keeps the compiler from running the fragment reads ahead of the MFMAs (measured: +8..10 % at 224 and 500 pools).
+template <bool FUSE, bool SPEC13, int SMALL = 0, bool SKIP = false> // SMALL bits: 1 = diagonal tiles on 4 x 4 blocks, 2 = 8-pool last column (n <= 200) on 4 x 4 blocks
 __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -534,6 +541,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
                 fb[q % R] = bufbase[bo];
 #endif
             } else {
+                if constexpr (SKIP) { if (!live[u]) return; } // (wave-uniform) a slot beyond this wave's tiles: neither its reads nor its matrix cycles
                 const double *row = bufbase + 4 * s * ldsld;
                 fa[q % R] = row[acol[u]];
                 fb[q % R] = row[bcol[u]];
@@ -543,6 +551,7 @@ __global__ __launch_bounds__(KIN_THREADS, 1) void k_kinship_syrk(KinParams P) {
             constexpr int q = decltype(qc)::value;
             constexpr int u = q % TPW;
             if constexpr (W >= 0 && W + KIN_WAVES * u >= 91) return;
+            if constexpr (W < 0 && SKIP) { if (!live[u]) return; }
             acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q % R], fb[q % R], acc[u], 0, 0, 0);
         };
         if (nstages > 0)
@@ -728,6 +737,7 @@ int KIN_LAUNCH_NAME(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, 
     nslab = (int)((p + P.loci_per_wg - 1) / P.loci_per_wg);
 
     P.npairs = npairs; P.nslab = nslab;
+    P.skip_dead = (!std::getenv("POOLGEN_KIN_NO_SKIP") && P.nb <= 2) ? 1 : 0; // (from 4 blocks on the lists are full: 500 pools 10.17 -> 10.36 ms with it)
     P.xcd_spx = 0;
     if (npairs > 1 && cus % 8 == 0 && !std::getenv("POOLGEN_KIN_NO_XCD")) {
         const int spx = (cus / 8) / npairs;        // whole slabs (all their pairs) that fit one XCD's CUs
@@ -773,6 +783,7 @@ int KIN_LAUNCH_NAME(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, 
         nslab = maxn;
         P.nslab = nslab;
         P.xcd_spx = 0;
+        P.skip_dead = 0;
         KC.blk = P.Tb * 16;
     }
     const size_t slab_bytes = (size_t)nslab * P.npad * P.npad * sizeof(double);
@@ -827,7 +838,7 @@ int KIN_LAUNCH_NAME(pg_ctx *ctx, const double *G, int64_t p, int n, int64_t ld, 
     if (std::getenv("POOLGEN_KIN_NO_SMALL")) sm = 0;
     auto pick = [&](auto fz) -> hipError_t {
         constexpr bool FZ = decltype(fz)::value;
-        if (!spec13) return launch(k_kinship_syrk<FZ, false>);
+        if (!spec13) return P.skip_dead ? launch(k_kinship_syrk<FZ, false, 0, true>) : launch(k_kinship_syrk<FZ, false, 0, false>);
         switch (sm) {
         case 1: return launch(k_kinship_syrk<FZ, true, 1>);
         case 2: return launch(k_kinship_syrk<FZ, true, 2>);
