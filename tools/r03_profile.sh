@@ -79,15 +79,15 @@ out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc passes of `python3
                    "(tools/r03_profile.sh; per-kernel means in the `source` file): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 being the "
                    "gfx950 wide-read correction of MI355X_MICROARCH.md.  The sweep legs are separated by dispatch order.",
        "source": f"profiles/{TAG}_pmc_summary.txt", "workload": "200x10000000", "kernel_sources_sha256": src.hexdigest(),
-       "kinship_hbm_bytes_per_launch": hbm("k_kinship_syrk<true, true, 3>"),
-       "kinship_two_pass_hbm_bytes_per_launch": hbm("k_kinship_syrk<false, true, 3>"),
+       "kinship_hbm_bytes_per_launch": hbm("k_kinship_syrk<true, true, 3"),
+       "kinship_two_pass_hbm_bytes_per_launch": hbm("k_kinship_syrk<false, true, 3"),
        "sweep_two_pass_hbm_bytes_per_launch": hbm("k_ols_sweep_mfma<5, 3, 1, 0> [leg two_pass]"),
        "sweep_m8_hbm_bytes_per_launch": hbm("k_ols_sweep_mfma<5, 3, 1, 0> [leg m8]"),
        "ols_iter_stream_hbm_bytes_per_launch": hbm("k_locus_stream<0, true, 1>"),
        "pearson_stream_hbm_bytes_per_launch": hbm("k_locus_stream<1, true, 1>"),
        "chisq_stream_hbm_bytes_per_launch": hbm("k_locus_stream<2, true, 1>"),
        "ridge_predict_hbm_bytes_per_launch": hbm("k_gp_predict_folds")}
-mf, ga = find("k_kinship_syrk<true, true, 3>", "SQ_VALU_MFMA_BUSY_CYCLES"), find("k_kinship_syrk<true, true, 3>", "GRBM_GUI_ACTIVE")
+mf, ga = find("k_kinship_syrk<true, true, 3", "SQ_VALU_MFMA_BUSY_CYCLES"), find("k_kinship_syrk<true, true, 3", "GRBM_GUI_ACTIVE")
 if mf and ga: out["kinship_mfma_busy_frac"] = mf / 1024.0 / (ga / 8.0)
 json.dump(out, open(f"gpurun_out/{TAG}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
