@@ -11,7 +11,7 @@ t1=$(date +%s.%N)
 big=$d/big.$kind
 : > $big
 for i in $(seq 1 $copies); do
-  pre=$(printf "\\$(printf '%03o' $((96 + i)))")      # a, b, c, ...: chromosome names stay sorted
+  pre=$(printf '%02d' $i)                              # 01, 02, ...: chromosome names stay sorted (up to 99 copies)
   sed "s/^chr/${pre}chr/" $d/base.sync >> $big
 done
 t2=$(date +%s.%N)
