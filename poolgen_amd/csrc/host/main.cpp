@@ -753,10 +753,15 @@ static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &lap
             n_out.resize(L); ids.resize((size_t)L * PG_MAX_OUT); mfq.resize((size_t)L * PG_MAX_OUT);
             stat.resize((size_t)L * per_stat); pv.resize((size_t)L * per_stat);
             hip_ok(hipMemcpy(n_out.data(), n_out_dev, sizeof(int32_t) * L, hipMemcpyDeviceToHost), "D2H results");
-            hip_ok(hipMemcpy(ids.data(), ids_dev, sizeof(int32_t) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
-            if (mode != 0) hip_ok(hipMemcpy(mfq.data(), mf_dev, sizeof(double) * L * PG_MAX_OUT, hipMemcpyDeviceToHost), "D2H results");
-            hip_ok(hipMemcpy(stat.data(), stat_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
-            hip_ok(hipMemcpy(pv.data(), pv_dev, sizeof(double) * L * per_stat, hipMemcpyDeviceToHost), "D2H results");
+            // slot-major arrays: the slots any locus of the piece uses are a prefix of every array (one slot on biallelic data)
+            int used = 0;
+            for (int64_t l = 0; l < L; ++l) used = std::max(used, (int)n_out[l]);
+            used = std::min(used, (int)PG_MAX_OUT);
+            const size_t per_stat_used = mode == 0 ? 1 : (size_t)used * k;
+            hip_ok(hipMemcpy(ids.data(), ids_dev, sizeof(int32_t) * L * used, hipMemcpyDeviceToHost), "D2H results");
+            if (mode != 0) hip_ok(hipMemcpy(mfq.data(), mf_dev, sizeof(double) * L * used, hipMemcpyDeviceToHost), "D2H results");
+            hip_ok(hipMemcpy(stat.data(), stat_dev, sizeof(double) * L * per_stat_used, hipMemcpyDeviceToHost), "D2H results");
+            hip_ok(hipMemcpy(pv.data(), pv_dev, sizeof(double) * L * per_stat_used, hipMemcpyDeviceToHost), "D2H results");
             if (!fo) {
                 fo = create_new(part[r]);
                 if (R == 1) fputs(header, fo);
