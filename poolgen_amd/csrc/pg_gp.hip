@@ -67,8 +67,31 @@ __global__ void k_gp_norm_max(const double *__restrict__ beta, int64_t p, int k,
     }
 }
 
+// all columns of a column-major matrix in one launch: blockIdx.y = column (its own values, or the proxy's column c % kx)
+__global__ void k_gp_norm_max_cols(const double *__restrict__ cols, int64_t p, Proxy X, int kx, double alpha, const int *__restrict__ skip,
+                                   double *__restrict__ part, int64_t part_stride) {
+    const int c = blockIdx.y;
+    if (skip[c]) return;
+    const double *src = X.b ? X.b : cols + (size_t)c * p;
+    const int k = X.b ? X.k : 1, j = X.b ? c % kx : 0, row0 = X.b ? 1 : 0;
+    double m = 0.0;
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < p; l += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, gp_norm(src[(l + row0) * k + j], alpha));
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, sm[w]);
+        part[(size_t)c * part_stride + blockIdx.x] = m;
+    }
+}
+
 // For every lambda_i: subtracted/added masses of the penalised set and the norm masses of the
 // de-penalised set, split by the sign of b (:296-326).  part: [block][4][GP_LMAX].
+// LP = the path length rounded up to even (a compile-time constant: the pass is bound by these 4 x LP conditional sums per element,
+// 16 instead of 12 of them cost a third more)
+template <int LP>
 __device__ __forceinline__ void gp_path_sums_body(const double *__restrict__ beta, int64_t p, int k, int j, int row0,
                                                   const PathParams &P, Proxy X, double *__restrict__ part) {
     double sp[GP_LMAX], ap[GP_LMAX], sd[GP_LMAX], ad[GP_LMAX];
@@ -83,7 +106,7 @@ __device__ __forceinline__ void gp_path_sums_body(const double *__restrict__ bet
         const double pen_pos = pos ? (((b - nrm) < 0.0) ? b : nrm) : 0.0;       // :298-305
         const double pen_neg = pos ? 0.0 : (((b + nrm) > 0.0) ? fabs(b) : nrm); // :306-313
 #pragma unroll
-        for (int i = 0; i < GP_LMAX; ++i) { // entries beyond P.L (lambda = 0) are never read: no guard, no branches
+        for (int i = 0; i < LP; ++i) { // entries beyond P.L (lambda = 0) are never read: no guard, no branches
             const bool pen = sc < P.lambda[i];
             sp[i] += pen ? pen_pos : 0.0;
             ap[i] += pen ? pen_neg : 0.0;
@@ -108,11 +131,13 @@ __device__ __forceinline__ void gp_path_sums_body(const double *__restrict__ bet
         part[(size_t)blockIdx.x * 4 * GP_LMAX + threadIdx.x] = s;
     }
 }
+template <int LP>
 __global__ __launch_bounds__(256) void k_gp_path_sums(const double *__restrict__ beta, int64_t p, int k, int j, int row0, PathParams P,
                                                       Proxy X, double *__restrict__ part) {
-    gp_path_sums_body(beta, p, k, j, row0, P, X, part);
+    gp_path_sums_body<LP>(beta, p, k, j, row0, P, X, part);
 }
 // all columns of a column-major matrix in one launch: blockIdx.y = column, its norm maximum from nmax[] (device)
+template <int LP>
 __global__ __launch_bounds__(256) void k_gp_path_sums_cols(const double *__restrict__ cols, int64_t p, PathParams P, Proxy X, int kx,
                                                            const double *__restrict__ nmax, const int *__restrict__ skip,
                                                            double *__restrict__ part) {
@@ -120,7 +145,7 @@ __global__ __launch_bounds__(256) void k_gp_path_sums_cols(const double *__restr
     if (skip[c]) return;
     P.nmax = nmax[c];
     X.j = c % kx;
-    gp_path_sums_body(cols + (size_t)c * p, p, 1, 0, 0, P, X, part + (size_t)c * gridDim.x * 4 * GP_LMAX);
+    gp_path_sums_body<LP>(cols + (size_t)c * p, p, 1, 0, 0, P, X, part + (size_t)c * gridDim.x * 4 * GP_LMAX);
 }
 
 // expand_and_contract of one coefficient for lambda_i (:296-352), given the global masses
@@ -411,7 +436,12 @@ int ridge_path_params(pg_ctx *ctx, const double *beta_dev, int64_t p, int k, int
     P.nmax = mx;
     P.L = (int)path.size();
     for (int i = 0; i < P.L; ++i) P.lambda[i] = path[i];
-    hipLaunchKernelGGL(k_gp_path_sums, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, P, X, W.part);
+    switch ((P.L + 1) & ~1) {
+#define PG_PATH_SUMS(LPV) case LPV: hipLaunchKernelGGL(k_gp_path_sums<LPV>, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, P, X, W.part); break;
+        PG_PATH_SUMS(2) PG_PATH_SUMS(4) PG_PATH_SUMS(6) PG_PATH_SUMS(8) PG_PATH_SUMS(10) PG_PATH_SUMS(12) PG_PATH_SUMS(14)
+        default: hipLaunchKernelGGL(k_gp_path_sums<GP_LMAX>, dim3(nb), dim3(256), 0, ctx->stream, beta_dev, p, k, j, row0, P, X, W.part); break;
+#undef PG_PATH_SUMS
+    }
     PG_HIP(ctx, hipGetLastError());
     PG_HIP(ctx, hipMemcpyAsync(h.data(), W.part, sizeof(double) * nb * 4 * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -464,27 +494,34 @@ int ridge_path_params_cols(pg_ctx *ctx, const double *cols_dev, int64_t p, int n
     std::vector<double> h((size_t)ncols * width);
     out.assign(ncols, PathParams{});
     PG_HIP(ctx, hipMemsetAsync(W.part, 0, sizeof(double) * (size_t)ncols * nb * width, ctx->stream)); // skipped columns reduce to 0
-    for (int c = 0; c < ncols; ++c) {
-        if (skip[c]) continue;
-        const Proxy X{proxy_dev, k, c % k};
-        if (X.b) hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, X.b, p, X.k, X.j, 1, alpha, W.part + (size_t)c * nb * width);
-        else hipLaunchKernelGGL(k_gp_norm_max, dim3(nb), dim3(256), 0, ctx->stream, cols_dev + (size_t)c * p, p, 1, 0, 0, alpha, W.part + (size_t)c * nb * width);
-    }
-    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream, W.part, ncols, nb, (int64_t)nb * width, 1,
-                       1, 1, red);
-    PG_HIP(ctx, hipGetLastError());
     // the maxima stay on the device for the path sums (and travel to the host with them, further down)
     double *nmax_dev = red + (size_t)ncols * width;
     int *skip_dev = reinterpret_cast<int *>(nmax_dev + ncols);
-    PG_HIP(ctx, hipMemcpyAsync(nmax_dev, red, sizeof(double) * ncols, hipMemcpyDeviceToDevice, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(skip_dev, skip.data(), sizeof(int) * ncols, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gp_norm_max_cols, dim3(nb, ncols), dim3(256), 0, ctx->stream, cols_dev, p, Proxy{proxy_dev, k, 0}, k, alpha, skip_dev,
+                       W.part, (int64_t)nb * width); // every column in one launch (was one launch per column: 200 per config-4 run)
+    hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream, W.part, ncols, nb, (int64_t)nb * width, 1,
+                       1, 1, red);
+    PG_HIP(ctx, hipGetLastError());
+    PG_HIP(ctx, hipMemcpyAsync(nmax_dev, red, sizeof(double) * ncols, hipMemcpyDeviceToDevice, ctx->stream));
     PathParams Pc;
     std::memset(&Pc, 0, sizeof Pc);
     Pc.alpha = alpha;
     Pc.L = (int)path.size();
     for (int i = 0; i < Pc.L; ++i) Pc.lambda[i] = path[i];
-    hipLaunchKernelGGL(k_gp_path_sums_cols, dim3(nb, ncols), dim3(256), 0, ctx->stream, cols_dev, p, Pc, Proxy{proxy_dev, k, 0}, k, nmax_dev,
-                       skip_dev, W.part);
+    switch ((Pc.L + 1) & ~1) {
+#define PG_PATH_SUMS(LPV)                                                                                                   \
+    case LPV:                                                                                                               \
+        hipLaunchKernelGGL(k_gp_path_sums_cols<LPV>, dim3(nb, ncols), dim3(256), 0, ctx->stream, cols_dev, p, Pc, Proxy{proxy_dev, k, 0}, k, \
+                           nmax_dev, skip_dev, W.part);                                                                     \
+        break;
+        PG_PATH_SUMS(2) PG_PATH_SUMS(4) PG_PATH_SUMS(6) PG_PATH_SUMS(8) PG_PATH_SUMS(10) PG_PATH_SUMS(12) PG_PATH_SUMS(14)
+        default:
+            hipLaunchKernelGGL(k_gp_path_sums_cols<GP_LMAX>, dim3(nb, ncols), dim3(256), 0, ctx->stream, cols_dev, p, Pc, Proxy{proxy_dev, k, 0}, k,
+                               nmax_dev, skip_dev, W.part);
+            break;
+#undef PG_PATH_SUMS
+    }
     hipLaunchKernelGGL(k_gp_reduce_parts, dim3((ncols * width + 3) / 4), dim3(256), 0, ctx->stream, W.part, ncols, nb,
                        (int64_t)nb * width, width, width, 0, red);
     PG_HIP(ctx, hipGetLastError());
