@@ -273,3 +273,32 @@ def test_config2_full_size_properties(engine, oracle):
     rows = counts[sl].cpu().numpy().astype(np.uint64)
     res = engine.ols_iterate(counts, ps, f, Y)
     check_stat_op(tuple(x[sl] for x in res), oracle.ols_iterate_locus, rows, Y, ps, fo, oracle=oracle)
+
+
+def test_slot_major_layout_of_the_abi(engine, oracle):
+    """include/poolgen_hip.h: element (slot r, locus l) of allele_ids / mean_freq at r * L + l, of stat / pval at
+    (r * L + l) * k + trait; only the slots r < n_out[l] are specified.  The raw arrays of the library against the
+    locus-major copies the other tests index, on the reference's fixture (multi-allelic loci included) with two traits."""
+    rows, Y, ps = load_fixture(oracle)
+    f, _ = flt_pair(oracle)
+    Y2 = np.column_stack([Y[:, 0], Y[:, 0] ** 2 + 0.1 * np.arange(Y.shape[0])])
+    counts = to_dev(rows)
+    L = counts.shape[0]
+    for op in (engine.ols_iterate, engine.correlation):
+        n_out, ids, mf, stat, pv = (x.cpu().numpy() for x in op(counts, ps, f, Y2))
+        rn, rids, rmf, rstat, rpv = (x.cpu().numpy() for x in op(counts, ps, f, Y2, raw=True))
+        assert rids.shape == (5, L) and rmf.shape == (5, L) and rstat.shape == (5, L, 2) and rpv.shape == (5, L, 2)
+        assert np.array_equal(rn, n_out) and n_out.max() >= 2   # the fixture has loci that emit several rows
+        for r in range(5):
+            live = n_out > r
+            assert np.array_equal(rids[r][live], ids[live, r])
+            assert np.array_equal(rmf[r][live], mf[live, r], equal_nan=True)
+            assert np.array_equal(rstat[r][live], stat[live, r], equal_nan=True)
+            assert np.array_equal(rpv[r][live], pv[live, r], equal_nan=True)
+            assert np.all(ids[~live, r] == -1) and np.all(np.isnan(mf[~live, r]))   # the copies fill what the library leaves open
+    n_out, ids, chi2, pv = (x.cpu().numpy() for x in engine.chisq(counts, ps, f))
+    rn, rids, rchi2, rpv = (x.cpu().numpy() for x in engine.chisq(counts, ps, f, raw=True))
+    assert rids.shape == (5, L) and np.array_equal(rn, n_out)
+    for r in range(5):
+        live = n_out > r
+        assert np.array_equal(rids[r][live], ids[live, r])
