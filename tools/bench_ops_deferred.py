@@ -1,5 +1,5 @@
 import sys, time, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
 import numpy as np, torch
 from poolgen_amd import Engine, Filter, synth
 n, L = 100, 1_000_000
