@@ -282,12 +282,17 @@ def test_slot_major_layout_of_the_abi(engine, oracle):
     rows, Y, ps = load_fixture(oracle)
     f, _ = flt_pair(oracle)
     Y2 = np.column_stack([Y[:, 0], Y[:, 0] ** 2 + 0.1 * np.arange(Y.shape[0])])
+    Y3 = np.column_stack([Y2, np.cos(np.arange(Y.shape[0]))])   # three traits: ols_iter takes them as two launches (2 + 1)
     counts = to_dev(rows)
     L = counts.shape[0]
-    for op in (engine.ols_iterate, engine.correlation):
-        n_out, ids, mf, stat, pv = (x.cpu().numpy() for x in op(counts, ps, f, Y2))
-        rn, rids, rmf, rstat, rpv = (x.cpu().numpy() for x in op(counts, ps, f, Y2, raw=True))
-        assert rids.shape == (5, L) and rmf.shape == (5, L) and rstat.shape == (5, L, 2) and rpv.shape == (5, L, 2)
+    for op, Yk in ((engine.ols_iterate, Y2), (engine.correlation, Y2), (engine.ols_iterate, Y3)):
+        k = Yk.shape[1]
+        n_out, ids, mf, stat, pv = (x.cpu().numpy() for x in op(counts, ps, f, Yk))
+        rn, rids, rmf, rstat, rpv = (x.cpu().numpy() for x in op(counts, ps, f, Yk, raw=True))
+        assert rids.shape == (5, L) and rmf.shape == (5, L) and rstat.shape == (5, L, k) and rpv.shape == (5, L, k)
+        if k == 3:   # the third trait's column equals a one-trait call on it (the launch groups write disjoint trait columns)
+            s1 = op(counts, ps, f, Y3[:, 2:3])[3].cpu().numpy()
+            assert np.array_equal(stat[:, :, 2], s1[:, :, 0], equal_nan=True)
         assert np.array_equal(rn, n_out) and n_out.max() >= 2   # the fixture has loci that emit several rows
         for r in range(5):
             live = n_out > r
