@@ -234,17 +234,22 @@ struct FoldMasses { double nmax, sub_scale[GP_LMAX], add_scale[GP_LMAX]; };
 // and is slower: 0.55 with two 8-wave workgroups per CU and one chunk of rows ahead, 0.46 with one 16-wave workgroup and
 // two chunks ahead -- the serial phases of a chunk (stage write, table, barrier, products) outlast its memory time
 // (tools/experiments/).
-template <int LP>
+template <int LP, bool GROUPED>
 __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
                                                           int C, const int32_t *__restrict__ colof,
                                                           const FoldMasses *__restrict__ FM, PathParams P0, Proxy X,
                                                           int64_t p, int n, int64_t ld, int64_t loci_per_block,
-                                                          int chunk, double *__restrict__ part) {
+                                                          int chunk, double *__restrict__ part, int groups) {
     extern __shared__ __attribute__((aligned(16))) double Bs[]; // [chunk][F][LS]
     constexpr int LS = LP + 2; // fold stride: 8 * LS bytes put the folds' 16-byte reads of one lambda pair on distinct banks
     const int k = X.k, j = X.j;
     const int F = C / k;
-    const int pool = blockIdx.y * blockDim.x + threadIdx.x; // 256 or 512 threads: one block spans up to 512 pools
+    // 256 or 512 threads: one block spans up to 512 pools.  With fewer pools than that the block splits into `groups` of
+    // blockDim / groups threads: group g takes the loci g, g + groups, ... of every chunk (a row of 100 pools would leave three
+    // fifths of a 256-thread block without a pool, and the pass with a third of its loads in flight) and leaves its own partial.
+    // (GROUPED is a template parameter: the run-time strides cost the plain form 50 registers and half its occupancy)
+    const int gsz = GROUPED ? blockDim.x / groups : blockDim.x, grp = GROUPED ? threadIdx.x / gsz : 0;
+    const int pool = GROUPED ? (int)threadIdx.x - grp * gsz : (int)(blockIdx.y * blockDim.x + threadIdx.x);
     const int64_t l0 = (int64_t)blockIdx.x * loci_per_block;
     const int64_t l1 = min(p, l0 + loci_per_block);
     double acc[LP];
@@ -312,14 +317,26 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
         if (on) {
             const double *bs = Bs + (size_t)f * LS;
             constexpr int U = 8; // loads of G in flight per thread
+            // this group's loci of the chunk: grp, grp + groups, ...  (mg of them; ll counts them)
+            // (uniform trip count: the loci every group has; the m % groups left-over loci go to the first groups below)
+            const int mg = GROUPED ? m / groups : m;
+            // GROUPED: uniform row base + one 32-bit per-thread offset (a per-thread 64-bit base costs the loop 50 registers)
+            const double *gq = GROUPED ? G + lc * ld : gp + lc * ld;
+            const uint32_t voff = GROUPED ? (uint32_t)(((int64_t)grp * ld + (inr ? pool : 0)) * 8) : 0u;
+            const int64_t gstep = GROUPED ? (int64_t)groups * ld : ld;
+            auto gload = [&](int i) -> double {
+                return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(gq + i * gstep) + voff);
+            };
+            const double *bq = bs + (size_t)grp * F * LS;
+            const int bstep = GROUPED ? groups * F * LS : F * LS;
             int ll = 0;
-            for (; ll + U <= m; ll += U) {
+            for (; ll + U <= mg; ll += U) {
                 double g[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) g[u] = gp[(lc + ll + u) * ld];
+                for (int u = 0; u < U; ++u) g[u] = gload(ll + u);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const double *q = bs + (size_t)(ll + u) * F * LS;
+                    const double *q = bq + (ll + u) * bstep;
 #pragma unroll
                     for (int i = 0; i < LP; i += 2) {
                         const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
@@ -328,9 +345,19 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
                     }
                 }
             }
-            for (; ll < m; ++ll) {
-                const double g = gp[(lc + ll) * ld];
-                const double *q = bs + (size_t)ll * F * LS;
+            for (; ll < mg; ++ll) {
+                const double g = gload(ll);
+                const double *q = bq + ll * bstep;
+#pragma unroll
+                for (int i = 0; i < LP; i += 2) {
+                    const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
+                    acc[i] = fma(g, b2.x, acc[i]);
+                    acc[i + 1] = fma(g, b2.y, acc[i + 1]);
+                }
+            }
+            if (GROUPED && grp + groups * mg < m) { // one of the m % groups left-over loci
+                const double g = gload(mg);
+                const double *q = bq + mg * bstep;
 #pragma unroll
                 for (int i = 0; i < LP; i += 2) {
                     const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
         }
     }
     if (inr) {
-        double *o = part + ((size_t)blockIdx.x * n + pool) * GP_LMAX;
+        double *o = part + (((size_t)blockIdx.x * (GROUPED ? groups : 1) + grp) * n + pool) * GP_LMAX;
 #pragma unroll
         for (int i = 0; i < GP_LMAX; ++i) o[i] = i < LP ? acc[i] : 0.0;
     }
@@ -584,7 +611,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
     const int nblk2 = (int)((p + lpb - 1) / lpb);
     RidgeWork W;
     const size_t part_doubles = std::max<size_t>((size_t)(n_folds * k + 1) * 1024 * 4 * GP_LMAX + (size_t)n_folds * k * 4 * GP_LMAX,
-                                                 (size_t)nblk2 * n * GP_LMAX);
+                                                 (size_t)nblk2 * n * GP_LMAX * 4); // (x 4: the prediction pass' locus groups at n <= 256)
     char *raw = nullptr;
     PG_HIP(ctx, hipMalloc((void **)&raw, sizeof(double) * (part_doubles + (size_t)p * GP_LMAX + (size_t)n * GP_LMAX)));
     W.part = reinterpret_cast<double *>(raw);
@@ -728,15 +755,20 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 const int LP = (P0.L + 1) & ~1;
                 const size_t masses_b = sizeof(double) * n_folds * (2 * GP_LMAX + 1);
                 const int chunk = std::max(4, std::min(64, (int)((49152 - masses_b) / (sizeof(double) * n_folds * (LP + 2)))));
-                const int bthreads = n > 256 ? 512 : 256; // the coefficient stage is shared by all waves of a block
-                const dim3 grid(nblk2, (n + bthreads - 1) / bthreads);
+                const int bthreads = n > 128 ? 512 : 256; // the coefficient stage is shared by all waves of a block
+                const int groups = n <= 256 ? bthreads / (((n + 63) / 64) * 64) : 1; // locus groups inside a block (n <= 256: 2 .. 4)
+                const dim3 grid(nblk2, groups > 1 ? 1 : (n + bthreads - 1) / bthreads);
                 const size_t lds = sizeof(double) * chunk * n_folds * (LP + 2) + masses_b;
                 const Proxy X{proxy_dev, k, j};
                 pg_prof_begin(ctx, PG_K_GP_PREDICT);
 #define PG_PREDICT_FOLDS(LPV)                                                                                              \
     case LPV:                                                                                                              \
-        hipLaunchKernelGGL(k_gp_predict_folds<LPV>, grid, dim3(bthreads), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, p, n, \
-                           ld, lpb, chunk, W.part);                                                                        \
+        if (groups > 1)                                                                                                    \
+            hipLaunchKernelGGL((k_gp_predict_folds<LPV, true>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, \
+                               p, n, ld, lpb, chunk, W.part, groups);                                                      \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_gp_predict_folds<LPV, false>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, \
+                               p, n, ld, lpb, chunk, W.part, 1);                                                           \
         break;
                 switch (LP) {
                     PG_PREDICT_FOLDS(2) PG_PREDICT_FOLDS(4) PG_PREDICT_FOLDS(6) PG_PREDICT_FOLDS(8) PG_PREDICT_FOLDS(10)
@@ -744,7 +776,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 }
 #undef PG_PREDICT_FOLDS
                 pg_prof_end(ctx);
-                hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 63) / 64), dim3(512), 0, ctx->stream, W.part, nblk2, n, W.yhat);
+                hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 63) / 64), dim3(512), 0, ctx->stream, W.part, nblk2 * groups, n, W.yhat);
                 if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                     hipStreamSynchronize(ctx->stream) != hipSuccess)
                     return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
