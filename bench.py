@@ -144,6 +144,121 @@ def secondary_legs(eng, dev, args, torch, np):
     return sec
 
 
+def shard_probe_legs(eng, G, Y, n, p_total, var_explained, steps, torch, np):
+    """What ONE rank of an N-rank run does per step, measured on this one GPU with the REAL library communicator (a one-rank RCCL
+    communicator: ncclCommInitRank + ncclAllReduce inside libpoolgen_hip, the path tests/test_gpu_bench.py drives): the rank's slab
+    p_local = p_total / N of the resident matrix, K divided by p_total (gwas/ols.rs:295), the all-reduce of the n x n sums
+    (gwas/ols.rs:291-295 is the one reduction of the analysis; the slabs are the chunks of base/sync.rs:913-939).  A PROBE, not a
+    measurement of N GPUs: the all-reduce of one rank moves no bytes over xGMI, so a real N-rank step adds the ring latency of a
+    320 KB message to these figures."""
+    from poolgen_amd.distributed import ols_with_covariate_sharded
+    legs = {"what": "one rank's step at p_local = p_total / N with a ONE-rank RCCL communicator inside libpoolgen_hip (same calls as the "
+                    "headline step); kernel times = HIP events on the library's stream; fixed_remainder_ms = ms_per_step minus the kernels "
+                    "and the all-reduce (host n x n decision, launches, synchronisations); a probe of the rank-shaped step, NOT an N-GPU "
+                    "measurement"}
+    own_comm = False
+    try:
+        if not getattr(eng, "_comm_ready", False):
+            eng.comm_init(eng.comm_unique_id(), 1, 0)
+            own_comm = True
+        legs["comm_size"] = int(eng.comm_size)
+        try:
+            legs["rccl_version"] = int(eng.comm_version())
+        except Exception:
+            legs["rccl_version"] = None
+        dev = G.device
+        for N in (2, 4, 8):
+            p_local = p_total // N
+            if p_local < 1 or p_local > G.shape[0]:
+                continue
+            Gl = G[:p_local]
+            out = torch.empty((3, p_local, 1), dtype=torch.float64, device=dev)
+            for _ in range(2):
+                ols_with_covariate_sharded(eng, Gl, p_total, Y, var_explained, -1, n, out)
+            eng.profile_reset()
+            torch.cuda.synchronize(dev)
+            stamps = [time.perf_counter()]
+            for _ in range(steps):
+                m = ols_with_covariate_sharded(eng, Gl, p_total, Y, var_explained, -1, n, out)[0]
+                stamps.append(time.perf_counter())
+            torch.cuda.synchronize(dev)
+            total = time.perf_counter() - stamps[0]
+            per = np.diff(np.asarray(stamps)) * 1e3
+            k_ms, k_n = eng.profile_get("kinship")
+            r_ms, r_n = eng.profile_get("kinship_reduce")
+            f_ms, f_n = eng.profile_get("sweep_finish")
+            s_ms, s_n = eng.profile_get("sweep")
+            a_ms, a_n = eng.profile_get("allreduce")
+            ms = total / steps * 1e3
+            kern = (k_ms + r_ms + f_ms + s_ms) / steps
+            legs[f"n{N}"] = {"ranks_modelled": N, "p_local": p_local, "p_total": p_total, "n_eigenvecs": int(m), "steps": steps,
+                             "ms_per_step": ms, "ms_per_step_median": float(np.median(per)),
+                             "kinship_ms": k_ms / max(k_n, 1), "kinship_reduce_ms": r_ms / max(r_n, 1),
+                             "sweep_finish_ms": f_ms / max(f_n, 1), "sweep_ms": s_ms / max(s_n, 1) if s_n else 0.0,
+                             "allreduce_ms": a_ms / max(a_n, 1), "allreduce_launches": int(a_n),
+                             "fixed_remainder_ms": ms - kern - a_ms / steps,
+                             "loci_per_s_if_N_ranks_ran_this": p_total / (ms * 1e-3)}
+            del out
+    except Exception as e:
+        legs["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        if own_comm:
+            try:
+                eng.comm_destroy()
+            except Exception:
+                pass
+    return legs
+
+
+def end_to_end_leg(eng, G, Y, n, loci, var_explained, torch, np):
+    """SURVEY 8(d) timing protocol, second half: wall clock of the host-buffer entry point pg_ols_kinship (what main.rs:285-291 hands
+    over: the matrix in HOST memory) from PINNED host buffers -- H2D of G in slabs overlapped with the partial kinship, n x n step,
+    sweep slab by slab overlapped with the D2H of the results.  Never the headline `value`."""
+    import ctypes as C
+    leg = {"what": "pg_ols_kinship from pinned host memory: wall clock incl. H2D of G, kinship, n x n step, sweep, D2H of beta/var/p; "
+                   "gpu_compute_share = (kinship + sweep kernel time by HIP events) / wall; PCIe-inclusive, never the headline value"}
+    try:
+        p = int(min(loci, G.shape[0]))
+        ld = int(G.shape[1])
+        dev = G.device
+        t0 = time.perf_counter()
+        pinned = torch.empty((p, ld), dtype=torch.float64, pin_memory=True)
+        outs = [torch.empty((p, 1), dtype=torch.float64, pin_memory=True) for _ in range(3)]
+        leg["pin_seconds"] = time.perf_counter() - t0
+        pinned.copy_(G[:p]); torch.cuda.synchronize(dev)
+        # the link alone: one H2D of the same buffer
+        scratch = torch.empty((p, ld), dtype=torch.float64, device=dev)
+        scratch.copy_(pinned, non_blocking=True); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        scratch.copy_(pinned, non_blocking=True); torch.cuda.synchronize(dev)
+        link = time.perf_counter() - t0
+        del scratch
+        Yh = np.ascontiguousarray(Y, dtype=np.float64).reshape(n, -1)
+        m = C.c_int()
+        lib, ctx = eng._lib, eng._ctx
+        walls = []
+        for rep in range(3):
+            eng.profile_reset()
+            t0 = time.perf_counter()
+            rc = lib.pg_ols_kinship(ctx, pinned.data_ptr(), p, n, ld, Yh.ctypes.data, 1, float(var_explained), -1, C.byref(m), None,
+                                    outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())
+            walls.append(time.perf_counter() - t0)
+            if rc != 0:
+                raise RuntimeError(lib.pg_last_error(ctx).decode())
+        k_ms, k_n = eng.profile_get("kinship")
+        s_ms, s_n = eng.profile_get("sweep")
+        wall = float(np.median(walls))
+        gbytes = 8.0 * ld * p
+        leg.update({"pools": n, "loci": p, "host_bytes": gbytes, "wall_s": wall, "wall_s_all": walls, "loci_per_s": p / wall,
+                    "h2d_gbs_equiv": gbytes / wall / 1e9, "h2d_gbs_link_alone": gbytes / link / 1e9,
+                    "kinship_kernel_ms_total": k_ms, "kinship_launches": int(k_n), "sweep_kernel_ms_total": s_ms,
+                    "sweep_launches": int(s_n), "gpu_compute_share": (k_ms + s_ms) * 1e-3 / walls[-1], "n_eigenvecs": int(m.value)})
+        del pinned, outs
+    except Exception as e:
+        leg["error"] = f"{type(e).__name__}: {e}"
+    return leg
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +277,11 @@ def parse_args(argv=None):
     ap.add_argument("--secondary-loci", type=int, default=1_000_000, help="loci of the count-operator leg (configs[1]: 1M)")
     ap.add_argument("--ridge-loci", type=int, default=5_000_000, help="loci of the ridge leg (configs[3]: 5M)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--no-shard-probe", action="store_true",
+                    help="skip the untimed rank-shaped legs (p_local = p/2, p/4, p/8 with a one-rank RCCL communicator)")
+    ap.add_argument("--probe-steps", type=int, default=10, help="steps per shard-probe leg")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the untimed PCIe-inclusive leg (pg_ols_kinship from pinned host memory)")
+    ap.add_argument("--e2e-loci", type=int, default=4_000_000, help="loci of the end-to-end leg (6.4 GB of pinned host memory at 200 pools)")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="seconds the self-launching parent of --gpus N > 1 waits for its rank processes before it kills them")
     return ap.parse_args(argv)
@@ -368,10 +488,14 @@ def worker(args):
     eng.profile_reset()
     fence()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(args.steps):
         m = step()[0]
+        stamps.append(time.perf_counter())   # a step ends in the host's n x n decision (a stream synchronisation), so the stamps need none
     fence()
     dt = time.perf_counter() - t0
+    step_ms = [(b - a) * 1e3 for a, b in zip(stamps[:-1], stamps[1:])]
+    step_ms[-1] += (t0 + dt - stamps[-1]) * 1e3   # the tail of the last step's kernels, drained by the fence
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -418,6 +542,13 @@ def worker(args):
             ls_ms, ls_n = eng.profile_get("sweep")
             legs[tag] = dict(m=int(lm), ms_per_step=ldt / extra * 1e3, kin_avg=lk_ms / max(lk_n, 1),
                              sw_avg=ls_ms / max(ls_n, 1), sw_n=int(ls_n))
+    # ---- rank-shaped probe and the PCIe-inclusive leg: after the timed region, 1 GPU only, bounded ----
+    shard_probe = None
+    if world == 1 and not args.no_shard_probe and args.force_m < 0:
+        shard_probe = shard_probe_legs(eng, G, Y, n, p_total, args.var_explained, args.probe_steps, torch, np)
+    end_to_end = None
+    if world == 1 and not args.no_end_to_end and args.force_m < 0:
+        end_to_end = end_to_end_leg(eng, G, Y, n, args.e2e_loci, args.var_explained, torch, np)
     # ---- BASELINE configs[1] and configs[3], driver-visible: after the timed region, bounded, 1 GPU only ----
     secondary = None
     if world == 1 and not args.no_secondary and args.force_m < 0:
@@ -478,7 +609,9 @@ def worker(args):
         rec = {
             "metric": "loci/sec ols_iter_with_kinship, 200 pools x 10M loci",
             "value": value, "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(step_ms)),
+            "ms_per_step_min": float(np.min(step_ms)), "ms_per_step_max": float(np.max(step_ms)),
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ols_iter_with_kinship {n} pools x {p_total} loci (BASELINE configs[2])",
                        "pools": n, "loci_total": p_total, "loci_per_gpu": p_local, "traits": k,
@@ -515,6 +648,10 @@ def worker(args):
             rs["achieved"] = rs["two_pass"]["achieved"]; rs["frac"] = rs["two_pass"]["frac"]
             rs["traffic"] = rs["two_pass"]["traffic"]
             rec["roofline_sweep"] = rs
+        if shard_probe:
+            rec["shard_probe"] = shard_probe
+        if end_to_end:
+            rec["end_to_end"] = end_to_end
         if secondary:
             co = secondary.get("count_operators", {})
             for op, key in (("ols_iter", "ols_iter_stream_hbm_bytes_per_launch"), ("pearson_corr", "pearson_stream_hbm_bytes_per_launch"),

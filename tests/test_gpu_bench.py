@@ -24,10 +24,24 @@ def last_json(out: str):
 
 def test_single_gpu_line():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--loci", "1000000",
-                        "--cpu-sample", "20000"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+                        "--cpu-sample", "20000", "--e2e-loci", "400000", "--probe-steps", "3", "--secondary-loci", "100000",
+                        "--ridge-loci", "100000"], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     assert NEED <= set(d) and "cpu_baseline" in d
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
+    # the rank-shaped probe: a ONE-rank RCCL communicator inside the library, slabs of p/2, p/4, p/8 with K over p_total
+    sp = d["shard_probe"]
+    assert "error" not in sp, sp
+    assert sp["comm_size"] == 1 and sp["rccl_version"] >= 20000
+    for N in (2, 4, 8):
+        leg = sp[f"n{N}"]
+        assert leg["p_local"] == 1000000 // N and leg["p_total"] == 1000000 and leg["allreduce_launches"] == 3
+        assert leg["kinship_ms"] > 0 and leg["allreduce_ms"] > 0 and leg["ms_per_step"] > leg["kinship_ms"]
+    # the PCIe-inclusive leg: pg_ols_kinship from pinned host memory
+    ee = d["end_to_end"]
+    assert "error" not in ee, ee
+    assert ee["loci"] == 400000 and ee["wall_s"] > 0 and 0 < ee["gpu_compute_share"] < 1 and ee["h2d_gbs_equiv"] > 1
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "loci/s" and d["dtype"] == "f64"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     rf = d["roofline"]

@@ -278,6 +278,85 @@ def test_full_size_properties(engine):
     assert torch.allclose(b2[sl, 0], bt, rtol=1e-9, atol=1e-12)
 
 
+FULL_SLICES = ((0, 4096), (5_000_000 - 2048, 5_000_000 + 2048), (10_000_000 - 4096, 10_000_000))   # first, middle, last slab
+
+
+def test_full_size_fused_headline_path(engine, oracle, monkeypatch):
+    """The kernels bench.py TIMES, at the size it times them (BASELINE configs[2]: 200 pools x 10M loci, m = 0 at -x 0.75):
+    k_kinship_syrk with the fused intercept-only sums + k_sweep_finish_x2, through engine.ols_with_covariate (= pg_ols_kinship_dev).
+    Slab lengths, 32-bit descriptor offsets and the spec[l*NV+v] indexing depend on the size, so: three 4096-locus slices
+    (first / middle / last slab) against the oracle at 1e-10, and every locus against the two-pass path (plain kinship +
+    k_ols_sweep_mfma, itself oracle-checked on slabs by test_full_size_properties) at rtol 1e-9.  gwas/ols.rs:291-370."""
+    from poolgen_amd import synth
+    n, p = 200, 10_000_000
+    G = synth.genotype_matrix(p, n, "cuda")
+    Y = synth.phenotypes(G[:100000], n, k=1)
+    monkeypatch.delenv("POOLGEN_TWO_PASS", raising=False)
+    engine.profile(True); engine.profile_reset()
+    m, K, beta, var, pv = engine.ols_with_covariate(G, Y, 0.75)
+    torch.cuda.synchronize()
+    fin_ms, fin_n = engine.profile_get("sweep_finish")
+    sw_ms, sw_n = engine.profile_get("sweep")
+    engine.profile(False)
+    assert m == 0 and fin_n == 1 and sw_n == 0, "the fused path (k_sweep_finish, no sweep launch) is what must have run"
+    fused = tuple(x.clone() for x in (beta, var, pv))
+    # (a) slices against the oracle (m = 0: the fits need no kinship, so a slice is self-contained)
+    for lo, hi in FULL_SLICES:
+        ref = oracle.ols_with_covariate(G[lo:hi].cpu().numpy(), Y, force_m=0)
+        cmp_fit(tuple(x[lo:hi] for x in fused), ref, f"fused slice [{lo}, {hi})")
+    # K itself: trace and row sums (size-independent), then the two-pass kinship of the same matrix entry by entry
+    engine.set_phenotypes(None)
+    S2 = engine.kinship_partial(G)
+    assert np.allclose(K, (S2 / p).cpu().numpy(), rtol=1e-12, atol=0), "fused and plain kinship passes disagree"
+    # (b) every locus against the two-pass path
+    engine.covariates_set(n, None, Y)
+    b2, v2, p2 = engine.ols_sweep(G, 1)
+    torch.cuda.synchronize()
+    sb =float(b2.abs().max()); sv = float(v2.abs().max())
+    assert torch.allclose(fused[0], b2, rtol=1e-9, atol=1e-10 * sb), "beta: fused vs two-pass"
+    assert torch.allclose(fused[1], v2, rtol=1e-9, atol=1e-10 * sv), "var: fused vs two-pass"
+    assert float((fused[2] - p2).abs().max()) <= 1e-10, "pval: fused vs two-pass"
+    assert bool(torch.isfinite(fused[0]).all())
+
+
+def test_full_size_forced_m8(engine, oracle, exact):
+    """The m >= 1 step of the driver line (roofline_sweep.m8) at 200 x 10M: non-fused kinship, n x n eigen step, k_ols_sweep_mfma
+    with [1 | C(8) | g].  The three slices against binary128 fits with the covariates the PRODUCT chose (handed to the arbiter,
+    so this pins the sweep at full size at 1e-10); the covariates themselves against an independent eigen-decomposition of the
+    product's K (subspace agreement); every locus of the one-call path against the explicit three-call path (identical kernels:
+    bit-equal)."""
+    from poolgen_amd import synth
+    from test_gpu_exact import assert_close, formula_p
+    n, p, m8 = 200, 10_000_000, 8
+    G = synth.genotype_matrix(p, n, "cuda")
+    Y = synth.phenotypes(G[:100000], n, k=1)
+    m, K, beta, var, pv = engine.ols_with_covariate(G, Y, 0.75, force_m=m8)
+    torch.cuda.synchronize()
+    assert m == m8
+    got = tuple(x.clone() for x in (beta, var, pv))
+    # the explicit path: kinship_partial -> kinship_set -> ols_sweep
+    engine.set_phenotypes(None)
+    S = engine.kinship_partial(G)
+    m2, K2, _ = engine.kinship_set(S, p, Y, 0.75, m8)
+    b2, v2, p2 = engine.ols_sweep(G, 1)
+    torch.cuda.synchronize()
+    assert m2 == m8 and np.array_equal(K, K2)
+    for a, b in zip(got, (b2, v2, p2)):
+        assert torch.equal(a, b), "one-call and three-call paths run the same kernels on the same inputs"
+    # covariates: the span of the 8 leading eigenvectors of K, from LAPACK (independent of pg_sym_eig_top)
+    w, V = np.linalg.eigh(K)
+    C = V[:, ::-1][:, :m8].copy()
+    ev_host = np.empty(n); Vp = np.empty((n, m8))
+    rc = engine._lib.pg_host_sym_eig_top(K.ctypes.data, n, m8, ev_host.ctypes.data, Vp.ctypes.data)
+    assert rc == 0
+    assert np.allclose(ev_host[:m8], w[::-1][:m8], rtol=1e-12)
+    assert np.max(np.abs(np.abs(np.sum(Vp * C, axis=0)) - 1.0)) < 1e-9, "leading eigenvectors: product vs LAPACK"
+    for lo, hi in FULL_SLICES:
+        Gh = G[lo:hi].cpu().numpy()
+        ex = exact.ols_covariate(Gh, Y, Vp, n=n)                    # binary128 cells with the product's own covariates
+        assert_close(tuple(x[lo:hi].cpu().numpy() for x in got), ex, formula_p(oracle, ex, n), f"m8 slice [{lo}, {hi})")
+
+
 @pytest.mark.parametrize("n,p,k,rows", [(24, 3000, 1, None), (60, 5000, 2, "odd"), (200, 2500, 3, "fold")])
 def test_gp_ols_matches_oracle(engine, oracle, n, p, k, rows):
     """gp::ols (gp/ols.rs:47-72): b = X^T pinv(X X^T) y on a training subset of the pools."""
