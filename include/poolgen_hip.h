@@ -71,6 +71,11 @@ int pg_profile_enable(pg_ctx *ctx, int on);
 int pg_profile_reset(pg_ctx *ctx);
 /* Synchronises, then returns total milliseconds and launch count of one kernel id. */
 int pg_profile_get(pg_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+/* Diagnostics of the last batch operator call (pg_ols_iter_batch[_dev], pg_pearson_batch[_dev], pg_chisq_batch[_dev],
+ * pg_load_plan_dev) on this context: *loci = L of that call, *listed = the loci its streaming pass could not close in place
+ * and handed to the second pass (three or more surviving alleles, or a speculated allele pair that did not hold; summed
+ * over the launch groups of a multi-trait call).  Either pointer may be NULL. */
+int pg_locus_op_stats(const pg_ctx *ctx, int64_t *loci, int64_t *listed);
 
 /* ---------------------------------------------------------------------------------------
  * ols_iter_with_kinship   == gwas::ols_with_covariate (gwas/ols.rs:278-436, numeric core
@@ -165,7 +170,13 @@ int pg_ols_kinship_sharded_dev(pg_ctx *ctx, const double *G_dev, int64_t p_local
  * ChunkyReadAnalyseWrite::read_analyse_write (base/structs_and_traits.rs:245-265,
  * base/sync.rs:864, :674); here one call handles a batch of L parsed loci.
  * counts: L x n x 6 uint32, locus-major, sync column order A,T,C,G,N,D (base/sync.rs:134); every count below 2^29
- *   (the streaming pass sums coverages as integers; a larger count fails the call with PG_ERR_INVALID).
+ *   (the streaming pass sums coverages as integers; a larger count fails the call with PG_ERR_INVALID).  The *_dev forms (and
+ *   pg_load_plan_dev) require counts_dev to be 16-BYTE ALIGNED (PG_ERR_INVALID otherwise: the streaming pass reads 16-byte
+ *   pieces; a hipMalloc'ed buffer always is, a view that starts at an odd locus of a batch with odd n is not -- copy it).
+ *   Nothing behind the L * n * 24 bytes of the batch is ever interpreted, whatever it holds.
+ *   Real counts carry reads of alleles the MAF filter drops, and the reference recomputes the frequencies on the FILTERED
+ *   counts (gwas/ols.rs:210-230 -> base/sync.rs:166-192), so those reads change every denominator: the streaming pass closes
+ *   such loci in place whenever exactly two alleles survive; pg_locus_op_stats says how many loci needed the second pass.
  * pool_sizes: host, n (normalised or not -- only ratios are used, sync.rs:266-268).
  * Outputs are struct-of-arrays, SLOT-MAJOR (a locus emits up to PG_MAX_OUT rows = slots):
  *   n_out[L]            int32  rows emitted per trait (0 = locus dropped = None)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pg_profile_enable": (_i, [_vp, _i]),
     "pg_profile_reset": (_i, [_vp]),
     "pg_profile_get": (_i, [_vp, _i, _pd, _pi64]),
+    "pg_locus_op_stats": (_i, [_vp, _pi64, _pi64]),
     "pg_set_phenotypes": (_i, [_vp, _i, _vp, _i]),
     "pg_kinship_partial_dev": (_i, [_vp, _vp, _i64, _i, _i64, _vp]),
     "pg_kinship_set": (_i, [_vp, _vp, _i64, _i, _vp, _i, _d, _i, _pi, _vp, _vp]),

@@ -56,6 +56,7 @@ struct pg_ctx {
     int64_t load_L = 0, load_total = 0, load_nunits = 0;
     int load_n = 0, load_kpm1 = 0, load_pshift = 0;
     size_t load_off_flags = 0, load_off_local = 0, load_off_blockoff = 0, load_off_poolmap = 0;
+    int64_t lo_last_L = 0, lo_last_listed = 0; // pg_locus_op_stats
     std::vector<double> st_Y;    // phenotypes of the last m = 0 covariate state (lets an identical call skip the upload)
     // small pinned host staging
     void *pin = nullptr;
@@ -80,6 +81,7 @@ int pg_fail(pg_ctx *ctx, int code, const char *fmt, ...);
 
 int pg_ws_reserve(pg_ctx *ctx, size_t bytes);
 int pg_pin_reserve(pg_ctx *ctx, size_t bytes);
+constexpr int PG_PROF_CONT = 0x100; // pg_prof_begin(kid | PG_PROF_CONT): more device time of an operation already counted
 void pg_prof_begin(pg_ctx *ctx, int kid);
 void pg_prof_end(pg_ctx *ctx);
 

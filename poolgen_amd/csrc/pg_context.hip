@@ -110,7 +110,7 @@ int pg_pin_reserve(pg_ctx *ctx, size_t bytes) {
 
 // ---- profiling: one event pair per launch, on the launch stream, resolved at query time ----
 void pg_prof_begin(pg_ctx *ctx, int kid) {
-    if (!ctx->prof) return;
+    if (!ctx->prof || kid < 0) return;
     pg_event_pair p;
     if (!ctx->ev_free.empty()) {
         p = ctx->ev_free.back();
@@ -134,8 +134,8 @@ static void prof_drain(pg_ctx *ctx) {
     for (auto &p : ctx->ev_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            ctx->prof_ms[p.kid] += ms;
-            ctx->prof_n[p.kid] += 1;
+            ctx->prof_ms[p.kid & 0xff] += ms;
+            if (!(p.kid & PG_PROF_CONT)) ctx->prof_n[p.kid & 0xff] += 1; // (a continuation bracket adds time to the launch its first bracket counted)
         }
         ctx->ev_free.push_back(p);
     }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 #endif
 constexpr int LO_WAVES = LO_WAVES_DEF;
 constexpr int LO_THREADS = 64 * LO_WAVES;
-constexpr int LO_CHP = 8;                 // pools per stage
+constexpr int LO_CHP = 8;                 // pools per stage (second pass)
 constexpr int LO_ROWB = LO_CHP * 24;      // 192 bytes of counts per locus per stage
 constexpr int LO_PITCH = LO_ROWB + 16;    // 208: odd number of 16-byte slots
 constexpr int LO_TILEB = 64 * LO_PITCH;   // bytes per wave
@@ -58,7 +58,19 @@ struct LocusParams {
     int tdf, ntcoef;     // t-test degrees of freedom (OLS: n-1, Pearson: n-2)
     double syy[MAXK];    // OLS: sum of centred y^2
     double sy[MAXK];     // OLS: sum of centred y (~0)
+    // PEARSON: sum y, sum y^2 (fma chain) and the number of pools, y shifted by its first value, in pool order -- what the running
+    // sums over the complete pairs come to when every pair is complete; y_complete = 0 (a NaN phenotype) lists every locus
+    double py[MAXK], pyy[MAXK], pn[MAXK];
+    int y_complete;
+    // the streaming pass decides q < maf on a cheaper evaluation of q (see k_locus_stream); |q - threshold| <= qband sends the
+    // locus through the exact evaluation
+    double qband;
 };
+constexpr int LO_NB = 5;   // groups of the second pass' list: one per number of surviving alleles, 2 .. 6
+// words of the second pass' counter block: [0, LO_NB) loci per group | complaint flag | length of the list | (pad) | [SC_CURSOR, +LO_NB) the
+// sort's cursors
+constexpr int SC_COMPLAINT = LO_NB, SC_LIST = LO_NB + 1, SC_CURSOR = LO_NB + 3, SC_WORDS = 2 * LO_NB + 3;
+constexpr int LO_GROUP_FROM = 1 << 17; // lists from this length on are grouped by the number of survivors (two more launches)
 
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
@@ -642,26 +654,43 @@ constexpr int ST_PPT = 16;          // pools per ring turn of 3 lines
 constexpr int ST_STAGE = 8192;      // LDS bytes per wave for the results of a unit
 
 template <int OP, int NJ, int K>
-struct Acc { // running sums of one locus, every candidate allele in play; everything accumulated sequentially in pool order
-    double q[NJ], cs[NJ];
-    double dd[NJ];        // OLS, CHISQ: sum f^2
-    double xy[NJ * K];    // OLS: sum f y
-    // PEARSON: sums of x = z - z(first complete pool), z = sum_j j f_j, over the complete pairs (see the kernel's header)
-    double px[K], pxx[K], pxy[K], py[K], pyy[K], pn[K], shz;
-    uint32_t mincov, orm; // smallest coverage of a pool; OR of every count seen
-    int n_missing;
+struct Acc { // running sums of one locus; everything accumulated sequentially in pool order
+    double q[NJ];         // the filter's pool-size weighted frequencies, every candidate allele in play (sync.rs:258-271), see pool()
+    double cs[NJ], dd[NJ]; // LOAD: sum f with every candidate in play -- the reference's when the dropped alleles have no reads (dd: unused)
+    // The SPECULATED PAIR (round 4).  The reference recomputes the frequencies on the FILTERED counts (gwas/ols.rs:210-230 ->
+    // sync.rs:166-192): one stray read of an allele the filter drops changes every denominator of the locus, so sums taken over all
+    // candidates are useless for real data.  Instead the sums of a biallelic fit are taken with the denominator c_a + c_b of a pair
+    // chosen on the fly: a = the leading allele of the first covered pool, b = the first OTHER allele that shows a read (the largest
+    // of that pool, lowest slot on ties).  Until b shows up, every covered pool has f_a = 1, f_b = 0 whoever b turns out to be, so the
+    // choice can wait for the first pool that needs it and nothing is ever redone.  If the filter's survivors are exactly {a, b} the
+    // sums ARE the reference's, whatever reads the dropped alleles carry; otherwise (three or more survivors, or an error allele that
+    // showed before the real one) the locus is listed for the second pass.
+    double cs2[2], dd2[2];   // sum f, sum f^2 of a and b over the pair's own denominators
+    double xy2[2 * K];       // OLS: sum f y
+    // PEARSON: sums of x = f_a - f_a(first complete pool) over the complete pairs; the allele reported is the LOWER slot of the pair,
+    // and corr(f_b, y) = -corr(f_a, y) because f_a + f_b = 1 in every covered pool
+    // (sum y, sum y^2 and the number of pairs are the same for every locus whose pools are all covered: LocusParams carries them,
+    // formed on the host in this order; a locus with an uncovered pool, or phenotypes with NaN, goes to the second pass)
+    double px[K], pxx[K], pxy[K], shx;
+    uint32_t mincov, orm;    // smallest coverage of a pool; OR of every count seen
+    int n_missing, n_missing2; // pools uncovered over every candidate / over the pair
+    int pa, pb;              // slots of a and b, -1 until chosen
     bool shset;
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { q[j] = 0.0; cs[j] = 0.0; dd[j] = 0.0; }
 #pragma unroll
-        for (int j = 0; j < NJ * K; ++j) xy[j] = 0.0;
+        for (int j = 0; j < 2; ++j) { cs2[j] = 0.0; dd2[j] = 0.0; }
 #pragma unroll
-        for (int j = 0; j < K; ++j) { px[j] = 0.0; pxx[j] = 0.0; pxy[j] = 0.0; py[j] = 0.0; pyy[j] = 0.0; pn[j] = 0.0; }
-        shz = 0.0;
+        for (int j = 0; j < 2 * K; ++j) xy2[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { px[j] = 0.0; pxx[j] = 0.0; pxy[j] = 0.0; }
+        shx = 0.0;
         mincov = 0xffffffffu;
         orm = 0u;
         n_missing = 0;
+        n_missing2 = 0;
+        pa = -1; pb = -1;
         shset = false;
     }
 };
@@ -750,75 +779,71 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
     // the locus whose last pool has passed, reduced at that moment to what its closing needs (the heavy part runs once per ring
     // turn, after the turn's pools): filter decisions in `fh`, the selected sums in `fv`
     //   OLS     fv = cs, sum f^2, sum f y_t of the design column (the minor allele of a biallelic locus)
-    //   PEARSON fv = cs, sum x, sum x^2, sum x y of the first surviving allele, then sum y, sum y^2, pairs
-    //   CHISQ   fv = cs[NJ], sum f^2 / rowsum [NJ], total        LOAD  fv = cs[NJ]
-    constexpr int NFV = (OP == OP_OLS) ? 2 + K : (OP == OP_PEARSON) ? 7 : (OP == OP_CHISQ) ? 2 * NJ + 1 : NJ;
+    //   PEARSON fv = cs of the reported allele, sum x, sum x^2, sum x y of allele a
+    //   CHISQ   fv = cs2[2], dd2[2], total                       LOAD  fv = cs[NJ], cs2[2]
+    constexpr int NFV = (OP == OP_OLS) ? 2 + K : (OP == OP_PEARSON) ? 4 : (OP == OP_CHISQ) ? 5 : NJ + 2;
     double fv[NFV];
-    int fh = 0;          // bit 0 alive | 1..6 surviving alleles | 7 again | 8..10 nk | 11 poisoned | 12..14 id of the closed allele | 15.. kept mask by slot
+    int fh = 0;          // bit 0 alive but for the survivor count | 7 band (q to be recomputed) | 11 a pool uncovered over the pair | 12..14 id of the closed allele | 15..20 kept mask by slot | 21 the lower slot of the pair is b | 22..24 slot of a | 25..27 slot of b (7 = none)
     bool fin_pending = false;
     int fin_i = 0;       // which of the lane's M loci it is
     uint32_t orm_unit = 0; // OR of every count this lane has seen
+    int64_t cur_u = wid;   // the unit being computed
     int pi = 0, iloc = 0;
     uint2_t cy0 = {0u, 0u}, cy1 = {0u, 0u}; // the last 16 bytes of the previous line
 
-    // filter decisions of the locus in A (sync.rs:223-300) and the sums its closing will want
+    // the locus in A has seen its last pool: its filter decisions as far as they can be taken here (sync.rs:223-300) and the sums its
+    // closing will want; finish() completes the decision (number of survivors, the exact q of a band locus, does the pair hold?)
     auto boundary = [&]() {
-        int nk = 0, keepmask = 0, slotmask = 0;
-        bool dropped_with_reads = false;
+        int slotmask = 0;
+        bool band = false;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool kpj = !((A.q[j] < P.maf) | (A.q[j] > (1.00 - P.maf)));
-            nk += kpj ? 1 : 0;
-            keepmask |= kpj ? (2 << aj(j)) : 0;
             slotmask |= kpj ? (1 << j) : 0;
-            // "has reads" = a positive column sum of the frequencies: a count > 0 makes its pool covered and its frequency > 0, and sums of
-            // non-negative terms do not cancel
-            dropped_with_reads = dropped_with_reads || (!kpj && A.cs[j] != 0.0);
+            band = band || fabs(A.q[j] - P.maf) <= P.qband || fabs(A.q[j] - (1.00 - P.maf)) <= P.qband;
         }
-        bool alive = !((double)A.mincov < P.min_cov);                                // sync.rs:227
-        alive = alive && nk >= 2;                                                    // sync.rs:284
-        alive = alive && A.n_missing != n;                                           // sync.rs:293
-        alive = alive && !(((double)A.n_missing / (double)n) > P.max_miss);          // sync.rs:297
-        const bool again = alive && dropped_with_reads;
-        orm_unit |= A.orm;
+        bool alive0 = !((double)A.mincov < P.min_cov);                                 // sync.rs:227
+        alive0 = alive0 && A.n_missing != n;                                           // sync.rs:293
+        alive0 = alive0 && !(((double)A.n_missing / (double)n) > P.max_miss);          // sync.rs:297
+        // (the counts past the end of the batch read as zeros or as whatever follows the buffer inside its last 16 bytes: the loci they
+        // would make up do not exist and must not raise the complaint flag)
+        orm_unit |= (cur_u * lpu + (int64_t)lane * M + iloc < L) ? A.orm : 0u;
+        const int lo = (A.pa < A.pb) ? 0 : 1;            // which of (a, b) sits in the lower slot
         int idc = 0;
         if constexpr (OP == OP_OLS || OP == OP_PEARSON) {
-            // the two survivors of a biallelic locus: slots sa < sb
-            int sa = 0, sb = 0, seen = 0;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const bool kpj = (slotmask >> j) & 1;
-                sa = (kpj && seen == 0) ? j : sa;
-                sb = (kpj && seen == 1) ? j : sb;
-                seen += kpj ? 1 : 0;
-            }
-            int sc = sa; // PEARSON: all surviving alleles but the LAST, unsorted (gwas/correlation_test.rs:94-126): the first of two
+            int sc = lo; // PEARSON: all surviving alleles but the LAST, unsorted (gwas/correlation_test.rs:94-126): the lower slot of two
             if (OP == OP_OLS) {
                 // stable sort by decreasing column sum (sync.rs:477-506): rank 0 = the major allele, dropped (ols.rs:227-230)
-                const double ca = pickn<NJ>(A.cs, sa), cb = pickn<NJ>(A.cs, sb);
-                sc = (cb > ca) ? sa : sb; // the design column: the minor allele
+                const double ca = lo ? A.cs2[1] : A.cs2[0], cb = lo ? A.cs2[0] : A.cs2[1];
+                sc = (cb > ca) ? lo : 1 - lo; // the design column: the minor allele (ties: the lower slot stays first = major)
             }
+            const int scslot = sc ? A.pb : A.pa;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) idc = (sc == j) ? aj(j) : idc;
-            fv[0] = pickn<NJ>(A.cs, sc);
+            for (int j = 0; j < NJ; ++j) idc = (scslot == j) ? aj(j) : idc;
+            fv[0] = sc ? A.cs2[1] : A.cs2[0];
             if constexpr (OP == OP_OLS) {
-                fv[1] = pickn<NJ>(A.dd, sc);
+                fv[1] = sc ? A.dd2[1] : A.dd2[0];
 #pragma unroll
-                for (int t = 0; t < K; ++t) fv[2 + t] = pick_trait<NJ, K>(A.xy, sc, t);
+                for (int t = 0; t < K; ++t) fv[2 + t] = sc ? A.xy2[K + t] : A.xy2[t];
             } else {
                 fv[1] = A.px[0]; fv[2] = A.pxx[0]; fv[3] = A.pxy[0];
-                fv[4] = A.py[0]; fv[5] = A.pyy[0]; fv[6] = A.pn[0];
             }
         } else if constexpr (OP == OP_CHISQ) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { fv[j] = A.cs[j]; fv[NJ + j] = A.dd[j]; }
-            fv[2 * NJ] = (double)(n - A.n_missing);
+            // chi2 = total * (sum_j A_j / cs_j - 1) with A_j = sum_i f_ij^2 / rowsum_i and total = sum_i rowsum_i (tables/chisq_test.rs:15-31
+            // regrouped).  The row sum of a covered pool's frequencies is 1 to an ulp, so A_j = sum f^2 and total = the covered pools,
+            // within a few ulp of the reference's value (statistics are compared at 1e-10).  Closed from the pair's sums; three or more
+            // survivors go to the second pass
+            fv[0] = A.cs2[0]; fv[1] = A.cs2[1]; fv[2] = A.dd2[0]; fv[3] = A.dd2[1];
+            fv[4] = (double)(n - A.n_missing2);
         } else {
+            // LOAD needs column sums only to order the columns (--keep-p-minus-1): every candidate's when nothing dropped has reads,
+            // the pair's for a biallelic locus with stray reads (finish() knows which)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fv[j] = A.cs[j];
+            fv[NJ] = A.cs2[0]; fv[NJ + 1] = A.cs2[1];
         }
-        fh = (alive ? FLAG_ALIVE : 0) | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT) | ((A.n_missing > 0) ? (1 << 11) : 0) |
-             (idc << 12) | (slotmask << 15);
+        fh = (alive0 ? FLAG_ALIVE : 0) | (band ? (1 << 7) : 0) | ((A.n_missing2 > 0) ? (1 << 11) : 0) | (idc << 12) | (slotmask << 15) |
+             ((lo != 0) ? (1 << 21) : 0) | ((A.pa & 7) << 22) | ((A.pb & 7) << 25);
     };
 
     // one pool of this lane's locus
@@ -842,66 +867,130 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
         uint32_t ci[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) ci[j] = c0[aj(j)];
-        // coverage of the pool over the alleles in play (sync.rs:217-222 / :170-175), in integers: the reference adds the counts as
-        // f64, exact below 2^53, so any order and any exact arithmetic gives its value -- as long as the 32-bit sum does not wrap,
-        // which `orm` (every count < 2^29, checked at the end of the unit) guarantees
-        uint32_t rsi = ci[0];
-        uint32_t orv = ci[0];
+        // Which slots can hold reads in this pool is a WAVE-UNIFORM question (one scalar branch): on clean biallelic data only A and T
+        // do, and the arithmetic of the other slots would add exact zeros to every sum -- skipped (NAC = 2: a third of the work);
+        // one stray read in any of the 64 loci of the wave takes the pool through the general code (NAC = NJ).  Same sums either way.
+        auto arith = [&](auto nacc) {
+            constexpr int NAC = decltype(nacc)::value;
+            // coverage of the pool over the alleles in play (sync.rs:217-222 / :170-175), in integers: the reference adds the counts as
+            // f64, exact below 2^53, so any order and any exact arithmetic gives its value -- as long as the 32-bit sum does not wrap,
+            // which `orm` (every count < 2^29, checked at the end of the unit) guarantees
+            uint32_t rsi = ci[0];
+            uint32_t orv = ci[0];
 #pragma unroll
-        for (int j = 1; j < NJ; ++j) { rsi += ci[j]; orv |= ci[j]; }
-        A.orm |= orv;
-        const bool rowok = rsi != 0u;
-        A.mincov = rsi < A.mincov ? rsi : A.mincov;          // sync.rs:223-227
-        A.n_missing += rowok ? 0 : 1;
-        // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0, divided by 1) and the pool
-        // is counted in n_missing, which poisons / skips what NaN would
-        const double rsd = (double)(rsi > 1u ? rsi : 1u);
-        const double rinv = recip_for_div(rsd);
-        double f[NJ];
+            for (int j = 1; j < NAC; ++j) { rsi += ci[j]; orv |= ci[j]; }
+            A.orm |= orv;
+            const bool rowok = rsi != 0u;
+            A.mincov = rsi < A.mincov ? rsi : A.mincov;          // sync.rs:223-227
+            A.n_missing += rowok ? 0 : 1;
+            // an uncovered pool has NaN frequencies in the reference; here they are 0 (all counts are 0, divided by 1) and the pool
+            // is counted in n_missing, which poisons / skips what NaN would
+            const double rsd = (double)(rsi > 1u ? rsi : 1u);
+            const double rinv = recip_for_div(rsd);
+            // The filter's q_j = sum_i fl(c_ij / rs_i) * w_i (sync.rs:258-271: sequential, multiply then add) decides which alleles
+            // survive and must be decided as the reference decides it -- but its VALUE is needed nowhere else.  So the pass accumulates
+            // q~_j = fma(c_ij, fl(w_i * 1/rs_i), q~_j): one operation per allele and pool instead of five, within (n + 8) ulp of q_j
+            // (every term is positive).  A locus with some |q~_j - threshold| <= qband (P.qband = 8 (n + 16) eps: never, on real data)
+            // has its q recomputed literally in finish(); everybody else's decision is provably the reference's.
+            double f[NAC];
+            const double wi = tr.w;
+#ifdef LS_EXP_QEXACT // (timing experiment: the literal evaluation)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) f[j] = div_by((double)ci[j], rsd, rinv);
-        const double wi = tr.w;
-        // q += f * w_i with separate multiply and add; NaN frequencies contribute 0 (sync.rs:258-271)
+            for (int j = 0; j < NAC; ++j) { f[j] = div_by((double)ci[j], rsd, rinv); A.q[j] = A.q[j] + f[j] * wi; }
+#else
+            {
+                const double wr = wi * rinv;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) A.q[j] = A.q[j] + f[j] * wi;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) A.cs[j] = A.cs[j] + f[j];
-        if (OP == OP_OLS) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) A.dd[j] = fma(f[j], f[j], A.dd[j]);
-#pragma unroll
-            for (int tt = 0; tt < K; ++tt) {
-                const double y = tr.y[tt];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) A.xy[j * K + tt] = fma(f[j], y, A.xy[j * K + tt]);
+                for (int j = 0; j < NAC; ++j) A.q[j] = fma((double)ci[j], wr, A.q[j]);
             }
-        } else if (OP == OP_PEARSON) {
-            // ONE regressor for every allele: z = sum_j j f_j.  This pass only closes loci with two surviving alleles a < b whose
-            // other alleles have no reads at all: there f_a + f_b = 1 in every covered pool, z = b - (b - a) f_a, and the
-            // correlation of f_a with y is minus that of z (correlation_test.rs:36-52 is invariant under x -> c0 + c1 x).
-            double z = f[1];
+            if constexpr (OP == OP_LOAD || NAC == 2) {
 #pragma unroll
-            for (int j = 2; j < NJ; ++j) z = fma((double)j, f[j], z);
-            if (rowok && !A.shset) { A.shz = z; A.shset = true; } // shift by the first covered pool's value: small numbers in the sums
-#pragma unroll
-            for (int tt = 0; tt < K; ++tt) {
-                const double y = tr.y[tt];             // shifted by its first valid value on the host
-                const bool ok = rowok && !isnan(y);    // pairwise complete (correlation_test.rs:22-26)
-                const double ye = ok ? y : 0.0;        // an incomplete pair contributes exact zeros instead of being skipped
-                const double x = ok ? z - A.shz : 0.0;
-                A.py[tt] = A.py[tt] + ye;
-                A.pyy[tt] = fma(ye, ye, A.pyy[tt]);
-                A.pn[tt] = A.pn[tt] + (ok ? 1.0 : 0.0);
-                A.px[tt] = A.px[tt] + x;
-                A.pxx[tt] = fma(x, x, A.pxx[tt]);
-                A.pxy[tt] = fma(x, ye, A.pxy[tt]);
+                for (int j = 0; j < NAC; ++j) f[j] = div_by((double)ci[j], rsd, rinv);
             }
-        } else if (OP == OP_CHISQ) {
-            // chi2 = total * (sum_j A_j / cs_j - 1) with A_j = sum_i f_ij^2 / rowsum_i and total = sum_i rowsum_i (tables/chisq_test.rs:15-31
-            // regrouped).  The row sum of a covered pool's frequencies is 1 to an ulp, so A_j = sum f^2 and total = the covered pools,
-            // within a few ulp of the reference's value (statistics are compared at 1e-10)
+#endif
+            if constexpr (OP == OP_LOAD) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) A.dd[j] = fma(f[j], f[j], A.dd[j]);
+                for (int j = 0; j < NAC; ++j) A.cs[j] = A.cs[j] + f[j];
+            }
+            // ---- the speculated pair (see Acc) ------------------------------------------------------------------------------------
+            if (A.pb < 0) { // not settled yet: the first pools of a locus, longer where the minor allele is rare
+                if (A.pa < 0 && rowok) { // the first covered pool: its leading allele (lowest slot on ties)
+                    uint32_t best = ci[0];
+                    int bj = 0;
+#pragma unroll
+                    for (int j = 1; j < NAC; ++j) { const bool g = ci[j] > best; best = g ? ci[j] : best; bj = g ? j : bj; }
+                    A.pa = bj;
+                }
+                if (A.pa >= 0) { // the first OTHER allele that shows a read: the largest of this pool, lowest slot on ties
+                    uint32_t best = 0u;
+                    int bj = -1;
+#pragma unroll
+                    for (int j = 0; j < NAC; ++j) {
+                        const uint32_t v = (j == A.pa) ? 0u : ci[j];
+                        const bool g = v > best;
+                        best = g ? v : best;
+                        bj = g ? j : bj;
+                    }
+                    A.pb = bj;
+                }
+            }
+            uint32_t ca = 0u, cb = 0u;
+#pragma unroll
+            for (int j = 0; j < NAC; ++j) { ca = (A.pa == j) ? ci[j] : ca; cb = (A.pb == j) ? ci[j] : cb; }
+            const uint32_t rs2 = ca + cb;
+            const bool rowok2 = rs2 != 0u;
+            A.n_missing2 += rowok2 ? 0 : 1;
+            // frequencies over the pair's own coverage: what to_frequencies gives on the FILTERED counts (sync.rs:166-192) if the pair survives
+            double fa, fb;
+            if (NAC == 2 && __all(rs2 == rsi)) {
+                // every locus of the wave has its pair in {A, T} and nothing else here: the pair's coverage IS the pool's, and its
+                // frequencies are the quotients already formed (same operands, same arithmetic: the same bits)
+                fa = (A.pa == 0) ? f[0] : ((A.pa == 1) ? f[1] : 0.0);
+                fb = (A.pb == 0) ? f[0] : ((A.pb == 1) ? f[1] : 0.0);
+            } else {
+                const double rsd2 = (double)(rs2 > 1u ? rs2 : 1u);
+                const double rinv2 = recip_for_div(rsd2);
+                fa = div_by((double)ca, rsd2, rinv2);
+                fb = div_by((double)cb, rsd2, rinv2);
+            }
+            A.cs2[0] = A.cs2[0] + fa;
+            A.cs2[1] = A.cs2[1] + fb;
+            if constexpr (OP == OP_OLS || OP == OP_CHISQ) {
+                A.dd2[0] = fma(fa, fa, A.dd2[0]);
+                A.dd2[1] = fma(fb, fb, A.dd2[1]);
+            }
+            if constexpr (OP == OP_OLS) {
+#pragma unroll
+                for (int tt = 0; tt < K; ++tt) {
+                    const double y = tr.y[tt];
+                    A.xy2[tt] = fma(fa, y, A.xy2[tt]);
+                    A.xy2[K + tt] = fma(fb, y, A.xy2[K + tt]);
+                }
+            } else if constexpr (OP == OP_PEARSON) {
+                if (rowok2 && !A.shset) { A.shx = fa; A.shset = true; } // shift by the first covered pool's value: small numbers in the sums
+#pragma unroll
+                for (int tt = 0; tt < K; ++tt) {
+                    // (every pair is complete where this locus is closed in place: pools all covered, no NaN phenotype -- boundary())
+                    const double y = tr.y[tt];             // shifted by its first valid value on the host
+                    const double x = fa - A.shx;
+                    A.px[tt] = A.px[tt] + x;
+                    A.pxx[tt] = fma(x, x, A.pxx[tt]);
+                    A.pxy[tt] = fma(x, y, A.pxy[tt]);
+                }
+            }
+        };
+        {
+#ifdef LS_EXP_NOFASTPATH
+            arith(std::integral_constant<int, NJ>{});
+#else
+            // (tested for every pool: skipping the test for a while after a pool that needed the general code was measured -- nothing on
+            // error-bearing counts, where nearly every pool has a stray read in one of the wave's 64 loci, and -3 % on clean ones)
+            uint32_t others = 0u;
+#pragma unroll
+            for (int j = 2; j < NJ; ++j) others |= ci[j];
+            if (__any(others != 0u)) arith(std::integral_constant<int, NJ>{});
+            else arith(std::integral_constant<int, 2>{});
+#endif
         }
         // the locus' last pool: decide, keep what the closing needs (it runs at the end of the turn) and start the next locus
         if constexpr (CHK) {
@@ -961,16 +1050,62 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
     auto finish = [&](int64_t unit) {
         const int64_t l = unit * lpu + (int64_t)lane * M + fin_i;
         const bool valid = l < L;
-        const int nk = (fh >> H_NK_SHIFT) & 7;
-        const int keepmask = fh & 0x7e;
-        const int slotmask = (fh >> 15) & 63;
-        const bool alive = (fh & FLAG_ALIVE) != 0 && valid;
-        const bool again = alive && (fh & FLAG_SECOND) != 0;
-        const double pz = (fh & (1 << 11)) ? NAN : 0.0; // x + NaN = NaN: an uncovered pool makes the reference's plain sums NaN
-        // three or more surviving alleles need the cross products (ols_iter) or several outputs (pearson_corr): second pass
-        const bool deferred = alive && (again || ((OP == OP_OLS || OP == OP_PEARSON) && nk >= 3));
+        int slotmask = (fh >> 15) & 63;
+        // ---- a locus inside the band: its q as the reference forms it (sync.rs:258-271), from its counts in memory -------------------
+        if (__any((fh & (1 << 7)) != 0 && valid)) {
+            if ((fh & (1 << 7)) != 0 && valid) {
+                double qe[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) qe[j] = 0.0;
+                const uint2_t *rp = reinterpret_cast<const uint2_t *>(counts + (size_t)l * (size_t)n * 6);
+                for (int i = 0; i < n; ++i) {
+                    const uint2_t a0 = rp[3 * i], a1 = rp[3 * i + 1], a2 = rp[3 * i + 2];
+                    const uint32_t c6[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+                    uint32_t rs = 0u;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) rs += c6[aj(j)];
+                    const double rsd = (double)(rs > 1u ? rs : 1u);
+                    const double ri = recip_for_div(rsd);
+                    const double wi = tab[i * TW];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) qe[j] = qe[j] + div_by((double)c6[aj(j)], rsd, ri) * wi;
+                }
+                slotmask = 0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) slotmask |= !((qe[j] < P.maf) | (qe[j] > (1.00 - P.maf))) ? (1 << j) : 0;
+            }
+        }
+        int nk = 0, keepmask = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool kpj = (slotmask >> j) & 1;
+            nk += kpj ? 1 : 0;
+            keepmask |= kpj ? (2 << aj(j)) : 0;
+        }
+        const bool alive = (fh & FLAG_ALIVE) != 0 && nk >= 2 && valid;                // sync.rs:284 joins the tests of boundary()
+        const int pa = (fh >> 22) & 7, pb = (fh >> 25) & 7;
+        // did the speculation hold?  the survivors are exactly the pair the sums were taken over
+        const bool pair_ok = nk == 2 && pb != 7 && slotmask == ((1 << pa) | (1 << pb));
+        const bool pair_poisoned = (fh & (1 << 11)) != 0; // a pool uncovered over the SURVIVORS has NaN frequencies (sync.rs:176-183)
+        bool again; // second pass: three or more survivors (cross products, several outputs) or a pair that did not hold
+        double pz = pair_poisoned ? NAN : 0.0; // x + NaN = NaN: an uncovered pool makes the reference's plain sums NaN
+        bool load_clean = true;
+        if constexpr (OP == OP_OLS || OP == OP_CHISQ) again = alive && !pair_ok;
+        else if constexpr (OP == OP_PEARSON) // an incomplete pair (uncovered pool, NaN phenotype) changes sum y, sum y^2 and the pair count
+            again = alive && (!pair_ok || pair_poisoned || P.y_complete == 0);
+        else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) // "has reads" = a positive column sum of frequencies (non-negative terms do not cancel)
+                load_clean = load_clean && (((slotmask >> j) & 1) || fv[j < NFV ? j : 0] == 0.0);
+            again = alive && P.sort_desc != 0 && !load_clean && !pair_ok;
+        }
+        const bool deferred = again;
         if (OP == OP_LOAD) {
             // the loader wants the header of every locus: surviving alleles in the order its columns take (sync.rs:1033-1037)
+            double key[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                key[j] = load_clean ? fv[j < NFV ? j : 0] : (j == pa ? fv[NJ < NFV ? NJ : 0] : (j == pb ? fv[(NJ + 1) < NFV ? NJ + 1 : 0] : 0.0));
             int ordbits = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -978,7 +1113,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) {
                     if (i == j) continue;
-                    const bool before = P.sort_desc ? (fv[i < NFV ? i : 0] > fv[j < NFV ? j : 0] || (fv[i < NFV ? i : 0] == fv[j < NFV ? j : 0] && i < j)) : i < j;
+                    const bool before = P.sort_desc ? (key[i] > key[j] || (key[i] == key[j] && i < j)) : i < j;
                     r += (((slotmask >> i) & 1) && before) ? 1 : 0;
                 }
                 ordbits |= ((slotmask >> j) & 1) ? (aj(j) << (3 * r)) : 0;
@@ -987,18 +1122,17 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             if (staged & 1) *reinterpret_cast<int32_t *>(stage + (size_t)(lane * M + fin_i) * 4) = hdr;
             else if (valid) rec_flags[l] = hdr;
         } else if (deferred) {
-            rec_flags[l] = FLAG_ALIVE | keepmask | (again ? FLAG_SECOND : 0) | (nk << H_NK_SHIFT); // the second pass wants the surviving alleles
+            rec_flags[l] = FLAG_ALIVE | keepmask | FLAG_SECOND | (nk << H_NK_SHIFT); // the second pass wants the surviving alleles
         }
-        // the dense list of the second pass: one returning atomic per unit that has any (its wait drains the line in flight: rare)
+        // the list of the second pass: one returning atomic per unit that has any (its wait drains the line in flight)
         {
-            const bool listed = (OP == OP_LOAD) ? again : deferred;
-            const unsigned long long bal = __ballot(listed);
+            const unsigned long long bal = __ballot(deferred);
             if (bal) {
                 unsigned long long basev = 0;
-                if (lane == 0) basev = atomicAdd(second_count, (unsigned long long)__popcll(bal));
+                if (lane == 0) basev = atomicAdd(second_count + SC_LIST, (unsigned long long)__popcll(bal));
                 basev = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(basev >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)basev);
-                if (listed) second[basev + __popcll(bal & ((1ull << lane) - 1ull))] = l;
+                if (deferred) second[basev + __popcll(bal & ((1ull << lane) - 1ull))] = l;
             }
         }
         if (OP == OP_LOAD) return;
@@ -1023,10 +1157,8 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             }
             idsp |= nk << 16;
             if (__any(simple)) {
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc = ((slotmask >> j) & 1) ? acc + fv[(NJ + j) < NFV ? NJ + j : 0] / fv[j < NFV ? j : 0] : acc;
-                const double chi2 = fv[(2 * NJ) < NFV ? 2 * NJ : 0] * (acc - 1.0) + pz; // tables/chisq_test.rs:15-31 regrouped
+                const double acc = fv[2 < NFV ? 2 : 0] / fv[0] + fv[3 < NFV ? 3 : 0] / fv[1 < NFV ? 1 : 0];
+                const double chi2 = fv[4 < NFV ? 4 : 0] * (acc - 1.0) + pz; // tables/chisq_test.rs:15-31 regrouped
                 const double df = (double)(n * nk) - 1.0;
                 const double p = pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)); // :33-35
                 if (simple) { st[0] = chi2; pv[0] = p; nout = nk; }
@@ -1049,13 +1181,13 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
                 }
             } else { // OP_PEARSON
                 double rr, pp;
-                pearson_close(fv[1 < NFV ? 1 : 0], fv[2 < NFV ? 2 : 0], fv[3 < NFV ? 3 : 0], fv[4 < NFV ? 4 : 0], fv[5 < NFV ? 5 : 0],
-                              fv[6 < NFV ? 6 : 0], n, P, tcoef, rr, pp);
+                pearson_close(fv[1 < NFV ? 1 : 0], fv[2 < NFV ? 2 : 0], fv[3 < NFV ? 3 : 0], P.py[0], P.pyy[0], P.pn[0], n, P, tcoef, rr, pp);
                 if (simple) {
                     nout = 1;
                     idsp = (fh >> 12) & 7;
                     mf = (fv[0] + pz) / (double)n; // x.mean(), :119: the plain mean is NaN with an uncovered pool
-                    st[0] = -rr; pv[0] = pp;       // the sums are those of z = b - (b - a) f_a: the correlation changes sign
+                    st[0] = (fh & (1 << 21)) ? -rr : rr; // the sums are those of f_a; reported is the lower slot: if that is b, f_b = 1 - f_a changes the sign
+                    pv[0] = pp;
                 }
             }
         }
@@ -1184,7 +1316,6 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
         __builtin_amdgcn_wave_barrier();
     };
 
-    int64_t cur_u = wid;
     if (n < ST_PPT) {
         // fewer pools than a ring turn holds: several loci could end inside one turn.  Such rows are at most 360 bytes; every lane
         // reads its own stream straight from memory, pool by pool (same sums, same closing, no staging of lines)
@@ -1207,7 +1338,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
             }
             if (staged & 1) flush_unit(cur_u);
             if (__any((orm_unit >> 29) != 0u)) {
-                if (lane == 0) atomicOr(second_count + 1, 1ull);
+                if (lane == 0) atomicOr(second_count + SC_COMPLAINT, 1ull);
                 orm_unit = 0;
             }
         }
@@ -1278,7 +1409,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_BLOCKS_DEF) void k_locus_stream(
         if (staged & 1) flush_unit(cur_u);
 #endif
         if (__any((orm_unit >> 29) != 0u)) { // a count the 32-bit coverage sums cannot take: the host reports it
-            if (lane == 0) atomicOr(second_count + 1, 1ull);
+            if (lane == 0) atomicOr(second_count + SC_COMPLAINT, 1ull);
             orm_unit = 0;
         }
         cur_u += wstride;
@@ -1334,7 +1465,7 @@ __device__ __forceinline__ void ols_close(const double *rec, size_t rb, int k, i
     }
 }
 
-template <int OP>
+template <int OP, int PNFIX = 0>
 __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_flags,
                                             const double *rec, const double *__restrict__ tcoef,
                                             int32_t *__restrict__ n_out, int32_t *__restrict__ ids_out,
@@ -1404,85 +1535,282 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
         }
         static_for<2, NA + 1>([&](auto pc) {
             constexpr int PNc = decltype(pc)::value;
-            if (pn == PNc)
-                ols_close<PNc>(rec, rb, k, ordbits, alive, tcoef, n_out, ids_out, mf_out, stat_out, pv_out, l, P);
+            if constexpr (PNFIX == 0 || PNFIX == PNc) { // (a tile of the second pass holds loci with ONE number of survivors)
+                if (pn == PNc)
+                    ols_close<PNc>(rec, rb, k, ordbits, alive, tcoef, n_out, ids_out, mf_out, stat_out, pv_out, l, P);
+            }
         });
     } while (false);
 }
 
 // ---- second pass: only the loci the first pass listed ----------------------------------------------
-// One lane per listed locus (rows gathered through the list), sums over the SURVIVING alleles only.
-template <int OP, int PB, int K>
-__global__ __launch_bounds__(LO_THREADS, 2) void k_locus_second(
+// One lane per listed locus (rows gathered through the list).  The survivors are known now (flags), so the sums are taken over
+// the frequencies of the FILTERED counts, as the reference does (gwas/ols.rs:210-230 -> sync.rs:166-192).  Round 4:
+//  * the surviving columns are COMPACTED (NS running columns instead of all six: 3 / 6 / 10 / 15 cross products for 2 / 3 / 4 / 5
+//    survivors instead of 21) and the code is specialised on the largest survivor count of the wave;
+//  * rows still arrive through a wave-private LDS tile in stages of eight pools (48 lanes fetch 4 rows x 192 contiguous bytes per
+//    instruction: a lane reading its own row 8 bytes at a time makes every load instruction touch 64 cache lines and the pass ran
+//    at 1 TB/s, measured), but the NEXT stage's loads are in flight while a stage is summed, and the eight pools of a stage are
+//    straight-line code (no branch inside: with one, the wait-count pass waits for every load at every pool).
+template <int OP, int NS, int K, int PB>
+__device__ __forceinline__ void second_tile(const uint32_t *__restrict__ counts, const double *__restrict__ Y, int32_t *rec_flags,
+                                            double *rec, char *tile, const int64_t *lidx, const int64_t l, const int mask,
+                                            const bool valid, const LocusParams &P, const int lane) {
+    const int n = P.n;
+    // the r-th surviving sync column (ascending); columns r >= nk read as zero counts and stay out of every result
+    int col[NS];
+    bool kp[NS];
+    {
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) col[r] = 7;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bool k = (mask & (2 << j)) != 0;
+#pragma unroll
+            for (int r = 0; r < NS; ++r) col[r] = (k && cnt == r) ? j : col[r];
+            cnt += k ? 1 : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < NS; ++r) kp[r] = r < cnt;
+    }
+    Sums<OP, NS, K> A;
+    A.clear();
+    int n_missing = 0;
+    const char *row = tile + lane * LO_PITCH;
+    const int nfull = n / LO_CHP;
+    const int nst = (n + LO_CHP - 1) / LO_CHP;
+    auto rowsel = [&](int r) { return lidx[r]; };
+    StageRegs S;
+    auto load_stage = [&](int st) {
+        const int pool0 = st * LO_CHP;
+        if (st < nfull) stage_load<PB, false>(S, counts, n, pool0, LO_CHP, lane, rowsel);
+        else stage_load<8, true>(S, counts, n, pool0, n - pool0, lane, rowsel);
+    };
+    load_stage(0);
+    for (int st = 0; st < nst; ++st) {
+        const int pool0 = st * LO_CHP;
+        const int np = st < nfull ? LO_CHP : n - pool0;
+        if (st < nfull) stage_store<PB, false>(S, tile, np, lane);
+        else stage_store<8, true>(S, tile, np, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (st + 1 < nst) load_stage(st + 1); // in flight while this stage is summed
+        // The eight pools of a stage are a ROLLED loop (two per trip, the next trip's words requested before this trip's arithmetic):
+        // unrolled eight times, the bodies of the NS variants together with the closing code overflowed the instruction cache that
+        // two CUs share, and every wave waited for instruction fetches (19 us per stage of eight pools, measured, against 3 us of
+        // arithmetic).  Pools past the row's end in the last stage are stale tile bytes, forced to zero counts.
+        uint2_t wn[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wn[u][k] = *reinterpret_cast<const uint2_t *>(row + u * 24 + 8 * k);
+#pragma unroll 1
+        for (int a0 = 0; a0 < LO_CHP; a0 += 2) {
+            uint2_t w[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w[u][k] = wn[u][k];
+            {
+                const int an = (a0 + 2 < LO_CHP) ? a0 + 2 : a0; // (the last trip re-reads its own words)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wn[u][k] = *reinterpret_cast<const uint2_t *>(row + (an + u) * 24 + 8 * k);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int a = a0 + u;
+                const bool live = a < np;
+                const uint32_t c[NA] = {w[u][0].x, w[u][0].y, w[u][1].x, w[u][1].y, w[u][2].x, w[u][2].y};
+                uint32_t cc[NS];
+                uint32_t rsi = 0u; // row sum over the surviving alleles (second to_frequencies, sync.rs:170-175): exact in integers
+#pragma unroll
+                for (int r = 0; r < NS; ++r) {
+                    uint32_t v = 0u;
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) v = (col[r] == j) ? c[j] : v;
+                    v = live ? v : 0u;
+                    cc[r] = v;
+                    rsi += v;
+                }
+                const bool rowok = rsi != 0u;
+                const double rsd = (double)(rsi > 1u ? rsi : 1u);
+                const double rinv = recip_for_div(rsd);
+                n_missing += (live && !rowok) ? 1 : 0;
+                double f[NS];
+#pragma unroll
+                for (int r = 0; r < NS; ++r) f[r] = div_by((double)cc[r], rsd, rinv);
+                A.add_pool(f, rowok, Y + (size_t)(pool0 + a) * K); // (the host pads Y with LO_CHP rows of zeros)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto ajc = [&](int r) { return col[r] & 7; };
+    emit_record<OP, NS, K>(A, n_missing > 0, kp, true, false, valid, rec_flags, rec, unit_slot(l, P.pshift), ajc, P.sort_desc != 0);
+}
+
+// The list grouped by the number of surviving alleles: group b (b + 2 survivors) occupies whole tiles of 64 entries of `sorted`, so
+// that a wave of the sums / closing kernels below runs code compiled for ONE number of survivors (mixed tiles ran every lane at the
+// tile's maximum and, in the closing, every variant in turn: together with the instruction-cache misses of that much code, 2.5 x).
+__device__ __forceinline__ void group_tiles(const unsigned long long *__restrict__ second_count, int64_t (&cnt)[LO_NB], int64_t (&first)[LO_NB + 1]) {
+    first[0] = 0;
+#pragma unroll
+    for (int b = 0; b < LO_NB; ++b) {
+        cnt[b] = (int64_t)second_count[b];
+        first[b + 1] = first[b] + (cnt[b] + 63) / 64;
+    }
+}
+
+// how many listed loci keep 2, 3, .. alleles (five atomics per wave)
+__global__ __launch_bounds__(256) void k_locus_hist(const int64_t *__restrict__ second, unsigned long long *second_count,
+                                                    const int32_t *__restrict__ rec_flags, int64_t total, int pshift) {
+    const int lane = threadIdx.x & 63;
+    int c[LO_NB];
+#pragma unroll
+    for (int b = 0; b < LO_NB; ++b) c[b] = 0;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t * 64 < total; t += nw) {
+        const int64_t e = t * 64 + lane;
+        const int nk = e < total ? ((rec_flags[unit_slot(second[e], pshift)] >> H_NK_SHIFT) & 7) : 0;
+#pragma unroll
+        for (int b = 0; b < LO_NB; ++b) c[b] += __popcll(__ballot(nk == b + 2));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < LO_NB; ++b)
+            if (c[b]) atomicAdd(second_count + b, (unsigned long long)c[b]);
+    }
+}
+
+constexpr int SORT_CH = 16; // tiles per wave and reservation
+__global__ __launch_bounds__(256) void k_locus_sort(const int64_t *__restrict__ second, unsigned long long *second_count,
+                                                    const int32_t *__restrict__ rec_flags, int64_t *__restrict__ sorted, int64_t total,
+                                                    int pshift) {
+    const int lane = threadIdx.x & 63;
+    int64_t cnt[LO_NB], first[LO_NB + 1];
+    group_tiles(second_count, cnt, first);
+    const int64_t ntile = (total + 63) / 64;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SORT_CH; t0 < ntile; t0 += nw * SORT_CH) {
+        // this wave's chunk: count per group, reserve once per group, scatter
+        int c[LO_NB];
+        int nkv[SORT_CH];
+        int64_t lv[SORT_CH];
+#pragma unroll
+        for (int b = 0; b < LO_NB; ++b) c[b] = 0;
+#pragma unroll
+        for (int u = 0; u < SORT_CH; ++u) {
+            const int64_t e = (t0 + u) * 64 + lane;
+            const bool valid = e < total;
+            lv[u] = valid ? second[e] : 0;
+            nkv[u] = valid ? ((rec_flags[unit_slot(lv[u], pshift)] >> H_NK_SHIFT) & 7) : 0;
+#pragma unroll
+            for (int b = 0; b < LO_NB; ++b) c[b] += __popcll(__ballot(nkv[u] == b + 2));
+        }
+        int64_t base[LO_NB];
+#pragma unroll
+        for (int b = 0; b < LO_NB; ++b) {
+            unsigned long long bv = 0;
+            if (lane == 0 && c[b]) bv = atomicAdd(second_count + SC_CURSOR + b, (unsigned long long)c[b]);
+            bv = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bv >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
+            base[b] = first[b] * 64 + (int64_t)bv;
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_CH; ++u) {
+#pragma unroll
+            for (int b = 0; b < LO_NB; ++b) {
+                const bool mine = nkv[u] == b + 2;
+                const unsigned long long bal = __ballot(mine);
+                if (mine) sorted[base[b] + __popcll(bal & ((1ull << lane) - 1ull))] = lv[u];
+                base[b] += __popcll(bal);
+            }
+        }
+    }
+}
+
+// the tile t of the list: this lane's entry (clamped to the last one: `valid` false) and the number of survivors the tile's code is
+// compiled for -- the group's when the list is grouped (k_locus_sort), the largest of the tile's loci when it is not (short lists)
+__device__ __forceinline__ int tile_entry(const int64_t t, const int grouped, const int64_t total, const int64_t (&cnt)[LO_NB],
+                                          const int64_t (&first)[LO_NB + 1], const int64_t *__restrict__ list,
+                                          const int32_t *__restrict__ rec_flags, const int pshift, const int lane, int64_t &l, bool &valid) {
+    if (grouped) {
+        int b = 0;
+#pragma unroll
+        for (int q = 1; q < LO_NB; ++q) b = (t >= first[q]) ? q : b;
+        b = __builtin_amdgcn_readfirstlane(b);
+        int64_t cb = cnt[0], fb = first[0];
+#pragma unroll
+        for (int q = 1; q < LO_NB; ++q) { cb = (b == q) ? cnt[q] : cb; fb = (b == q) ? first[q] : fb; }
+        const int64_t e = (t - fb) * 64 + lane;
+        valid = e < cb;
+        l = list[fb * 64 + (valid ? e : cb - 1)];
+        return b + 2;
+    }
+    const int64_t e = t * 64 + lane;
+    valid = e < total;
+    l = list[valid ? e : total - 1];
+    int nsw = (rec_flags[unit_slot(l, pshift)] >> H_NK_SHIFT) & 7;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nsw = max(nsw, __shfl_xor(nsw, off));
+    return __builtin_amdgcn_readfirstlane(nsw);
+}
+
+template <int OP, int NMAX, int K, int PB>
+__global__ __launch_bounds__(LO_THREADS) void k_locus_second(
     const uint32_t *__restrict__ counts, const double *__restrict__ Y, int32_t *rec_flags,
-    double *rec, const int64_t *__restrict__ second,
-    const unsigned long long *__restrict__ second_count, const double *__restrict__ tcoef, const StreamOut O,
-    const LocusParams P) {
+    double *rec, const int64_t *__restrict__ list,
+    const unsigned long long *__restrict__ second_count, const LocusParams P, const int grouped, const int64_t total) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     char *tile = lds_raw + wave * LO_TILEB;
     int64_t *lidx = reinterpret_cast<int64_t *>(lds_raw + LO_WAVES * LO_TILEB) + wave * 64;
-    const char *row = tile + lane * LO_PITCH;
-    const int n = P.n;
-    const int nfull = n / LO_CHP;
-    const int nst = (n + LO_CHP - 1) / LO_CHP;
-    const int64_t cnt = (int64_t)*second_count;
-    const int64_t ntiles = (cnt + 63) / 64;
+    int64_t cnt[LO_NB], first[LO_NB + 1];
+    group_tiles(second_count, cnt, first);
+    const int64_t ntile = grouped ? first[LO_NB] : (total + 63) / 64;
     const int64_t wstride = (int64_t)gridDim.x * LO_WAVES;
-    auto aj = [](int jj) { return jj; };
-    StageRegs S;
-    Sums<OP, NA, K> A;
-    for (int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave; t < ntiles; t += wstride) {
-        const int64_t e = t * 64 + lane;
-        const int64_t l = second[e < cnt ? e : cnt - 1];
+    for (int64_t t = (int64_t)blockIdx.x * LO_WAVES + wave; t < ntile; t += wstride) {
+        int64_t l;
+        bool valid;
+        const int ns = tile_entry(t, grouped, total, cnt, first, list, rec_flags, P.pshift, lane, l, valid);
+        __builtin_amdgcn_wave_barrier();
         lidx[lane] = l;
         __builtin_amdgcn_wave_barrier();
-        const int64_t slot = unit_slot(l, P.pshift);
-        const int mask = rec_flags[slot];
-        bool keep[NA];
-#pragma unroll
-        for (int j = 0; j < NA; ++j) keep[j] = (mask & (2 << j)) != 0;
-        auto rowsel = [&](int r) { return lidx[r]; };
-        A.clear();
-        int n_missing = 0;
-        for (int st = 0; st < nst; ++st) {
-            const int pool0 = st * LO_CHP;
-            const int np = st < nfull ? LO_CHP : n - pool0;
-            if (st < nfull) {
-                stage_load<PB, false>(S, counts, n, pool0, np, lane, rowsel);
-                stage_store<PB, false>(S, tile, np, lane);
-            } else {
-                stage_load<8, true>(S, counts, n, pool0, np, lane, rowsel);
-                stage_store<8, true>(S, tile, np, lane);
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-            for (int i = 0; i < np; ++i) {
-                const uint2_t a = *reinterpret_cast<const uint2_t *>(row + i * 24);
-                const uint2_t b = *reinterpret_cast<const uint2_t *>(row + i * 24 + 8);
-                const uint2_t d = *reinterpret_cast<const uint2_t *>(row + i * 24 + 16);
-                const uint32_t c[NA] = {a.x, a.y, b.x, b.y, d.x, d.y};
-                double cd[NA], f[NA];
-                double rs = 0.0; // row sum over the surviving alleles (second to_frequencies, sync.rs:170-175)
-#pragma unroll
-                for (int j = 0; j < NA; ++j) { cd[j] = keep[j] ? (double)c[j] : 0.0; rs = rs + cd[j]; }
-                const bool rowok = rs != 0.0;
-                const double rsd = rowok ? rs : 1.0;
-                const double rinv = recip_for_div(rsd);
-                n_missing += rowok ? 0 : 1;
-#pragma unroll
-                for (int j = 0; j < NA; ++j) f[j] = div_by(cd[j], rsd, rinv);
-                A.add_pool(f, rowok, Y + (size_t)(pool0 + i) * K);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        emit_record<OP, NA, K>(A, n_missing > 0, keep, true, false, e < cnt, rec_flags, rec, slot, aj, P.sort_desc != 0);
-        if (OP != OP_LOAD) {
-            // close the locus from the record just written (same lane; the fence orders its loads behind its stores)
-            __threadfence();
-            if (e < cnt) close_locus<(OP == OP_LOAD ? OP_OLS : OP)>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
-        }
+        const int mask = rec_flags[unit_slot(l, P.pshift)];
+        // (the arithmetic of a locus does not depend on the variant: padding columns contribute exact zeros to sums that are never read)
+        if (ns <= 2) second_tile<OP, 2, K, PB>(counts, Y, rec_flags, rec, tile, lidx, l, mask, valid, P, lane);
+        else if (ns == 3) second_tile<OP, 3, K, PB>(counts, Y, rec_flags, rec, tile, lidx, l, mask, valid, P, lane);
+        else if (ns == 4) second_tile<OP, 4, K, PB>(counts, Y, rec_flags, rec, tile, lidx, l, mask, valid, P, lane);
+        else if (ns == 5 || NMAX == 5) second_tile<OP, 5, K, PB>(counts, Y, rec_flags, rec, tile, lidx, l, mask, valid, P, lane);
+        else second_tile<OP, NMAX, K, PB>(counts, Y, rec_flags, rec, tile, lidx, l, mask, valid, P, lane);
+    }
+}
+
+// closing arithmetic of the listed loci from their records: its own launch (the sums kernel's code stays small); on a grouped list a
+// tile = one number of survivors = one variant of the closing code per wave
+template <int OP>
+__global__ __launch_bounds__(256) void k_locus_close(const int32_t *rec_flags, const double *rec, const int64_t *__restrict__ list,
+                                                     const unsigned long long *__restrict__ second_count,
+                                                     const double *__restrict__ tcoef, const StreamOut O, const LocusParams P,
+                                                     const int grouped, const int64_t total) {
+    const int lane = threadIdx.x & 63;
+    int64_t cnt[LO_NB], first[LO_NB + 1];
+    group_tiles(second_count, cnt, first);
+    const int64_t ntile = grouped ? first[LO_NB] : (total + 63) / 64;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntile; t += nw) {
+        int64_t l;
+        bool valid;
+        const int ns = tile_entry(t, grouped, total, cnt, first, list, rec_flags, P.pshift, lane, l, valid);
+        if (!valid) continue;
+        if (!grouped) close_locus<OP, 0>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
+        else if (ns == 2) close_locus<OP, 2>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
+        else if (ns == 3) close_locus<OP, 3>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
+        else if (ns == 4) close_locus<OP, 4>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
+        else if (ns == 5) close_locus<OP, 5>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
+        else close_locus<OP, 6>(l, rec_flags, rec, tcoef, O.n_out, O.ids, O.mf, O.stat, O.pv, P);
     }
 }
 
@@ -1501,13 +1829,15 @@ struct StreamWs { // device pointers into the context's workspace
     double *Y;                  // n x MAXK for the second pass
     double *tcoef;
     double *rec;                // records of the second pass, one per locus (touched only for listed loci)
-    int64_t *second;
-    unsigned long long *second_count;
+    int64_t *second;            // the second pass' list (L entries), and grouped by the number of survivors (L + 64 LO_NB)
+    int64_t *sorted;
+    unsigned long long *second_count; // SC_WORDS words
     int32_t *flags;
 };
 
 template <int OP>
-int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, const StreamOut &O, const LocusParams &P, int kg, bool rns) {
+int launch_passes(pg_ctx *ctx, int kid, const uint32_t *counts_dev, const StreamWs &W, const StreamOut &O, const LocusParams &P, int kg, bool rns,
+                  int64_t *listed, bool *complaint) {
     const int n = P.n;
     const int64_t L = P.L;
     const int M = stream_period(n);
@@ -1531,7 +1861,8 @@ int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, co
     };
     const void *kstream = pick();
     PG_HIP(ctx, hipFuncSetAttribute(kstream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PG_HIP(ctx, hipMemsetAsync(W.second_count, 0, 16, ctx->stream)); // the list's length, and the streaming pass' complaint flag
+    PG_HIP(ctx, hipMemsetAsync(W.second_count, 0, 8 * SC_WORDS, ctx->stream)); // the list's length and groups, the sort's cursors, the streaming pass' complaint flag
+    if (kid >= 0) pg_prof_begin(ctx, kid);
     {
         const double *a1 = W.table, *a2 = W.tcoef;
         int32_t *a3 = W.flags;
@@ -1541,27 +1872,63 @@ int launch_passes(pg_ctx *ctx, const uint32_t *counts_dev, const StreamWs &W, co
         void *args[] = {(void *)&counts_dev, &a1, &a2, &a3, &a4, &a5, (void *)&O, (void *)&P, &mm, &st};
         PG_HIP(ctx, hipLaunchKernel(kstream, dim3(grid), dim3(LO_THREADS), args, shmem, ctx->stream));
     }
-    // the listed loci, ONE launch: sums over the SURVIVING alleles from the counts, then the closing arithmetic from the record
+    // What the streaming pass could not close in place.  The host looks at the length of the list first (the call ends in a
+    // synchronisation anyway: it has to report the complaint flag): an empty list -- clean data -- costs no launch at all, a short
+    // one is taken as it is (tiles of mixed survivor counts), a long one is grouped by the number of survivors first.
+    unsigned long long tail[SC_LIST + 1]; // (the groups, not counted yet), the complaint flag, the list's length
+    if (kid >= 0) pg_prof_end(ctx);
+    PG_HIP(ctx, hipMemcpyAsync(tail, W.second_count, sizeof tail, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *complaint = tail[SC_COMPLAINT] != 0;
+    const int64_t total = (int64_t)tail[SC_LIST];
+    *listed = total;
+    if (total == 0 || *complaint) return PG_OK;
+    if (kid >= 0) pg_prof_begin(ctx, kid | PG_PROF_CONT);
     const bool p16 = ((int64_t)n * 24) % 16 == 0;
     auto pick_second = [&]() -> const void * {
+        constexpr int KK = (OP == OP_OLS ? 2 : 1);
         if (OP == OP_OLS && kg == 2)
-            return p16 ? (const void *)k_locus_second<OP, 16, (OP == OP_OLS ? 2 : 1)> : (const void *)k_locus_second<OP, 8, (OP == OP_OLS ? 2 : 1)>;
-        return p16 ? (const void *)k_locus_second<OP, 16, 1> : (const void *)k_locus_second<OP, 8, 1>;
+            return rns ? (p16 ? (const void *)k_locus_second<OP, 5, KK, 16> : (const void *)k_locus_second<OP, 5, KK, 8>)
+                       : (p16 ? (const void *)k_locus_second<OP, 6, KK, 16> : (const void *)k_locus_second<OP, 6, KK, 8>);
+        return rns ? (p16 ? (const void *)k_locus_second<OP, 5, 1, 16> : (const void *)k_locus_second<OP, 5, 1, 8>)
+                   : (p16 ? (const void *)k_locus_second<OP, 6, 1, 16> : (const void *)k_locus_second<OP, 6, 1, 8>);
     };
     const void *ksecond = pick_second();
     const size_t shmem2 = (size_t)LO_WAVES * LO_TILEB + (size_t)LO_WAVES * 64 * sizeof(int64_t);
     PG_HIP(ctx, hipFuncSetAttribute(ksecond, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
     {
+        const int64_t tiles = (total + 63) / 64 + LO_NB;
+        const int64_t wants = (tiles + 3) / 4, caps = (int64_t)ctx->cus * 8;
+        const unsigned gs = (unsigned)(wants < caps ? wants : caps);
+        int grouped = total >= (int64_t)LO_GROUP_FROM ? 1 : 0;
+        if (const char *e = std::getenv("POOLGEN_LOCUS_GROUPED")) grouped = std::atoi(e) != 0; // (A/B runs, tests of both routes)
+        const int64_t *list = W.second;
+        if (grouped) {
+            // (few, long-running waves: every wave ends in five atomics on the same five words -- with a wave per tile they took
+            // 0.34 ms per million entries, all of it contention)
+            hipLaunchKernelGGL(k_locus_hist, dim3((unsigned)(wants < (int64_t)ctx->cus ? wants : (int64_t)ctx->cus)), dim3(256), 0, ctx->stream,
+                               (const int64_t *)W.second, W.second_count, (const int32_t *)W.flags, total, P.pshift);
+            const int64_t wantq = (tiles + 4 * SORT_CH - 1) / (4 * SORT_CH);
+            hipLaunchKernelGGL(k_locus_sort, dim3((unsigned)(wantq < caps ? wantq : caps)), dim3(256), 0, ctx->stream,
+                               (const int64_t *)W.second, W.second_count, (const int32_t *)W.flags, W.sorted, total, P.pshift);
+            list = W.sorted;
+        }
         const double *a2 = W.Y;
         int32_t *b0 = W.flags;
         double *recp = W.rec;
-        const int64_t *b1 = W.second;
         const unsigned long long *b2 = W.second_count;
-        const double *b3 = W.tcoef;
-        void *args2[] = {(void *)&counts_dev, &a2, &b0, &recp, &b1, &b2, &b3, (void *)&O, (void *)&P};
-        const int64_t tiles_cap = (int64_t)ctx->cus * 2;
-        PG_HIP(ctx, hipLaunchKernel(ksecond, dim3((unsigned)tiles_cap), dim3(LO_THREADS), args2, shmem2, ctx->stream));
+        int64_t tot = total;
+        void *args2[] = {(void *)&counts_dev, &a2, &b0, &recp, &list, &b2, (void *)&P, &grouped, &tot};
+        const int64_t want = (tiles + LO_WAVES - 1) / LO_WAVES, cap2 = (int64_t)ctx->cus * 2;
+        PG_HIP(ctx, hipLaunchKernel(ksecond, dim3((unsigned)(want < cap2 ? want : cap2)), dim3(LO_THREADS), args2, shmem2, ctx->stream));
+        if (OP != OP_LOAD) {
+            constexpr int OPC = (OP == OP_LOAD) ? OP_OLS : OP;
+            hipLaunchKernelGGL(k_locus_close<OPC>, dim3(gs), dim3(256), 0, ctx->stream,
+                               (const int32_t *)W.flags, (const double *)W.rec, list,
+                               (const unsigned long long *)W.second_count, (const double *)W.tcoef, O, P, grouped, total);
+        }
     }
+    if (kid >= 0) pg_prof_end(ctx);
     PG_HIP(ctx, hipGetLastError());
     return PG_OK;
 }
@@ -1591,27 +1958,30 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
     const int M = stream_period(n);
     PG_CHECK(ctx, (int64_t)64 * M * n * 24 < ((int64_t)1 << 31), "locus op: too many pools (%d) for one unit of loci", n);
     // workspace: [table n x 3 | Y n x MAXK | tcoef] [records of the second pass] [its list: L x i64] [its length: u64] [flags: i32 per locus]
-    const size_t side = ((size_t)n * 3 + (size_t)n * MAXK + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
+    const size_t ypad = (size_t)(n + LO_CHP) * MAXK; // the second pass reads whole stages of LO_CHP pools: zeros behind the last
+    const size_t side = ((size_t)n * 3 + ypad + tc.size() + 8 + 1) & ~(size_t)1; // doubles, even
     const size_t slots = (size_t)((L + 63) / 64) * 64;
     const size_t recd = slots * REC_DOUBLES;
-    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * (size_t)L + 16 + sizeof(int32_t) * slots;
+    const size_t nsorted = (size_t)L + 64 * LO_NB;
+    const size_t need = sizeof(double) * (side + recd) + sizeof(int64_t) * ((size_t)L + nsorted) + 8 * (SC_WORDS + 1) + sizeof(int32_t) * slots;
     int rc = pg_ws_reserve(ctx, need);
     if (rc) return rc;
     StreamWs W;
     W.table = static_cast<double *>(ctx->ws);
     W.Y = W.table + (size_t)n * 3;
-    W.tcoef = W.Y + (size_t)n * MAXK;
+    W.tcoef = W.Y + ypad;
     W.rec = W.table + side;
     W.second = reinterpret_cast<int64_t *>(W.rec + recd);
-    W.second_count = reinterpret_cast<unsigned long long *>(W.second + L);
-    W.flags = reinterpret_cast<int32_t *>(W.second_count + 2);
+    W.sorted = W.second + L;
+    W.second_count = reinterpret_cast<unsigned long long *>(W.sorted + nsorted);
+    W.flags = reinterpret_cast<int32_t *>(W.second_count + SC_WORDS + 1);
     if (!tc.empty())
         PG_HIP(ctx, hipMemcpyAsync(W.tcoef, tc.data(), sizeof(double) * tc.size(), hipMemcpyHostToDevice, ctx->stream));
     const bool rns = flt->remove_ns != 0;
     const StreamOut O{n_out, ids, mf, stat, pv};
     // pearson_corr takes one trait per launch (its sums per trait and allele do not fit two traits at two waves per SIMD)
     const int kstep = (OP == OP_OLS) ? MAXK : 1;
-    std::vector<double> Yd((size_t)n * MAXK), tab((size_t)n * 3);
+    std::vector<double> Yd(ypad), tab((size_t)n * 3);
     for (int t0 = 0; t0 < k; t0 += kstep) { // the filter passes are recomputed per launch group
         const int kg = (k - t0) < kstep ? (k - t0) : kstep;
         LocusParams P;
@@ -1624,6 +1994,7 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
         P.max_miss = flt->max_missingness_rate;
         P.tdf = df;
         P.ntcoef = (int)tc.size();
+        P.qband = 8.0 * ((double)n + 16.0) * 2.220446049250313e-16;
         std::fill(Yd.begin(), Yd.end(), 0.0);
         if (OP == OP_OLS) {
             for (int t = 0; t < kg; ++t) {
@@ -1646,6 +2017,17 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
                 for (int i = 0; i < n; ++i)
                     if (!std::isnan(Y[(size_t)i * k + t0 + t])) { sh = Y[(size_t)i * k + t0 + t]; break; }
                 for (int i = 0; i < n; ++i) Yd[(size_t)i * kg + t] = Y[(size_t)i * k + t0 + t] - sh;
+                // what the running sums over the complete pairs come to when every pair is complete (same order, same operations)
+                double py = 0.0, pyy = 0.0, pn = 0.0;
+                P.y_complete = 1;
+                for (int i = 0; i < n; ++i) {
+                    const double ye = Yd[(size_t)i * kg + t];
+                    if (std::isnan(ye)) { P.y_complete = 0; continue; }
+                    py = py + ye;
+                    pyy = std::fma(ye, ye, pyy);
+                    pn = pn + 1.0;
+                }
+                P.py[t] = py; P.pyy[t] = pyy; P.pn[t] = pn;
             }
         }
         const int TW = (OP == OP_OLS || OP == OP_PEARSON) ? 1 + kg : 1;
@@ -1654,15 +2036,14 @@ int run_locus_op(pg_ctx *ctx, int kid, const uint32_t *counts_dev, int64_t L, in
             for (int t = 0; t + 1 < TW; ++t) tab[(size_t)i * TW + 1 + t] = Yd[(size_t)i * kg + t];
         }
         PG_HIP(ctx, hipMemcpyAsync(W.table, tab.data(), sizeof(double) * n * TW, hipMemcpyHostToDevice, ctx->stream));
-        PG_HIP(ctx, hipMemcpyAsync(W.Y, Yd.data(), sizeof(double) * n * MAXK, hipMemcpyHostToDevice, ctx->stream));
-        pg_prof_begin(ctx, kid);
-        rc = launch_passes<OP>(ctx, counts_dev, W, O, P, kg, rns);
-        pg_prof_end(ctx);
+        PG_HIP(ctx, hipMemcpyAsync(W.Y, Yd.data(), sizeof(double) * ypad, hipMemcpyHostToDevice, ctx->stream));
+        int64_t listed = 0;
+        bool complaint = false;
+        rc = launch_passes<OP>(ctx, kid, counts_dev, W, O, P, kg, rns, &listed, &complaint); // (synchronises after the streaming pass: tab / Yd are free again)
         if (rc) return rc;
-        unsigned long long complaint = 0;
-        PG_HIP(ctx, hipMemcpyAsync(&complaint, W.second_count + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-        PG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // tab / Yd are reused by the next launch group
-        PG_CHECK(ctx, complaint == 0, "locus op: a count of 2^29 (536 870 912) reads or more: beyond what the streaming pass sums exactly");
+        PG_CHECK(ctx, !complaint, "locus op: a count of 2^29 (536 870 912) reads or more: beyond what the streaming pass sums exactly");
+        if (t0 == 0) { ctx->lo_last_L = L; ctx->lo_last_listed = 0; }
+        ctx->lo_last_listed += listed;
     }
     return PG_OK;
 }
@@ -1824,7 +2205,8 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     const size_t o_w = off; off = al16(off + sizeof(double) * n);
     const size_t o_flags = off; off = al16(off + sizeof(int32_t) * slots);
     const size_t o_second = off; off = al16(off + sizeof(int64_t) * (size_t)L);
-    const size_t o_count = off; off = al16(off + 16);
+    const size_t o_sorted = off; off = al16(off + sizeof(int64_t) * ((size_t)L + 64 * LO_NB));
+    const size_t o_count = off; off = al16(off + 8 * (SC_WORDS + 1));
     const size_t o_local = off; off = al16(off + sizeof(int32_t) * (size_t)L);
     const size_t o_bsum = off; off = al16(off + 8 * (size_t)nb);
     const size_t o_boff = off; off = al16(off + 8 * (size_t)nb);
@@ -1838,6 +2220,7 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     W.Y = nullptr; W.tcoef = nullptr; W.rec = nullptr;
     W.flags = reinterpret_cast<int32_t *>(ws + o_flags);
     W.second = reinterpret_cast<int64_t *>(ws + o_second);
+    W.sorted = reinterpret_cast<int64_t *>(ws + o_sorted);
     W.second_count = reinterpret_cast<unsigned long long *>(ws + o_count);
     int32_t *recf = W.flags;
     int32_t *local = reinterpret_cast<int32_t *>(ws + o_local);
@@ -1853,18 +2236,22 @@ int load_plan(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n, const d
     P.min_cov = (double)flt->min_coverage_depth;
     P.maf = flt->min_allele_frequency;
     P.max_miss = flt->max_missingness_rate;
-    rc = launch_passes<OP_LOAD>(ctx, counts_dev, W, StreamOut{nullptr, nullptr, nullptr, nullptr, nullptr}, P, 1, flt->remove_ns != 0);
+    P.qband = 8.0 * ((double)n + 16.0) * 2.220446049250313e-16;
+    P.y_complete = 1;
+    int64_t listed = 0;
+    bool complaint = false;
+    rc = launch_passes<OP_LOAD>(ctx, -1, counts_dev, W, StreamOut{nullptr, nullptr, nullptr, nullptr, nullptr}, P, 1, flt->remove_ns != 0,
+                                &listed, &complaint);
     if (rc) return rc;
+    PG_CHECK(ctx, !complaint, "load: a count of 2^29 (536 870 912) reads or more: beyond what the streaming pass sums exactly");
     hipLaunchKernelGGL(k_load_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, recf, order_dev, L, P.pshift,
                        P.sort_desc, local, bsum);
     hipLaunchKernelGGL(k_load_scan, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb, boff, tot_dev);
     PG_HIP(ctx, hipGetLastError());
     int64_t tot = 0;
-    unsigned long long complaint = 0;
     PG_HIP(ctx, hipMemcpyAsync(&tot, tot_dev, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(ctx, hipMemcpyAsync(&complaint, W.second_count + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PG_CHECK(ctx, complaint == 0, "load: a count of 2^29 (536 870 912) reads or more: beyond what the streaming pass sums exactly");
+    ctx->lo_last_L = L; ctx->lo_last_listed = listed;
     *p_out = tot;
     ctx->load_valid = true;
     ctx->load_counts = counts_dev; ctx->load_order = order_dev;
@@ -1905,6 +2292,13 @@ int load_emit(pg_ctx *ctx, const int32_t *pool_map, int n_out, double *G_dev, in
 }
 
 } // namespace
+
+extern "C" int pg_locus_op_stats(const pg_ctx *ctx, int64_t *loci, int64_t *listed) {
+    if (!ctx) return PG_ERR_INVALID;
+    if (loci) *loci = ctx->lo_last_L;
+    if (listed) *listed = ctx->lo_last_listed;
+    return PG_OK;
+}
 
 extern "C" int pg_ols_iter_batch_dev(pg_ctx *ctx, const uint32_t *counts_dev, int64_t L, int n,
                                      const double *pool_sizes, const pg_filter *filter, const double *Y,

@@ -45,8 +45,16 @@ def setup_comm(engine, group=None, force: bool = False) -> bool:
     world = dist.get_world_size(group)
     if (world <= 1 and not force) or not hasattr(engine, "comm_init") or os.environ.get("POOLGEN_COMM", "rccl") != "rccl":
         return False
-    if getattr(engine, "_comm_ready", False) and engine.comm_size == world:
+    # a communicator may already be there -- but "already there" must be the answer of EVERY rank (a rank that lost its
+    # communicator, e.g. an engine re-created after a partial comm_destroy, would otherwise enter the collectives below alone)
+    ready = bool(getattr(engine, "_comm_ready", False) and engine.comm_size == world)
+    if _all_agree(ready, group):
         return True
+    if getattr(engine, "_comm_ready", False):   # some rank is not ready: everybody starts from nothing
+        try:
+            engine.comm_destroy()
+        except Exception:
+            pass
     rank = dist.get_rank(group)
     # stage 1: can every rank load RCCL at all?
     try:

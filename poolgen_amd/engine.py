@@ -286,6 +286,16 @@ class Engine:
         live = torch.arange(5, device=dev)[None, :] < n_out[:, None]
         return n_out, torch.where(live, ids.T, torch.tensor(-1, dtype=torch.int32, device=dev)), chi2, pv
 
+    def last_listed(self):
+        """(loci, listed) of the last batch operator call: how many loci its streaming pass handed to the second pass."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.pg_locus_op_stats(self._ctx, C.byref(a), C.byref(b)), "pg_locus_op_stats")
+        return a.value, b.value
+
+    def last_listed_fraction(self) -> float:
+        loci, listed = self.last_listed()
+        return listed / loci if loci else 0.0
+
     def load_frequencies(self, counts, pool_sizes, flt: Filter, keep_p_minus_1: bool = False, order=None,
                          pool_keep=None, ld: int | None = None, coverages: bool = False):
         """The reference loader (base/sync.rs:972-1180) on a counts batch in HBM: filter, frequencies over the

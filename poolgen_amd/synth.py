@@ -44,8 +44,27 @@ def genotype_matrix(p: int, n: int, device, seed: int = SEED, start: int = 0, ld
     return G
 
 
-def sync_counts(p: int, n: int, device, seed: int = SEED, start: int = 0):
-    """Sync-style counts (p x n x 6 int32, columns A,T,C,G,N,D): A = ref, T = alt, rest 0."""
+def _spread_errors(src: torch.Tensor, rate: float, g: torch.Generator):
+    """Sequencing errors of the reads in `src` (float64 counts): each read is misread with probability `rate`, and a misread
+    read lands on one of the FIVE other sync columns with equal probability (the other allele, the two other bases, N, D).
+    Returns (reads that stay, [reads that move to each of the 5 other columns])."""
+    moved = torch.binomial(src, torch.full_like(src, rate), generator=g)
+    parts, rest = [], moved
+    for left in (5, 4, 3, 2):
+        part = torch.binomial(rest, torch.full_like(rest, 1.0 / left), generator=g)
+        parts.append(part)
+        rest = rest - part
+    parts.append(rest)
+    return src - moved, parts
+
+
+def sync_counts(p: int, n: int, device, seed: int = SEED, start: int = 0, error_rate: float = 0.0):
+    """Sync-style counts (p x n x 6 int32, columns A,T,C,G,N,D): A = ref, T = alt, rest 0.
+
+    error_rate > 0 makes the counts look like real pool-seq data: every read is misread with that probability and lands on one
+    of the other five columns (so a biallelic A/T locus carries stray C, G, N and D reads -- about n * depth * error_rate * 3/5 of
+    them per locus outside A, T and N).  The error draws come after the clean draws of a chunk, so the clean part is the same
+    matrix as with error_rate = 0."""
     out = torch.zeros((p, n, 6), dtype=torch.int32, device=device)
     lo = start
     while lo < start + p:
@@ -53,8 +72,17 @@ def sync_counts(p: int, n: int, device, seed: int = SEED, start: int = 0):
         c_lo, c_hi = c * CHUNK, (c + 1) * CHUNK
         hi = min(start + p, c_hi)
         alt, depth = _chunk(seed, c, CHUNK, n, device, True)
-        out[lo - start:hi - start, :, 1] = alt[lo - c_lo:hi - c_lo].to(torch.int32)
-        out[lo - start:hi - start, :, 0] = (depth - alt)[lo - c_lo:hi - c_lo].to(torch.int32)
+        ref = depth - alt
+        if error_rate > 0.0:
+            g = torch.Generator(device=device)
+            g.manual_seed(seed * 1_000_003 + c + 500_000_009)
+            ref_stay, ref_to = _spread_errors(ref, error_rate, g)   # A -> T, C, G, N, D
+            alt_stay, alt_to = _spread_errors(alt, error_rate, g)   # T -> A, C, G, N, D
+            cols = [ref_stay + alt_to[0], alt_stay + ref_to[0]] + [ref_to[1 + j] + alt_to[1 + j] for j in range(4)]
+        else:
+            cols = [ref, alt]
+        for j, col in enumerate(cols):
+            out[lo - start:hi - start, :, j] = col[lo - c_lo:hi - c_lo].to(torch.int32)
         lo = hi
     return out
 

@@ -108,6 +108,14 @@ def test_secondary_legs_in_the_line():
     for op in ("ols_iter", "pearson_corr", "chisq_test"):
         assert co[op]["kernel_ms"] > 0 and co[op]["launches"] == 10 and 0 < co[op]["frac"] < 1
         assert co[op]["bytes_per_launch"] == 24.0 * 100 * 200000
+    cr = sec["count_operators_realistic"]
+    for tag in ("error_0.005_maf_0.01", "error_0.001_default_filter", "error_0.005_default_filter"):
+        for op in ("ols_iter", "pearson_corr", "chisq_test"):
+            leg = cr[tag][op]
+            assert leg["kernel_ms"] > 0 and leg["launches"] == 10 and 0 < leg["frac"] < 1 and 0 <= leg["deferred_fraction"] <= 1
+    assert 0 < cr["error_0.005_maf_0.01"]["ols_iter"]["deferred_fraction"] < 0.15      # the speculated pair holds for most loci
+    assert cr["error_0.005_default_filter"]["ols_iter"]["deferred_fraction"] > 0.5     # error alleles that survive: multi-allelic fits
+    assert cr["ols_iter"] == cr["error_0.005_maf_0.01"]["ols_iter"]
     rd = sec["ridge"]
     assert "error" not in rd, rd
     assert rd["coefficient_pass"]["launches"] >= 10 and rd["prediction_pass"]["launches"] >= 10 and rd["wall_s"] > 0

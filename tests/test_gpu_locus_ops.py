@@ -307,3 +307,129 @@ def test_slot_major_layout_of_the_abi(engine, oracle):
     for r in range(5):
         live = n_out > r
         assert np.array_equal(rids[r][live], ids[live, r])
+
+
+@pytest.mark.parametrize("n,L,err,kw", [(100, 3000, 0.005, dict(maf=0.01)), (100, 2000, 0.001, dict()), (200, 1500, 0.005, dict()),
+                                        (33, 2001, 0.01, dict(maf=0.02)), (48, 1500, 0.02, dict(maf=0.05, remove_ns=False)),
+                                        (16, 1200, 0.01, dict(maf=0.01, min_cov=0, miss=0.3)), (7, 900, 0.01, dict(maf=0.01))])
+def test_error_bearing_counts(engine, oracle, n, L, err, kw):
+    """Realistic counts: every read misread with probability `err` onto one of the other five sync columns, so nearly every
+    locus carries reads of alleles the MAF filter drops.  The reference filters and THEN recomputes the frequencies on the
+    filtered counts (gwas/ols.rs:210-230 -> base/sync.rs:252-286, :166-192): one dropped read changes every denominator of
+    its pool.  Emission and allele ids bit-exact, mean frequencies bit-exact, statistics 1e-10 -- for the loci the streaming
+    pass closes from its speculated pair, for the mis-speculated ones and for the multi-allelic ones (error alleles that
+    survive the filter: the (200, default maf) and 7-pool cases) alike."""
+    from poolgen_amd import synth
+    counts = synth.sync_counts(L, n, "cuda", seed=41, error_rate=err)
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+    counts[3::89, : max(1, n // 5), :] = 0                        # uncovered pools (missingness; NaN frequencies where allowed)
+    counts[7::113, :, 1] = 0                                       # the minor allele gone: only error alleles beside the major one
+    hole = (torch.rand(L, n, generator=g, device="cuda") < 0.3 / n)  # pools where only stray reads remain: uncovered over the survivors
+    counts[:, :, 0] *= (~hole).int(); counts[:, :, 1] *= (~hole).int()
+    Y = synth.phenotypes(synth.genotype_matrix(64, n, "cuda", seed=41), n, k=2, seed=6)
+    ps = np.linspace(10, 30, n)
+    f, fo = flt_pair(oracle, **kw)
+    rows = counts.cpu().numpy().astype(np.uint64)
+    check_stat_op(engine.ols_iterate(counts, ps, f, Y), oracle.ols_iterate_locus, rows, Y, ps, fo, oracle=oracle)
+    check_stat_op(engine.correlation(counts, ps, f, Y), oracle.correlation_locus, rows, Y, ps, fo,
+                  stat_rtol=0, stat_atol=1.0000001e-7)
+    n_out, ids, chi2, pv = (x.cpu().numpy() for x in engine.chisq(counts, ps, f))
+    emitted = 0
+    for l in range(L):
+        a, rid, rc, rp = oracle.chisq_locus(rows[l], ps, fo)
+        assert n_out[l] == a, f"chisq locus {l}"
+        if a:
+            emitted += 1
+            assert ids[l, :min(a, 5)].tolist() == rid.tolist()[:5]
+            if np.isnan(rc):
+                assert np.isnan(chi2[l]) and np.isnan(pv[l]) and np.isnan(rp)
+                continue
+            assert abs(chi2[l] - rc) <= 1e-10 * max(1.0, abs(rc)) and abs(pv[l] - rp) <= 1e-10, f"chisq locus {l}"
+    assert emitted > L // 4
+
+
+def test_poisoned_tail_behind_an_odd_batch(engine, oracle):
+    """with L * n odd the last 16-byte load of the streaming pass reaches 8 bytes past the batch; whatever
+    lies there becomes counts of a locus that does not exist and must neither reach a result nor raise the 2^29 complaint."""
+    from poolgen_amd import synth
+    n, L = 33, 2001
+    big = torch.full(((L + 40) * n * 6,), -1, dtype=torch.int32, device="cuda")      # 0xFFFFFFFF words behind the batch
+    counts = big[: L * n * 6].view(L, n, 6)
+    counts.copy_(synth.sync_counts(L, n, "cuda", seed=5, error_rate=0.002))
+    assert counts.data_ptr() % 16 == 0 and (L * n * 24) % 16 == 8
+    Y = synth.phenotypes(synth.genotype_matrix(64, n, "cuda", seed=5), n, k=1, seed=3)
+    ps = np.full(n, 20.0)
+    f, fo = flt_pair(oracle)
+    rows = counts.cpu().numpy().astype(np.uint64)
+    check_stat_op(engine.ols_iterate(counts, ps, f, Y), oracle.ols_iterate_locus, rows, Y, ps, fo, oracle=oracle)
+    n_out = engine.chisq(counts, ps, f)[0]
+    assert int((n_out > 0).sum()) > L // 2
+    G, col_locus, col_allele = engine.load_frequencies(counts, ps, f)
+    assert G.shape[0] >= L
+
+
+@pytest.mark.parametrize("n", [40, 100])
+def test_filter_decision_on_the_threshold(engine, oracle, n):
+    """The streaming pass decides q < maf from a cheaper evaluation of q (fma(c, w / rs, q): within (n + 8) ulp of the reference's
+    sequential sum of fl(c / rs) * w, base/sync.rs:258-271) and recomputes q literally for loci within 8 (n + 16) eps of a
+    threshold.  Thresholds placed ON a locus' own q (to the bit), one ulp above and one below: the decisions must be the oracle's."""
+    from poolgen_amd import Filter, synth
+    L = 600
+    counts = synth.sync_counts(L, n, "cuda", seed=77, error_rate=0.004)
+    Y = synth.phenotypes(synth.genotype_matrix(64, n, "cuda", seed=77), n, k=1, seed=1)
+    ps = np.linspace(10, 30, n)
+    w = ps / ps.sum()
+    c = counts.cpu().numpy().astype(np.float64)[:, :, [0, 1, 2, 3, 5]]
+    rs = c.sum(axis=2)
+    q = np.zeros((L, 5))
+    for i in range(n):                        # the reference's order: pools sequentially, multiply then add
+        q = q + (c[:, i, :] / rs[:, i, None]) * w[i]
+    rows = counts.cpu().numpy().astype(np.uint64)
+    tested = 0
+    for l, j in ((3, 1), (17, 2), (101, 0), (333, 5 - 1)):
+        for maf in (q[l, j], np.nextafter(q[l, j], 1.0), np.nextafter(q[l, j], 0.0), 1.0 - q[l, j]):
+            if not (0.0 < maf < 0.5):
+                continue
+            f, fo = Filter(min_allele_frequency=float(maf)), oracle.filt(True, 1, float(maf), 0.0)
+            check_stat_op(engine.ols_iterate(counts, ps, f, Y), oracle.ols_iterate_locus, rows, Y, ps, fo, oracle=oracle)
+            n_out, ids, chi2, pv = (x.cpu().numpy() for x in engine.chisq(counts, ps, f))
+            for ll in (l, max(l - 1, 0), min(l + 1, L - 1)):
+                a, rid, rc, rp = oracle.chisq_locus(rows[ll], ps, fo)
+                assert n_out[ll] == a and (a == 0 or ids[ll, :a].tolist() == rid.tolist())
+            tested += 1
+    assert tested >= 8
+
+
+def test_second_pass_routes_agree(engine, oracle, monkeypatch):
+    """The second pass takes a short list as it is (tiles of mixed survivor counts) and groups a long one by the number of
+    survivors first (k_locus_hist / k_locus_sort): both routes forced on one batch with 2 .. 5 survivors per locus must give the
+    same bits (the arithmetic of a locus does not depend on the code variant its tile runs), and the oracle's answers."""
+    from poolgen_amd import synth
+    n, L = 100, 6000
+    counts = synth.sync_counts(L, n, "cuda", seed=13, error_rate=0.005)     # default maf: half of the error alleles survive
+    Y = synth.phenotypes(synth.genotype_matrix(64, n, "cuda", seed=13), n, k=2, seed=2)
+    ps = np.full(n, 20.0)
+    f, fo = flt_pair(oracle)
+    rows = counts.cpu().numpy().astype(np.uint64)
+    outs = {}
+    for route in ("0", "1"):
+        monkeypatch.setenv("POOLGEN_LOCUS_GROUPED", route)
+        outs[route] = [tuple(x.clone() for x in engine.ols_iterate(counts, ps, f, Y, raw=True)),
+                       tuple(x.clone() for x in engine.correlation(counts, ps, f, Y, raw=True)),
+                       tuple(x.clone() for x in engine.chisq(counts, ps, f, raw=True))]
+        loci, listed = engine.last_listed()
+        assert loci == L and listed > L // 2
+    for a, b in zip(outs["0"], outs["1"]):
+        n_out = a[0]
+        assert torch.equal(n_out, b[0])
+        for x, y in zip(a[1:], b[1:]):
+            if x.dim() == 1:
+                live = n_out > 0
+            else:
+                live = torch.arange(x.shape[0], device="cuda")[:, None] < n_out[None, :]
+                if x.dim() == 3:
+                    live = live[:, :, None].expand_as(x)
+            same = (x == y) | (torch.isnan(x) & torch.isnan(y)) if x.is_floating_point() else (x == y)
+            assert bool(same[live].all())
+    monkeypatch.setenv("POOLGEN_LOCUS_GROUPED", "1")
+    check_stat_op(engine.ols_iterate(counts, ps, f, Y), oracle.ols_iterate_locus, rows[:1500], Y, ps, fo, oracle=oracle)
