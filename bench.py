@@ -569,6 +569,32 @@ def worker(args):
             ls_ms, ls_n = eng.profile_get("sweep")
             legs[tag] = dict(m=int(lm), ms_per_step=ldt / extra * 1e3, kin_avg=lk_ms / max(lk_n, 1),
                              sw_avg=ls_ms / max(ls_n, 1), sw_n=int(ls_n))
+    # ---- the lazy-kinship route (labelled, NEVER the headline): K_out = NULL lets the library decide m = 0 from a bound that needs no K ----
+    lazy = None
+    if world == 1 and extra > 0 and args.force_m < 0:
+        try:
+            eng.ols_with_covariate(G, Y, args.var_explained, n=n, out=out, want_K=False)
+            eng.profile_reset()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(extra):
+                lm = eng.ols_with_covariate(G, Y, args.var_explained, n=n, out=out, want_K=False)[0]
+            fence()
+            ldt = (time.perf_counter() - t1) / extra
+            lk_ms, lk_n = eng.profile_get("kinship")
+            ls_ms, ls_n = eng.profile_get("sweep")
+            sb = (8.0 * n + 24.0 * k) * p_local
+            lazy = {"what": "NOT the headline: pg_ols_kinship_dev with K_out = NULL.  The n_eigenvecs rule (gwas/ols.rs:297-311) gives m = 0 "
+                            "as soon as lambda_1 / trace(K) >= x, and lambda_1 >= 1'K1 / n = sum_l (sum_i g_li)^2 / n; the intercept-only sweep "
+                            "forms that bound on the side, K is never built, one HBM-bound pass.  Outputs bit-identical to the two-pass route "
+                            "(tests/test_gpu_kinship_path.py::test_lazy_kinship_route); the headline value and roofline keep forming K on "
+                            "the matrix cores as north_star specifies",
+                    "n_eigenvecs": int(lm), "ms_per_step": ldt * 1e3, "loci_per_s": p_total / ldt, "kinship_launches": int(lk_n),
+                    "sweep_avg_ms": ls_ms / max(ls_n, 1), "sweep_launches": int(ls_n), "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "achieved": sb / (ls_ms / max(ls_n, 1) * 1e-3) / 1e9 if ls_n else None,
+                    "frac": sb / (ls_ms / max(ls_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if ls_n else None}
+        except Exception as e:
+            lazy = {"error": f"{type(e).__name__}: {e}"}
     # ---- rank-shaped probe and the PCIe-inclusive leg: after the timed region, 1 GPU only, bounded ----
     shard_probe = None
     if world == 1 and not args.no_shard_probe and args.force_m < 0:
@@ -686,6 +712,8 @@ def worker(args):
                 if op in co and int(args.secondary_loci) == 1_000_000:
                     co[op]["traffic"] = traffic_db.get(key)
             rec["secondary"] = secondary
+        if lazy:
+            rec.setdefault("secondary", {"what": "untimed legs after the headline region"})["lazy_kinship"] = lazy
         if world == 1 and not args.no_cpu_baseline:
             s = min(args.cpu_sample, p_local)
             rec["cpu_baseline"] = cpu_baseline(G[:s, :n].cpu().numpy(), Y, args.var_explained, args.force_m)

@@ -111,6 +111,12 @@ int pg_covariates_set(pg_ctx *ctx, int n, const double *C, int m, const double *
 /* beta/var/pval: p x k row-major on the device; NaN where the reference's fit fails. */
 int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
                      double *beta_dev, double *var_dev, double *pval_dev);
+/* All three stages in one call.  K_out (host, n x n) is optional, and leaving it NULL (with force_m < 0) permits the LAZY route:
+ * the n_eigenvecs rule (gwas/ols.rs:297-311) yields m = 0 as soon as lambda_1 / trace(K) >= var_explained, and
+ * lambda_1 >= 1'K1 / n = sum_l (sum_i g_li)^2 / (n p) for any K, so when that bound clears var_explained by 1e-9 (an uncentred
+ * kinship of allele frequencies: always) the intercept-only sweep alone -- ONE pass over G, no kinship matrix -- gives the
+ * analysis' beta / var / pval (bit-identical to pg_kinship_partial_dev + pg_kinship_set + pg_ols_sweep_dev without fused sums);
+ * otherwise the full route runs.  POOLGEN_NO_LAZY_KINSHIP=1 disables it. */
 int pg_ols_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld,
                        const double *Y, int k, double var_explained, int force_m, int *m_out,
                        double *K_out, double *beta_dev, double *var_dev, double *pval_dev);

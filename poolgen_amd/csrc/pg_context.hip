@@ -70,6 +70,7 @@ extern "C" void pg_destroy(pg_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->W_dev) (void)hipFree(ctx->W_dev);
     if (ctx->S_dev) (void)hipFree(ctx->S_dev);
+    if (ctx->lz_dev) (void)hipFree(ctx->lz_dev);
     if (ctx->ph_ytil_dev) (void)hipFree(ctx->ph_ytil_dev);
     if (ctx->spec_dev) (void)hipFree(ctx->spec_dev);
     if (ctx->syy_dev) (void)hipFree(ctx->syy_dev);

@@ -52,6 +52,7 @@ struct SweepDims {
     int n, m1, k, tdf, ntcoef;
     int colmajor; // k_gp_beta*: out is k x p instead of p x k
     double *ss;   // k_gp_beta: if set, sum of squares of every row (the MLE path's g'g)
+    double *lz;   // k_ols_sweep_mfma MODE 2: per wave (sum over its loci of (sum_i g_i)^2, sum over its loci of sum_i g_i^2)
     double dfe; // n - P as f64 (ols.rs:103)
     double tau; // relative singularity threshold on s_gg / g'g
 };
@@ -441,6 +442,8 @@ __device__ __forceinline__ void ms_static_for(F &&f) {
 
 // MODE 0: the regression sweep.  MODE 1: the products alone (gp::ols slopes, pg_gp_beta_cols): out = G Z for D.k columns, row-
 // or column-major, no shift, optionally the rows' sums of squares in D.ss; `beta` is the output, the other pointers unused.
+// MODE 2: the intercept-only sweep (m = 0) that also leaves, per wave, sum_l (sum_i g_li)^2 and sum_l sum_i g_li^2 = 1'S1 and
+// trace(S) of the kinship sums S = sum_l g_l g_l' it never forms (the lazy-kinship route of pg_ols_kinship_dev).
 template <int U, int R, int NCG, int MODE>
 __global__ __launch_bounds__(ms_threads(NCG), 1) void k_ols_sweep_mfma(
     const double *__restrict__ G, const double *__restrict__ W, const double *__restrict__ syy,
@@ -493,13 +496,15 @@ __global__ __launch_bounds__(ms_threads(NCG), 1) void k_ols_sweep_mfma(
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) acc[cg] = ms_d4{0.0, 0.0, 0.0, 0.0};
     double s2 = 0.0, shift = 0.0;
+    double lz1 = 0.0, lz2 = 0.0; // MODE 2
+    const double lz_invq = (MODE == 2) ? 1.0 / W[0] : 0.0;
     auto as_f64 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
 
     auto products = [&](uint4_t (&v)[U], const double2 (&bq)[NCG][U], const MsCursor &c, auto masked) {
         ms_static_for<U>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             double ga = as_f64(v[u].x, v[u].y), gb = as_f64(v[u].z, v[u].w);
-            if constexpr (MODE == 0) { ga -= shift; gb -= shift; }
+            if constexpr (MODE != 1) { ga -= shift; gb -= shift; }
             if (decltype(masked)::value) { // the group that holds the row's end: pools n .. are not this locus's
                 const int pl = 8 * (U * c.g + u) + 2 * lk;
                 ga = pl < D.n ? ga : 0.0;
@@ -524,7 +529,10 @@ __global__ __launch_bounds__(ms_threads(NCG), 1) void k_ols_sweep_mfma(
 #pragma unroll
                 for (int u = 0; u < U; ++u) bq[cg][u] = wl[(size_t)(cg * ncp + u) * 64];
         }
-        if (MODE == 0 && c.g == 0) shift = __shfl(as_f64(v[0].x, v[0].y), li); // any per-locus constant cancels because Z contains the intercept
+        if (MODE != 1 && c.g == 0) shift = __shfl(as_f64(v[0].x, v[0].y), li); // any per-locus constant cancels because Z contains the intercept
+        if constexpr (MODE == 2) { // the closing lane of this locus wants it back (no load there: it would wait for the whole ring)
+            if (c.g == 0 && lk == 0) stage[(16 * c.T + li) * M.pitch + M.cu + 1] = shift;
+        }
         if (c.g != M.ng - 1) {
             products(v, bq, c, std::false_type{});
             return;
@@ -561,6 +569,14 @@ __global__ __launch_bounds__(ms_threads(NCG), 1) void k_ols_sweep_mfma(
             const double gg = sr[M.cu];
             const double sgg = gg - uu;
             const bool bad = !(sgg > D.tau * gg);
+            if constexpr (MODE == 2) {
+                // g = g' + g0 with g0 the locus' first value: sum g = sum g' + n g0, sum g^2 = sum g'^2 + 2 g0 sum g' + n g0^2, and
+                // sum g' = u / q with u = sr[0] the product with the constant column q = W[0][0] = +-1 / sqrt(n) of the basis
+                const double g0 = sr[M.cu + 1], s1 = sr[0] * lz_invq, nn = (double)D.n;
+                const double sg = fma(nn, g0, s1);
+                lz1 = fma(sg, sg, lz1);
+                lz2 += fma(nn * g0, g0, fma(2.0 * g0, s1, gg));
+            }
             if (D.k == 1) { // straight-line code and ordinary stores
                 double b = sgg, vb = gg, pv = uu;
                 if (!(M.exp & 1)) ols_close(sgg, sr[D.m1], syy[0], bad, D.dfe, D.tdf, tcoef, D.ntcoef, b, vb, pv);
@@ -596,6 +612,15 @@ __global__ __launch_bounds__(ms_threads(NCG), 1) void k_ols_sweep_mfma(
             advance(cc);
             issue(v[r], ci);
             advance(ci);
+        }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { lz1 += __shfl_xor(lz1, off); lz2 += __shfl_xor(lz2, off); }
+        if (lane == 0) {
+            double *o = D.lz + 2 * ((int64_t)blockIdx.x * (ms_threads(NCG) / 64) + wave);
+            o[0] = lz1;
+            o[1] = lz2;
         }
     }
 }
@@ -982,7 +1007,7 @@ int launch_sweep_mfma(pg_ctx *ctx, const SweepArgs &A, int cols, int cu, int ker
     M.nc = (A.D.n + 7) / 8;
     M.cols = cols;
     M.cu = cu;
-    M.pitch = (cu + 1) | 1;
+    M.pitch = (MODE == 2) ? ((cu + 2) | 1) : ((cu + 1) | 1); // MODE 2 keeps the locus' shift behind the sums
     M.n64 = (A.D.p + 63) / 64;
     const int U = ms_pick_u(M.nc);
     const int ncg = (cu + 15) / 16;
@@ -999,6 +1024,14 @@ int launch_sweep_mfma(pg_ctx *ctx, const SweepArgs &A, int cols, int cu, int ker
             if (ncg == 1 && U == 8 && r == 2) return launch_sweep_mfma_as<8, 2, 1, 0>(ctx, A, M, kernel_id);
         }
     }
+    if constexpr (MODE == 2) { // intercept + traits only: one accumulator
+        switch (U) {
+        case 5: return launch_sweep_mfma_as<5, 3, 1, 2>(ctx, A, M, kernel_id);
+        case 6: return launch_sweep_mfma_as<6, 3, 1, 2>(ctx, A, M, kernel_id);
+        case 7: return launch_sweep_mfma_as<7, 3, 1, 2>(ctx, A, M, kernel_id);
+        default: return launch_sweep_mfma_as<8, 3, 1, 2>(ctx, A, M, kernel_id);
+        }
+    } else
     switch (U) { // ring depth: 3 with one accumulator (205-223 registers at U = 7, 8), 2 for U >= 7 with more (measured: +2 % at n = 500)
     case 5: MS_GO(5, 3, 3)
     case 6: MS_GO(6, 3, 3)
@@ -1289,6 +1322,7 @@ extern "C" int pg_ols_sweep_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int
     P.D.tau = 1e-12;
     P.D.colmajor = 0;
     P.D.ss = nullptr;
+    P.D.lz = nullptr;
     if (ctx->st_m == 0 && ctx->spec_valid && ctx->spec_G == G_dev && ctx->spec_p == p && ctx->spec_n == n &&
         ctx->spec_ld == ld && ctx->spec_k == ctx->st_k && ctx->ph_n == n && ctx->st_Y_matches_ph) {
         // m = 0: the kinship pass already formed the sums of the intercept-only fits from its read of G
@@ -1333,6 +1367,48 @@ extern "C" int pg_ols_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
                                   double *pval_dev) {
     if (!ctx) return PG_ERR_INVALID;
     PG_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    // ---- the lazy route: a caller that does not want K may not need it formed at all ----------------------------------------------
+    // The rule of gwas/ols.rs:297-311 returns m = 0 as soon as lambda_1 / trace(K) >= x, and lambda_1 >= 1'K1 / n for any K: with
+    // K = S / p that is (sum_l (sum_i g_li)^2 / n) / (sum_l sum_i g_li^2), two numbers the intercept-only sweep can form on the side.
+    // One HBM-bound pass then gives the outputs of the m = 0 analysis (the sweep kernel's own: bit-identical to the two-pass
+    // route); if the bound does not clear x by 1e-9 -- never on an uncentred kinship of real frequencies -- the full route below runs.
+    if (!K_out && force_m < 0 && G_dev && Y && beta_dev && var_dev && pval_dev && p > 0 && n >= 3 && k >= 1 && k <= 15 && ld >= n &&
+        (ld % 2) == 0 && (reinterpret_cast<uintptr_t>(G_dev) & 15) == 0 && ms_fits(n, 1 + k) && !std::getenv("POOLGEN_NO_LAZY_KINSHIP")) {
+        rc = pg_covariates_set(ctx, n, nullptr, 0, Y, k);
+        if (rc) return rc;
+        const size_t lzbytes = sizeof(double) * 2 * (size_t)ctx->cus * 8 * 2; // a workgroup per CU (launch bounds), 8 waves each; twice that
+        if (!ctx->lz_dev) PG_HIP(ctx, hipMalloc((void **)&ctx->lz_dev, lzbytes));
+        PG_HIP(ctx, hipMemsetAsync(ctx->lz_dev, 0, lzbytes, ctx->stream));
+        SweepArgs P;
+        P.G = G_dev; P.W = ctx->W_dev; P.syy = ctx->syy_dev; P.tcoef = ctx->tcoef_dev;
+        P.beta = beta_dev; P.var = var_dev; P.pval = pval_dev;
+        std::memset(&P.Q, 0, sizeof P.Q);
+        P.D.p = p; P.D.ld = ld; P.D.ntiles = 0;
+        P.D.n = n; P.D.m1 = 1; P.D.k = k;
+        P.D.tdf = ctx->tcoef_df; P.D.ntcoef = ctx->tcoef_len;
+        P.D.dfe = (double)n - 2.0;
+        P.D.tau = 1e-12;
+        P.D.colmajor = 0;
+        P.D.ss = nullptr;
+        P.D.lz = ctx->lz_dev;
+        rc = launch_sweep_mfma<2>(ctx, P, ctx->st_cols, 1 + k, PG_K_SWEEP);
+        if (rc) return rc;
+        rc = pg_pin_reserve(ctx, lzbytes);
+        if (rc) return rc;
+        PG_HIP(ctx, hipMemcpyAsync(ctx->pin, ctx->lz_dev, lzbytes, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double *hp = static_cast<const double *>(ctx->pin);
+        double tot = 0.0, tr = 0.0;
+        for (size_t w = 0; w < lzbytes / 16; ++w) { tot += hp[2 * w]; tr += hp[2 * w + 1]; }
+        if (tr > 0.0 && std::isfinite(tot) && (tot / n) / tr >= var_explained + 1e-9) {
+            if (m_out) *m_out = 0;
+            ctx->lazy_taken = true;
+            return PG_OK;
+        }
+        // (a NaN frequency, or a kinship whose leading share is not decided by the ones vector: the full route says what the reference says)
+    }
+    ctx->lazy_taken = false;
     if (ctx->S_n < n) {
         PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->S_dev) PG_HIP(ctx, hipFree(ctx->S_dev));
@@ -1342,7 +1418,7 @@ extern "C" int pg_ols_kinship_dev(pg_ctx *ctx, const double *G_dev, int64_t p, i
         ctx->S_n = n;
     }
     double *S_dev = ctx->S_dev;
-    int rc = pg_set_phenotypes(ctx, n, Y, k);
+    rc = pg_set_phenotypes(ctx, n, Y, k);
     if (rc) return rc;
     rc = pg_launch_kinship(ctx, G_dev, p, n, ld, S_dev, false, PG_K_KINSHIP, true);
     if (rc) return rc;
@@ -1506,6 +1582,7 @@ int pg_gp_beta_cols(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t 
     std::memset(&D, 0, sizeof D);
     D.p = p; D.ld = ld; D.ntiles = (p + 63) / 64; D.n = n; D.k = ncol; D.colmajor = colmajor;
     D.ss = ss_out_dev; // (only the scalar-operand kernel below writes it)
+    D.lz = nullptr;
     int64_t blocks = (D.ntiles + SW_WAVES - 1) / SW_WAVES;
     const int64_t cap = (int64_t)ctx->cus * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);

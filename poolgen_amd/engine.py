@@ -205,17 +205,19 @@ class Engine:
         return out[0], out[1], out[2]
 
     def ols_with_covariate(self, G: torch.Tensor, Y, var_explained: float = 0.75, force_m: int = -1,
-                           n: int | None = None, out=None):
-        """Single-GPU ols_iter_with_kinship numeric core.  Returns (m, K, beta, var, pval)."""
+                           n: int | None = None, out=None, want_K: bool = True):
+        """Single-GPU ols_iter_with_kinship numeric core.  Returns (m, K, beta, var, pval).  want_K=False passes K_out = NULL:
+        the library may then decide m = 0 from a bound that needs no kinship matrix (the lazy route, include/poolgen_hip.h)."""
         p, ld, n = self._g_dims(G, n)
         Yh = _host_f64(Y).reshape(n, -1)
         k = Yh.shape[1]
         if out is None:
             out = torch.empty((3, p, k), dtype=torch.float64, device=G.device)
-        K = np.empty((n, n)); m = C.c_int()
+        K = np.empty((n, n)) if want_K else None
+        m = C.c_int()
         self._check(self._lib.pg_ols_kinship_dev(self._ctx, self._dev(G, torch.float64), p, n, ld,
                                                  Yh.ctypes.data, k, float(var_explained), int(force_m),
-                                                 C.byref(m), K.ctypes.data, out[0].data_ptr(),
+                                                 C.byref(m), K.ctypes.data if want_K else None, out[0].data_ptr(),
                                                  out[1].data_ptr(), out[2].data_ptr()),
                     "pg_ols_kinship_dev")
         return m.value, K, out[0], out[1], out[2]

@@ -278,6 +278,42 @@ def test_full_size_properties(engine):
     assert torch.allclose(b2[sl, 0], bt, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("p,n,k", [(20000, 200, 1), (7001, 100, 2), (513, 40, 3)])
+def test_lazy_kinship_route(engine, oracle, p, n, k, monkeypatch):
+    """pg_ols_kinship_dev with K_out = NULL: m = 0 is decided from lambda_1 / trace >= (1'K1 / n) / trace(K) (gwas/ols.rs:297-311
+    returns 0 as soon as the leading share reaches x), two sums the intercept-only sweep forms on the side -- K is never built.
+    Outputs bit-identical to the two-pass route (same sweep kernel), the oracle's at 1e-10; a matrix whose ones-vector bound does
+    not clear x takes the full route and gives what the full route gives."""
+    G, Y = make(p, n, 53)
+    Y = np.hstack([Y, Y[:, :1] ** 2])[:, :k]
+    m, K, beta, var, pv = engine.ols_with_covariate(G, Y, 0.75, want_K=False, n=n)
+    torch.cuda.synchronize()
+    assert m == 0 and K is None
+    lazy = tuple(x.clone() for x in (beta, var, pv))
+    engine.set_phenotypes(None)
+    engine.covariates_set(n, None, Y)
+    two = engine.ols_sweep(G, k, n)
+    for a, b in zip(lazy, two):
+        assert torch.equal(a, b), "lazy route vs the two-pass route: same kernel, same bits"
+    ref = oracle.ols_with_covariate(G.cpu().numpy(), Y, 0.75, n=n)
+    assert ref["m"] == 0
+    cmp_fit(lazy, ref, "lazy route")
+    # the switch: with it the full route runs and (m = 0) agrees at 1e-10 (fused sums: other arithmetic)
+    monkeypatch.setenv("POOLGEN_NO_LAZY_KINSHIP", "1")
+    m2, _, b2, v2, p2 = engine.ols_with_covariate(G, Y, 0.75, want_K=False, n=n)
+    assert m2 == 0
+    cmp_fit((b2, v2, p2), ref, "full route without K")
+    monkeypatch.delenv("POOLGEN_NO_LAZY_KINSHIP")
+    # a matrix the bound cannot decide: signed entries, the ones vector explains ~1/n of the trace
+    Gs = torch.randn(4000, n + (n & 1), dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    Gs[:, n:] = 0.0
+    ml, _, bl, vl, pl = engine.ols_with_covariate(Gs, Y, 0.2, want_K=False, n=n)
+    mf, Kf, bf, vf, pf = engine.ols_with_covariate(Gs, Y, 0.2, want_K=True, n=n)
+    assert ml == mf and ml >= 1
+    for a, b in zip((bl, vl, pl), (bf, vf, pf)):
+        assert torch.equal(a, b)
+
+
 FULL_SLICES = ((0, 4096), (5_000_000 - 2048, 5_000_000 + 2048), (10_000_000 - 4096, 10_000_000))   # first, middle, last slab
 
 
