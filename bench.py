@@ -119,7 +119,7 @@ def secondary_legs(eng, dev, args, torch, np):
                     "sync columns with that probability; frac = 24 n bytes per locus / (streaming pass + second pass device time) / 8 TB/s; "
                     "deferred_fraction = loci handed to the second pass",
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_locus": 24.0 * n1}
-    for tag, err, maf, note in (
+    for tag, err, maf, note in () if args.no_realistic else (
             ("error_0.005_maf_0.01", 0.005, 0.01, "the headline case of this leg: --min-allele-frequency 0.01 drops every error allele (pooled frequency 0.001 "
                                                   "each), every locus stays biallelic with stray reads in ~20 % of its pools"),
             ("error_0.001_default_filter", 0.001, 0.001, "CLI default filter (maf 0.001): error alleles at 0.0002 each are dropped"),
@@ -129,9 +129,10 @@ def secondary_legs(eng, dev, args, torch, np):
         counts = synth.sync_counts(L1, n1, dev, error_rate=err)
         real[tag] = {"error_rate": err, "min_allele_frequency": maf, "note": note, **run_ops(counts, Filter(min_allele_frequency=maf))}
         del counts
-    for op in ("ols_iter", "pearson_corr", "chisq_test"):   # the leg's own figures = its headline case
-        real[op] = real["error_0.005_maf_0.01"][op]
-    sec["count_operators_realistic"] = real
+    if not args.no_realistic:
+        for op in ("ols_iter", "pearson_corr", "chisq_test"):   # the leg's own figures = its headline case
+            real[op] = real["error_0.005_maf_0.01"][op]
+        sec["count_operators_realistic"] = real
     # configs[3]: ridge path (alpha = 0), 11 lambda, 10 repetitions x 10 folds, folds fixed by fold[i] = (i + rep) mod 10
     n3, p3, reps3, folds3 = 500, int(args.ridge_loci), 10, 10
     try:
@@ -303,6 +304,8 @@ def parse_args(argv=None):
                     help="skip the untimed BASELINE configs[1] / configs[3] legs (count operators 100 x 1M, ridge path 500 x 5M)")
     ap.add_argument("--secondary-loci", type=int, default=1_000_000, help="loci of the count-operator leg (configs[1]: 1M)")
     ap.add_argument("--ridge-loci", type=int, default=5_000_000, help="loci of the ridge leg (configs[3]: 5M)")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the count-operator legs on error-bearing counts")
+    ap.add_argument("--no-lazy", action="store_true", help="skip the labelled lazy-kinship leg")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-shard-probe", action="store_true",
                     help="skip the untimed rank-shaped legs (p_local = p/2, p/4, p/8 with a one-rank RCCL communicator)")
@@ -571,7 +574,7 @@ def worker(args):
                              sw_avg=ls_ms / max(ls_n, 1), sw_n=int(ls_n))
     # ---- the lazy-kinship route (labelled, NEVER the headline): K_out = NULL lets the library decide m = 0 from a bound that needs no K ----
     lazy = None
-    if world == 1 and extra > 0 and args.force_m < 0:
+    if world == 1 and extra > 0 and args.force_m < 0 and not args.no_lazy:
         try:
             eng.ols_with_covariate(G, Y, args.var_explained, n=n, out=out, want_K=False)
             eng.profile_reset()
