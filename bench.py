@@ -187,7 +187,8 @@ def shard_probe_legs(eng, G, Y, n, p_total, var_explained, steps, torch, np):
     own_comm = False
     try:
         if not getattr(eng, "_comm_ready", False):
-            eng.comm_init(eng.comm_unique_id(), 1, 0)
+            with _StdoutToStderr():
+                eng.comm_init(eng.comm_unique_id(), 1, 0)
             own_comm = True
         legs["comm_size"] = int(eng.comm_size)
         try:
@@ -315,6 +316,27 @@ def parse_args(argv=None):
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="seconds the self-launching parent of --gpus N > 1 waits for its rank processes before it kills them")
     return ap.parse_args(argv)
+
+
+class _StdoutToStderr:
+    """RCCL prints a version banner to the C-level stdout when a communicator is initialised; stdout is reserved for the ONE JSON
+    line.  While active, file descriptor 1 points at stderr, and libc's buffer is flushed before it is restored."""
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            self._libc.fflush(None)
+        finally:
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+        return False
 
 
 def _free_port() -> int:
@@ -462,10 +484,11 @@ def worker(args):
         # nccl == RCCL on ROCm.  POOLGEN_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
         # control flow on a single-GPU box (several ranks sharing cuda:0), never for measurements.
         backend = os.environ.get("POOLGEN_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
 
     from poolgen_amd import Engine, synth
     from poolgen_amd.distributed import ols_with_covariate_sharded, setup_comm, shard_range
@@ -481,7 +504,9 @@ def worker(args):
     if use_dist:
         # setup_comm answers the same on every rank (its stages end in agreements over torch.distributed), so either every
         # rank all-reduces inside the library or every rank uses dist.all_reduce -- never a mixture
-        if setup_comm(eng, force=force_dist):
+        with _StdoutToStderr():
+            comm_ok = setup_comm(eng, force=force_dist)
+        if comm_ok:
             allreduce_impl = "RCCL inside libpoolgen_hip (pg_allreduce_sum_dev)"
         else:
             allreduce_impl = f"FALLBACK torch.distributed all_reduce ({os.environ.get('POOLGEN_BENCH_BACKEND', 'nccl')}): " \

@@ -28,6 +28,7 @@ def test_single_gpu_line():
                         "--ridge-loci", "100000"], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, "stdout carries the ONE JSON line and nothing else (RCCL's banner goes to stderr)"
     assert NEED <= set(d) and "cpu_baseline" in d
     assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
     # the rank-shaped probe: a ONE-rank RCCL communicator inside the library, slabs of p/2, p/4, p/8 with K over p_total

@@ -115,15 +115,17 @@ python3 - <<'PY'
 import json, os, shutil
 tag = os.environ["TAG"]
 first, last = f"gpurun_out/{tag}_bench_first.json", f"gpurun_out/{tag}_bench_last.json"
+def line(f):
+    return json.loads([l for l in open(f) if l.startswith("{")][0])
 try:
-    fresh_first = not json.load(open(first))["roofline"].get("traffic_stale", True)
+    fresh_first = not line(first)["roofline"].get("traffic_stale", True)
 except Exception:
     fresh_first = False
-shutil.copy(first if fresh_first else last, f"gpurun_out/{tag}_bench.json")
+json.dump(line(first if fresh_first else last), open(f"gpurun_out/{tag}_bench.json", "w"))
 print("bench line kept:", "the first (counter file already matched the sources)" if fresh_first else "the last (taken with the new counter file)")
 for f in (first, last):
     try:
-        d = json.load(open(f)); print(f, "step %.3f ms" % d["ms_per_step"], "sweep %.3f ms" % d["roofline_sweep"]["two_pass"]["avg_ms"])
+        d = line(f); print(f, "step %.3f ms" % d["ms_per_step"], "sweep %.3f ms" % d["roofline_sweep"]["two_pass"]["avg_ms"])
     except Exception as e:
         print(f, "unreadable:", e)
 PY
