@@ -69,7 +69,8 @@ struct LocusParams {
 constexpr int LO_NB = 5;   // groups of the second pass' list: one per number of surviving alleles, 2 .. 6
 // words of the second pass' counter block: [0, LO_NB) loci per group | complaint flag | length of the list | (pad) | [SC_CURSOR, +LO_NB) the
 // sort's cursors
-constexpr int SC_COMPLAINT = LO_NB, SC_LIST = LO_NB + 1, SC_CURSOR = LO_NB + 3, SC_WORDS = 2 * LO_NB + 3;
+constexpr int SC_COMPLAINT = LO_NB, SC_LIST = LO_NB + 1, SC_DIRTY = LO_NB + 2, SC_CURSOR = LO_NB + 3, SC_WORDS = 2 * LO_NB + 3;
+// (SC_DIRTY: k_ols_rows counts the loci that carry reads of alleles the filter drops, or keep three alleles or more)
 constexpr int LO_GROUP_FROM = 1 << 17; // lists from this length on are grouped by the number of survivors (two more launches)
 
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
@@ -1543,6 +1544,385 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
     } while (false);
 }
 
+// ---- ols_iter, order-free (round 4): a LOCUS PER ROW OF LANES instead of a locus per lane ---------------------------------------
+// The streaming pass above reads with the lane-per-locus request pattern (0.68 - 0.74 of the HBM peak with nothing else going on) because
+// the filter's q must be summed in pool order.  ols_iter does not need that: its decisions (which alleles survive, which is the major
+// one, is the fit singular) must be the reference's, but its NUMBERS -- beta, p, the mean frequency it prints with 8 decimals -- only
+// to 1e-10.  So here a wave reads whole loci with plain coalesced 16-byte loads into a wave-private LDS buffer (a group of 64 / LPL loci,
+// <= 10.5 KB, the next group in registers meanwhile), LPL = 16 / 32 / 64 lanes share one locus (pool = round * LPL + lane), and the
+// sums are reduced over the lanes in a fixed butterfly order:
+//   phase 1  q~_j of every candidate allele, coverage minimum, missing pools -> the filter's decisions; a locus with some
+//            |q~ - threshold| <= qband has its q recomputed literally (pool order, multiply then add) from the buffer;
+//   phase 2  (exactly two survivors: the buffer is read again) frequencies over the SURVIVORS' coverage, sum f, sum f^2, sum f y of both.
+// No speculation is needed -- the survivors are known before the sums are taken -- so stray reads of dropped alleles cost nothing
+// here.  What stays with the exact second pass (k_locus_second, pool-order sums): three or more survivors, and the loci whose
+// decision could depend on the order of the sums: column sums of the two survivors within 1e-9 of each other (which one is the
+// major allele), a design within 1e-8 of singular (ols.rs:77-83).  pearson_corr and chisq_test print full-precision means and keep the
+// streaming pass.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+// all LPL lanes of a locus end up with the same total, combined in the same order (xor 1, 2, mirror in 8, mirror in 16, xor 16, xor 32)
+template <int LPL, typename T, typename OPF>
+__device__ __forceinline__ T row_all(T v, OPF op) {
+    if constexpr (std::is_same<T, double>::value) {
+        v = op(v, dpp_d<0xB1>(v)); v = op(v, dpp_d<0x4E>(v)); v = op(v, dpp_d<0x141>(v)); v = op(v, dpp_d<0x140>(v));
+    } else {
+        v = op(v, (T)dpp_i<0xB1>((int)v)); v = op(v, (T)dpp_i<0x4E>((int)v)); v = op(v, (T)dpp_i<0x141>((int)v)); v = op(v, (T)dpp_i<0x140>((int)v));
+    }
+    if constexpr (LPL >= 32) v = op(v, __shfl_xor(v, 16));
+    if constexpr (LPL >= 64) v = op(v, __shfl_xor(v, 32));
+    return v;
+}
+constexpr int RW_NP = 11;               // 16-byte pieces per lane and group: 11 KB >= 24 bytes x 448 pools (x 2 loci x 224, x 4 x 112)
+constexpr int RW_BUF = RW_NP * 1024;
+
+template <int LPL, bool RNS, int K>
+__global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
+    const uint32_t *__restrict__ counts, const double *__restrict__ wy, const double *__restrict__ tcoef,
+    int32_t *__restrict__ rec_flags, int64_t *__restrict__ second, unsigned long long *__restrict__ second_count,
+    const StreamOut O, const LocusParams P, const int coalesced) {
+    constexpr int NJ = RNS ? 5 : 6;
+    constexpr int GL = 64 / LPL;            // loci per group
+    constexpr int TW = 1 + K;
+    constexpr int RECB = 16 + 16 * K;
+    constexpr int NSUM = 2 + K;             // staged per locus: cs, sum f^2, sum f y_t of the design column
+    auto aj = [](int jj) { return (RNS && jj >= 4) ? jj + 1 : jj; };
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int PER_WAVE = RW_BUF + 64 * NSUM * 8 + 64 * 4 + 64 * RECB;
+    char *buf = lds_raw + wave * PER_WAVE;
+    double *sums = reinterpret_cast<double *>(buf + RW_BUF);
+    int32_t *hdrs = reinterpret_cast<int32_t *>(buf + RW_BUF + 64 * NSUM * 8);
+    char *stage = buf + RW_BUF + 64 * NSUM * 8 + 64 * 4;
+    const double *tab = reinterpret_cast<const double *>(lds_raw + LO_WAVES * PER_WAVE);
+    const int n = P.n;
+    const int64_t L = P.L;
+    const float *tabf = reinterpret_cast<const float *>(lds_raw + LO_WAVES * PER_WAVE + sizeof(double) * TW * n); // the weights in fp32
+    {
+        double *t = reinterpret_cast<double *>(lds_raw + LO_WAVES * PER_WAVE);
+        float *tf = reinterpret_cast<float *>(lds_raw + LO_WAVES * PER_WAVE + sizeof(double) * TW * n);
+        for (int i = threadIdx.x; i < TW * n; i += LO_THREADS) t[i] = wy[i];
+        for (int i = threadIdx.x; i < n; i += LO_THREADS) tf[i] = (float)wy[i * TW];
+        __syncthreads();
+    }
+    const uint32_t rowb = (uint32_t)n * 24u;
+    const uint32_t grpb = (uint32_t)GL * rowb;                 // bytes of a group: a multiple of 16 (GL n even: the host checked)
+    const uint64_t total_bytes = (uint64_t)L * rowb;
+    const uint64_t base0 = reinterpret_cast<uint64_t>(counts);
+    const int64_t nunits = (L + 63) / 64;
+    const int64_t wid = (int64_t)blockIdx.x * LO_WAVES + wave, wstride = (int64_t)gridDim.x * LO_WAVES;
+    if (wid >= nunits) return;
+    const int row = lane / LPL, li = lane % LPL;
+    const char *lbase = buf + (uint32_t)row * rowb;
+
+    // ---- the request side: the next group's 16-byte pieces wait in registers while the current group is summed -----------------------
+    uint4_t SR[RW_NP];
+    int64_t pre_u = wid;
+    int pre_g = 0;
+    auto issue_group = [&]() {
+        const uint64_t go = ((uint64_t)pre_u * 64u + (uint64_t)pre_g * GL) * rowb; // (past the batch: the descriptor answers with zeros)
+        const uint64_t left = total_bytes > go ? total_bytes - go : 0;
+        const uint64_t lim = left < grpb ? left : grpb;                          // this group's bytes only: the rest of the buffer stays zero
+        const uint64_t ub = base0 + (left ? go : 0);
+        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((lim + 15u) & ~(uint64_t)15));
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ub >> 32));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < RW_NP; ++i) SR[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)lane * 16u + (uint32_t)i * 1024u, 0, 0);
+        if (++pre_g >= LPL) { pre_g = 0; pre_u += wstride; }
+    };
+    auto land_group = [&]() {
+#pragma unroll
+        for (int i = 0; i < RW_NP; ++i) *reinterpret_cast<uint4_t *>(buf + lane * 16 + i * 1024) = SR[i];
+    };
+    auto add = [](double a, double b) { return a + b; };
+    auto addi = [](int a, int b) { return a + b; };
+    auto mini = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+
+    uint32_t orm_unit = 0;
+    int ndirty = 0;
+    issue_group();
+    for (int64_t unit = wid; unit < nunits; unit += wstride) {
+        for (int g = 0; g < LPL; ++g) {           // the 64 / GL groups of the unit
+            __builtin_amdgcn_wave_barrier();
+            land_group();
+            __builtin_amdgcn_wave_barrier();
+            issue_group();
+            const int lu = g * GL + row;          // this row's locus inside the unit
+            const int64_t l = unit * 64 + lu;
+            // ---- phase 1: the filter, in SINGLE precision ---------------------------------------------------------------------------------
+            // q~_j = sum_i c_ij * (w_i / rs_i) in fp32 is within (n + 4) 2^-24 < 3e-5 of q_j relative (positive terms): it decides every
+            // locus whose q stay 2e-4 (relative) away from both thresholds -- practically all -- at a quarter of the fp64 cost; the others
+            // get the literal fp64 evaluation below.  q~ == 0 means "no read at all" exactly, whatever the precision.
+            float q[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) q[j] = 0.0f;
+            uint32_t mincov = 0xffffffffu, orv = 0u;
+            int nmiss = 0;
+            auto p1_pool = [&](const int pool) { // one pool of this lane (pool < n)
+                const char *pp = lbase + pool * 24;
+                const uint2_t w0 = *reinterpret_cast<const uint2_t *>(pp), w1 = *reinterpret_cast<const uint2_t *>(pp + 8),
+                              w2 = *reinterpret_cast<const uint2_t *>(pp + 16);
+                const float wi = tabf[pool];
+                const uint32_t c0[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                uint32_t rsi = c0[aj(0)], o2 = c0[aj(0)];
+#pragma unroll
+                for (int j = 1; j < NJ; ++j) { rsi += c0[aj(j)]; o2 |= c0[aj(j)]; }
+                orv |= o2;
+                mincov = rsi < mincov ? rsi : mincov;
+                nmiss += (rsi == 0u) ? 1 : 0;
+                const float wr = wi * __builtin_amdgcn_rcpf((float)(rsi > 1u ? rsi : 1u));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) q[j] = fmaf((float)c0[aj(j)], wr, q[j]);
+            };
+            {
+                const int full = n / LPL;          // rounds in which every lane has a pool
+#pragma unroll 2
+                for (int t = 0; t < full; ++t) p1_pool(t * LPL + li);
+                if (full * LPL + li < n) p1_pool(full * LPL + li); // the last, partial round
+            }
+            {
+                auto addf = [](int x, int y) { return __float_as_int(__int_as_float(x) + __int_as_float(y)); };
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) q[j] = __int_as_float(row_all<LPL>(__float_as_int(q[j]), addf));
+            }
+            mincov = row_all<LPL>(mincov, mini);
+            {   // missing pools (<= 448) and "a count of 2^29 or more" in one word
+                int pk = nmiss | (((orv >> 29) != 0u) ? (1 << 16) : 0);
+                pk = row_all<LPL>(pk, addi);
+                nmiss = pk & 0xffff;
+                orm_unit |= (l < L && (pk >> 16) != 0) ? (1u << 29) : 0u;
+            }
+            int slotmask = 0;
+            bool band = false;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const double qd = (double)q[j];
+                slotmask |= !((qd < P.maf) | (qd > (1.00 - P.maf))) ? (1 << j) : 0;
+                band = band || (q[j] != 0.0f && (fabs(qd - P.maf) <= 2e-4 * P.maf || fabs(qd - (1.00 - P.maf)) <= 2e-4));
+            }
+            if (__any(band && l < L)) { // the literal q (sync.rs:258-271) of a locus inside the band: every lane of its row, redundantly
+                if (band && l < L) {
+                    double qe[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) qe[j] = 0.0;
+                    for (int i = 0; i < n; ++i) {
+                        const char *pp = lbase + i * 24;
+                        const uint2_t w0 = *reinterpret_cast<const uint2_t *>(pp), w1 = *reinterpret_cast<const uint2_t *>(pp + 8),
+                                      w2 = *reinterpret_cast<const uint2_t *>(pp + 16);
+                        const uint32_t c0[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                        uint32_t rs = 0u;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) rs += c0[aj(j)];
+                        const double rsd = (double)(rs > 1u ? rs : 1u);
+                        const double ri = recip_for_div(rsd);
+                        const double wi = tab[i * TW];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) qe[j] = qe[j] + div_by((double)c0[aj(j)], rsd, ri) * wi;
+                    }
+                    slotmask = 0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        slotmask |= !((qe[j] < P.maf) | (qe[j] > (1.00 - P.maf))) ? (1 << j) : 0;
+                        q[j] = (float)qe[j];
+                    }
+                }
+            }
+            int nk = 0, keepmask = 0, sa = 0, sb = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool kpj = (slotmask >> j) & 1;
+                sa = (kpj && nk == 0) ? j : sa;
+                sb = (kpj && nk == 1) ? j : sb;
+                nk += kpj ? 1 : 0;
+                keepmask |= kpj ? (2 << aj(j)) : 0;
+            }
+            bool alive = !((double)mincov < P.min_cov);                           // sync.rs:227
+            alive = alive && nk >= 2;                                             // sync.rs:284
+            alive = alive && nmiss != n;                                          // sync.rs:293
+            alive = alive && !(((double)nmiss / (double)n) > P.max_miss);         // sync.rs:297
+            alive = alive && l < L;
+            bool deferred = alive && nk >= 3; // the joint fit of several alleles: cross products, pool-order sums (second pass)
+            int hdr = 0;
+            {   // what the lane-per-locus streaming pass could not close from clean sums: told to the host, which picks the kernel of the
+                // NEXT batch by it (run_locus_op)
+                bool stray = nk >= 3;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) stray = stray || (!((slotmask >> j) & 1) && q[j] != 0.0f);
+                ndirty += (alive && stray && li == 0) ? 1 : 0;
+            }
+            // ---- phase 2: exactly two survivors a < b -- frequencies over THEIR coverage (gwas/ols.rs:210-230 -> sync.rs:166-192) ---------
+            // The design column is the MINOR allele (stable sort by decreasing column sum, sync.rs:477-506; the major one is dropped,
+            // ols.rs:227-230).  The sums are taken for the allele phase 1 saw as the rarer one; f_a + f_b = 1 in every covered pool, so
+            // the other allele's sums follow from them should the column sums say otherwise (both are then near 1/2: no cancellation).
+            if (__any(alive && nk == 2)) {
+                float qa = q[0], qb = q[0];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { qa = (sa == j) ? q[j] : qa; qb = (sb == j) ? q[j] : qb; }
+                const bool m_is_b = qb < qa;                     // the allele summed: m
+                int oa = 0, ob = 0;                              // byte offsets of the survivors' counts inside a pool
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { oa = (sa == j) ? 4 * aj(j) : oa; ob = (sb == j) ? 4 * aj(j) : ob; }
+                const int om = m_is_b ? ob : oa, oo = m_is_b ? oa : ob;
+                double csm = 0.0, ddm = 0.0, xym[K];
+#pragma unroll
+                for (int t = 0; t < K; ++t) xym[t] = 0.0;
+                int nmiss2 = 0;
+                auto p2_pool = [&](const int pool) {
+                    const char *pp = lbase + pool * 24;
+                    const uint32_t cm = *reinterpret_cast<const uint32_t *>(pp + om), co = *reinterpret_cast<const uint32_t *>(pp + oo);
+                    const uint32_t rs2 = cm + co;
+                    nmiss2 += (rs2 == 0u) ? 1 : 0;
+                    // c / rs to a few ulp: the hardware reciprocal and ONE Newton step (these sums need 1e-10, not the last bit)
+                    const double rsd2 = (double)(rs2 > 1u ? rs2 : 1u);
+                    const double r0 = __builtin_amdgcn_rcp(rsd2);
+                    const double f = (double)cm * fma(fma(-rsd2, r0, 1.0), r0, r0);
+                    csm += f;
+                    ddm = fma(f, f, ddm);
+#pragma unroll
+                    for (int tt = 0; tt < K; ++tt) xym[tt] = fma(f, tab[pool * TW + 1 + tt], xym[tt]);
+                };
+                {
+                    const int full = n / LPL;
+#pragma unroll 2
+                    for (int t = 0; t < full; ++t) p2_pool(t * LPL + li);
+                    if (full * LPL + li < n) p2_pool(full * LPL + li);
+                }
+                csm = row_all<LPL>(csm, add);
+                ddm = row_all<LPL>(ddm, add);
+#pragma unroll
+                for (int t = 0; t < K; ++t) xym[t] = row_all<LPL>(xym[t], add);
+                nmiss2 = row_all<LPL>(nmiss2, addi);
+                if (alive && nk == 2) {
+                    const double ncov = (double)(n - nmiss2);
+                    const double cso = ncov - csm;                              // the other survivor's column sum
+                    // decisions that could depend on the ORDER of the sums go to the pool-order second pass: which allele is the major
+                    // one (column sums within 1e-9 n), a design within 1e-8 of singular (ols.rs:77-83), derived sums with uncovered pools
+                    const bool close_call = fabs(csm - cso) <= 1e-9 * (double)n;
+                    const bool swap = cso < csm;                                 // phase 1's guess was the major allele after all
+                    double csd = csm, ddd = ddm, xyd[K];
+#pragma unroll
+                    for (int t = 0; t < K; ++t) xyd[t] = xym[t];
+                    if (swap) {
+                        csd = cso;
+                        ddd = ncov - 2.0 * csm + ddm;
+#pragma unroll
+                        for (int t = 0; t < K; ++t) xyd[t] = P.sy[t] - xym[t];
+                    }
+                    const double det = (double)n * ddd - csd * csd;                 // of the 2 x 2 normal matrix, up to rounding
+                    const bool near_singular = !(det > 1e-8 * (double)n * ddd);
+                    deferred = close_call || near_singular || (swap && nmiss2 > 0);
+                    const bool d_is_b = swap ? !m_is_b : m_is_b;
+                    int idc = 0;
+                    const int dslot = d_is_b ? sb : sa;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) idc = (dslot == j) ? aj(j) : idc;
+                    hdr = 1 | (nmiss2 > 0 ? 2 : 0) | (idc << 4);
+                    if (li == 0 && !deferred) {
+                        sums[lu * NSUM] = csd;
+                        sums[lu * NSUM + 1] = ddd;
+#pragma unroll
+                        for (int tt = 0; tt < K; ++tt) sums[lu * NSUM + 2 + tt] = xyd[tt];
+                    }
+                }
+            }
+            if (li == 0) {
+                hdrs[lu] = deferred ? 0x100 : hdr; // bit 0: close in place | bit 1: a pool uncovered over the survivors | 4..6 allele | 8: listed
+                if (deferred) rec_flags[l] = FLAG_ALIVE | keepmask | FLAG_SECOND | (nk << H_NK_SHIFT);
+            }
+        }
+        // ---- the unit's 64 loci: lane = locus -- close, list, write -------------------------------------------------------------------
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int64_t l = unit * 64 + lane;
+            const int hdr = hdrs[lane];
+            const bool listed = (hdr & 0x100) != 0;
+            const unsigned long long bal = __ballot(listed);
+            if (bal) {
+                unsigned long long basev = 0;
+                if (lane == 0) basev = atomicAdd(second_count + SC_LIST, (unsigned long long)__popcll(bal));
+                basev = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(basev >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)basev);
+                if (listed) second[basev + __popcll(bal & ((1ull << lane) - 1ull))] = l;
+            }
+            const bool simple = (hdr & 1) != 0;
+            int nout = 0, idsp = 0;
+            double mf = NAN, st[K], pv[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t) { st[t] = NAN; pv[t] = NAN; }
+            if (__any(simple)) {
+                const double pz = (hdr & 2) ? NAN : 0.0; // a pool uncovered over the survivors: NaN frequencies, NaN sums (sync.rs:176-183)
+                double cs1[1], xx1[1][1], xy1[1][MAXK], b1[MAXK][1], p1[MAXK][1];
+                cs1[0] = sums[lane * NSUM] + pz;
+                xx1[0][0] = sums[lane * NSUM + 1] + pz;
+#pragma unroll
+                for (int t = 0; t < MAXK; ++t) xy1[0][t] = (t < K) ? sums[lane * NSUM + 2 + (t < K ? t : 0)] + pz : 0.0;
+                bool singular;
+                ols_solve<2>(cs1, xx1, xy1, K, P, tcoef, singular, b1, p1);
+                if (simple && !singular) { // Err -> the whole locus is dropped (ols.rs:250-253)
+                    nout = 1;
+                    idsp = (hdr >> 4) & 7;
+                    mf = cs1[0] / (double)n; // ols.rs:266
+#pragma unroll
+                    for (int t = 0; t < K; ++t) { st[t] = b1[t][0]; pv[t] = p1[t][0]; }
+                }
+            }
+            // (a listed locus gets the "dropped" pattern here; the second pass overwrites it later in the stream)
+            char *r = stage + (size_t)lane * RECB;
+            *reinterpret_cast<uint2_t *>(r) = uint2_t{(uint32_t)nout, (uint32_t)idsp};
+            *reinterpret_cast<double *>(r + 8) = mf;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                *reinterpret_cast<double *>(r + 16 + 16 * t) = st[t];
+                *reinterpret_cast<double *>(r + 24 + 16 * t) = pv[t];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // slot 0 of every output array, 64 consecutive loci: contiguous runs
+            const int64_t l0 = unit * 64;
+            const int nv = (int)((L - l0) < 64 ? (L - l0) : 64);
+            auto hdr_of = [&](int j) { return *reinterpret_cast<const uint2_t *>(stage + (size_t)j * RECB); };
+            auto dbl_of = [&](int j, int off) { return *reinterpret_cast<const double *>(stage + (size_t)j * RECB + off); };
+            if (lane < nv) {
+                const uint2_t h = hdr_of(lane);
+                if (coalesced) {
+                    __builtin_nontemporal_store((int32_t)h.x, O.n_out + l0 + lane);
+                    __builtin_nontemporal_store(h.x ? (int32_t)(h.y & 7u) : -1, O.ids + l0 + lane);
+                    __builtin_nontemporal_store(h.x ? dbl_of(lane, 8) : NAN, O.mf + l0 + lane);
+                } else if (P.t0 == 0) {
+                    O.n_out[l0 + lane] = (int32_t)h.x;
+                    O.ids[l0 + lane] = h.x ? (int32_t)(h.y & 7u) : -1;
+                    O.mf[l0 + lane] = h.x ? dbl_of(lane, 8) : NAN;
+                }
+            }
+            // stat / pval: [slot 0][locus][trait of the call]
+            for (int e = lane; e < nv * K; e += 64) {
+                const int j = e / K, t = e - j * K;
+                const bool on = hdr_of(j).x != 0;
+                const size_t o = (size_t)(l0 + j) * P.k_total + P.t0 + t;
+                O.stat[o] = on ? dbl_of(j, 16 + 16 * t) : NAN;
+                O.pv[o] = on ? dbl_of(j, 24 + 16 * t) : NAN;
+            }
+        }
+        if (__any((orm_unit >> 29) != 0u)) { // a count the 32-bit coverage sums cannot take: the host reports it
+            if (lane == 0) atomicOr(second_count + SC_COMPLAINT, 1ull);
+            orm_unit = 0;
+        }
+    }
+    {
+        int c = ndirty;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+        if (lane == 0 && c) atomicAdd(second_count + SC_DIRTY, (unsigned long long)c);
+    }
+}
+
 // ---- second pass: only the loci the first pass listed ----------------------------------------------
 // One lane per listed locus (rows gathered through the list).  The survivors are known now (flags), so the sums are taken over
 // the frequencies of the FILTERED counts, as the reference does (gwas/ols.rs:210-230 -> sync.rs:166-192).  Round 4:
@@ -1863,8 +2243,43 @@ int launch_passes(pg_ctx *ctx, int kid, const uint32_t *counts_dev, const Stream
     const void *kstream = pick();
     PG_HIP(ctx, hipFuncSetAttribute(kstream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     PG_HIP(ctx, hipMemsetAsync(W.second_count, 0, 8 * SC_WORDS, ctx->stream)); // the list's length and groups, the sort's cursors, the streaming pass' complaint flag
+    // ols_iter from 32 pools up: the order-free kernel (a locus per row of 16 / 32 / 64 lanes, coalesced reads) or the streaming pass
+    // (sums in pool order, mean frequencies bit-identical to the reference's)
+    int lpl = 0;
+    // Which kernel: the order-free one costs the same whatever the counts look like (0.63 of the HBM peak at 100 pools); the
+    // streaming pass is faster on clean counts (0.68 - 0.70) and slower on error-bearing ones (second pass: 0.53).  A context
+    // remembers what its last ols_iter batch looked like (pieces of one file look alike) and starts with the robust kernel.
+    // POOLGEN_OLS_ITER_KERNEL=rows|stream fixes the choice (tests that compare bits across calls; A/B runs).
+    bool want_rows = ctx->ols_rows_next;
+    if (const char *e = std::getenv("POOLGEN_OLS_ITER_KERNEL")) want_rows = std::strcmp(e, "stream") != 0;
+    if (OP == OP_OLS && n >= 32 && want_rows) {
+        lpl = n <= 112 ? 16 : (n <= 224 ? 32 : (n <= 448 ? 64 : 0));
+        if (lpl == 64 && (n & 1)) lpl = 0; // a group = one locus must be a whole number of 16-byte pieces
+    }
     if (kid >= 0) pg_prof_begin(ctx, kid);
-    {
+    if (lpl) {
+        if constexpr (OP == OP_OLS) {
+            auto pick_rows = [&]() -> const void * {
+#define PG_ROWS(LPLV)                                                                                                        \
+    (kg == 2 ? (rns ? (const void *)k_ols_rows<LPLV, true, 2> : (const void *)k_ols_rows<LPLV, false, 2>)                     \
+             : (rns ? (const void *)k_ols_rows<LPLV, true, 1> : (const void *)k_ols_rows<LPLV, false, 1>))
+                return lpl == 16 ? PG_ROWS(16) : (lpl == 32 ? PG_ROWS(32) : PG_ROWS(64));
+#undef PG_ROWS
+            };
+            const void *krows = pick_rows();
+            const size_t per_wave = (size_t)RW_BUF + 64 * (2 + kg) * 8 + 64 * 4 + 64 * (16 + 16 * kg);
+            const size_t shr = (size_t)LO_WAVES * per_wave + sizeof(double) * (size_t)(1 + kg) * n + sizeof(float) * (size_t)n;
+            PG_HIP(ctx, hipFuncSetAttribute(krows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shr));
+            const int64_t units = (L + 63) / 64, blocks_r = (units + LO_WAVES - 1) / LO_WAVES, cap_r = (int64_t)ctx->cus * 2;
+            const double *a1 = W.table, *a2 = W.tcoef;
+            int32_t *a3 = W.flags;
+            int64_t *a4 = W.second;
+            unsigned long long *a5 = W.second_count;
+            int co = (staged & 2) ? 1 : 0;
+            void *args[] = {(void *)&counts_dev, &a1, &a2, &a3, &a4, &a5, (void *)&O, (void *)&P, &co};
+            PG_HIP(ctx, hipLaunchKernel(krows, dim3((unsigned)(blocks_r < cap_r ? blocks_r : cap_r)), dim3(LO_THREADS), args, shr, ctx->stream));
+        }
+    } else {
         const double *a1 = W.table, *a2 = W.tcoef;
         int32_t *a3 = W.flags;
         int64_t *a4 = W.second;
@@ -1876,13 +2291,17 @@ int launch_passes(pg_ctx *ctx, int kid, const uint32_t *counts_dev, const Stream
     // What the streaming pass could not close in place.  The host looks at the length of the list first (the call ends in a
     // synchronisation anyway: it has to report the complaint flag): an empty list -- clean data -- costs no launch at all, a short
     // one is taken as it is (tiles of mixed survivor counts), a long one is grouped by the number of survivors first.
-    unsigned long long tail[SC_LIST + 1]; // (the groups, not counted yet), the complaint flag, the list's length
+    unsigned long long tail[SC_DIRTY + 1]; // (the groups, not counted yet), the complaint flag, the list's length, the dirty loci
     if (kid >= 0) pg_prof_end(ctx);
     PG_HIP(ctx, hipMemcpyAsync(tail, W.second_count, sizeof tail, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *complaint = tail[SC_COMPLAINT] != 0;
     const int64_t total = (int64_t)tail[SC_LIST];
     *listed = total;
+    if (OP == OP_OLS && n >= 32) { // the next batch's kernel (see above): hysteresis between 0.5 % and 1 %
+        if (lpl) { if ((double)tail[SC_DIRTY] < 0.005 * (double)L) ctx->ols_rows_next = false; }
+        else if ((double)total > 0.01 * (double)L) ctx->ols_rows_next = true;
+    }
     if (total == 0 || *complaint) return PG_OK;
     if (kid >= 0) pg_prof_begin(ctx, kid | PG_PROF_CONT);
     const bool p16 = ((int64_t)n * 24) % 16 == 0;
