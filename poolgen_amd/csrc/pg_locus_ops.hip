@@ -1544,21 +1544,25 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
     } while (false);
 }
 
-// ---- ols_iter, order-free (round 4): a LOCUS PER ROW OF LANES instead of a locus per lane ---------------------------------------
+// ---- ols_iter and chisq_test, order-free (round 4): a LOCUS PER ROW OF LANES instead of a locus per lane ----------------------------
 // The streaming pass above reads with the lane-per-locus request pattern (0.68 - 0.74 of the HBM peak with nothing else going on) because
-// the filter's q must be summed in pool order.  ols_iter does not need that: its decisions (which alleles survive, which is the major
-// one, is the fit singular) must be the reference's, but its NUMBERS -- beta, p, the mean frequency it prints with 8 decimals -- only
-// to 1e-10.  So here a wave reads whole loci with plain coalesced 16-byte loads into a wave-private LDS buffer (a group of 64 / LPL loci,
-// <= 10.5 KB, the next group in registers meanwhile), LPL = 16 / 32 / 64 lanes share one locus (pool = round * LPL + lane), and the
-// sums are reduced over the lanes in a fixed butterfly order:
-//   phase 1  q~_j of every candidate allele, coverage minimum, missing pools -> the filter's decisions; a locus with some
-//            |q~ - threshold| <= qband has its q recomputed literally (pool order, multiply then add) from the buffer;
-//   phase 2  (exactly two survivors: the buffer is read again) frequencies over the SURVIVORS' coverage, sum f, sum f^2, sum f y of both.
-// No speculation is needed -- the survivors are known before the sums are taken -- so stray reads of dropped alleles cost nothing
-// here.  What stays with the exact second pass (k_locus_second, pool-order sums): three or more survivors, and the loci whose
-// decision could depend on the order of the sums: column sums of the two survivors within 1e-9 of each other (which one is the
-// major allele), a design within 1e-8 of singular (ols.rs:77-83).  pearson_corr and chisq_test print full-precision means and keep the
-// streaming pass.
+// the filter's q must be summed in pool order -- and it has to SPECULATE on the surviving pair, because it sees a locus once.  ols_iter
+// and chisq_test do not need pool-order sums: their decisions (which alleles survive, which is the major one, is the fit singular)
+// must be the reference's, but their NUMBERS -- beta, chi2, p, the mean frequency ols_iter prints with 8 decimals -- only to 1e-10.
+// So here a wave reads whole loci with plain coalesced 16-byte loads into a wave-private LDS buffer (a group of 64 / LPL loci,
+// <= 10.5 KB; the next group waits in registers meanwhile), LPL = 16 / 32 / 64 lanes share one locus (pool = round * LPL + lane), and
+// the sums are reduced over the lanes of the row in a fixed butterfly order (the result of a locus does not depend on its place):
+//   phase 1  q~_j of every candidate allele in SINGLE precision, coverage minimum, missing pools -> the filter's decisions; a locus
+//            with some q~ within 2e-4 (relative) of a threshold has its q recomputed literally (fp64, pool order, multiply then add);
+//   phase 2  the buffer is read again: frequencies over the SURVIVORS' coverage (the reference recomputes them on the filtered
+//            counts, gwas/ols.rs:210-230 -> sync.rs:166-192).  ols_iter, two survivors: sum f, sum f^2, sum f y of the rarer one (the
+//            other's follow from f_a + f_b = 1); chisq_test: any number of survivors.
+// No speculation -- the survivors are known before the sums are taken -- so stray reads of dropped alleles cost nothing, and the
+// pass runs at the same 0.62 of the HBM peak (100 pools) whatever the counts look like; on clean counts the streaming pass is
+// faster (0.68 - 0.70), which is why a context switches between the two (launch_passes).  What stays with the exact second pass
+// (k_locus_second, pool-order sums): ols_iter loci with three or more survivors, and those whose decision could depend on the order
+// of the sums -- column sums of the two survivors within 1e-9 n of each other (which one is the major allele), a design within
+// 1e-8 of singular (ols.rs:77-83).  pearson_corr prints a full-precision mean and keeps the streaming pass.
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
 template <int CTRL>
@@ -1580,16 +1584,16 @@ __device__ __forceinline__ T row_all(T v, OPF op) {
 constexpr int RW_NP = 11;               // 16-byte pieces per lane and group: 11 KB >= 24 bytes x 448 pools (x 2 loci x 224, x 4 x 112)
 constexpr int RW_BUF = RW_NP * 1024;
 
-template <int LPL, bool RNS, int K>
+template <int OP, int LPL, bool RNS, int K>
 __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
     const uint32_t *__restrict__ counts, const double *__restrict__ wy, const double *__restrict__ tcoef,
     int32_t *__restrict__ rec_flags, int64_t *__restrict__ second, unsigned long long *__restrict__ second_count,
     const StreamOut O, const LocusParams P, const int coalesced) {
     constexpr int NJ = RNS ? 5 : 6;
     constexpr int GL = 64 / LPL;            // loci per group
-    constexpr int TW = 1 + K;
+    constexpr int TW = (OP == OP_OLS) ? 1 + K : 1; // doubles per pool in the table: w_i (, y_i0, ...)
     constexpr int RECB = 16 + 16 * K;
-    constexpr int NSUM = 2 + K;             // staged per locus: cs, sum f^2, sum f y_t of the design column
+    constexpr int NSUM = 2 + K;             // staged per locus: cs, sum f^2, sum f y_t of the design column (chisq_test: sum_j A_j / cs_j, covered pools)
     auto aj = [](int jj) { return (RNS && jj >= 4) ? jj + 1 : jj; };
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -1748,7 +1752,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
             alive = alive && nmiss != n;                                          // sync.rs:293
             alive = alive && !(((double)nmiss / (double)n) > P.max_miss);         // sync.rs:297
             alive = alive && l < L;
-            bool deferred = alive && nk >= 3; // the joint fit of several alleles: cross products, pool-order sums (second pass)
+            bool deferred = alive && nk >= 3; // ols_iter: the joint fit of several alleles: cross products, pool-order sums (second pass)
             int hdr = 0;
             {   // what the lane-per-locus streaming pass could not close from clean sums: told to the host, which picks the kernel of the
                 // NEXT batch by it (run_locus_op)
@@ -1757,11 +1761,97 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                 for (int j = 0; j < NJ; ++j) stray = stray || (!((slotmask >> j) & 1) && q[j] != 0.0f);
                 ndirty += (alive && stray && li == 0) ? 1 : 0;
             }
+            if constexpr (OP == OP_CHISQ) {
+                // ---- chisq_test: the table of the SURVIVORS' frequencies, any number of them (tables/chisq_test.rs:5-47) -------------------
+                // chi2 = total * (sum_j A_j / cs_j - 1), A_j = sum_i f_ij^2 / rowsum_i, total = sum_i rowsum_i; a covered pool's row sum is
+                // 1 to an ulp, so A_j = sum f^2 and total = the covered pools (statistics are compared at 1e-10).  Nothing is deferred.
+                deferred = false;
+                if (__any(alive)) {
+                    double csj[NJ], ddj[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { csj[j] = 0.0; ddj[j] = 0.0; }
+                    int nmiss2 = 0;
+                    const bool two = nk == 2;                      // this row's locus (the usual case): only the pair's two columns
+                    const bool anygen = __any(alive && nk >= 3);   // (a locus' arithmetic depends on that locus alone: bits do not change with its neighbours)
+                    // two survivors: only the RARER one (by phase 1's q~) is summed; f_a + f_b = 1 in every covered pool gives the other's
+                    // sums without cancellation (they are of the order of the pool count)
+                    int oa = 0, ob = 0;
+                    float qa = q[0], qb = q[0];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        oa = (sa == j) ? 4 * aj(j) : oa; ob = (sb == j) ? 4 * aj(j) : ob;
+                        qa = (sa == j) ? q[j] : qa; qb = (sb == j) ? q[j] : qb;
+                    }
+                    const int om = (qb < qa) ? ob : oa, oo = (qb < qa) ? oa : ob;
+                    auto p2c_pool = [&](const int pool) {
+                        const char *pp = lbase + pool * 24;
+                        if (two) {
+                            const uint32_t cm = *reinterpret_cast<const uint32_t *>(pp + om), co = *reinterpret_cast<const uint32_t *>(pp + oo);
+                            const uint32_t rs2 = cm + co;
+                            nmiss2 += (rs2 == 0u) ? 1 : 0;
+                            const double rsd2 = (double)(rs2 > 1u ? rs2 : 1u);
+                            const double r0 = __builtin_amdgcn_rcp(rsd2);
+                            const double f = (double)cm * fma(fma(-rsd2, r0, 1.0), r0, r0);
+                            csj[0] += f;
+                            ddj[0] = fma(f, f, ddj[0]);
+                        } else {
+                            const uint2_t w0 = *reinterpret_cast<const uint2_t *>(pp), w1 = *reinterpret_cast<const uint2_t *>(pp + 8),
+                                          w2 = *reinterpret_cast<const uint2_t *>(pp + 16);
+                            const uint32_t c0[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                            uint32_t cj[NJ], rs2 = 0u;
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) { cj[j] = ((slotmask >> j) & 1) ? c0[aj(j)] : 0u; rs2 += cj[j]; }
+                            nmiss2 += (rs2 == 0u) ? 1 : 0;
+                            const double rsd2 = (double)(rs2 > 1u ? rs2 : 1u);
+                            const double r0 = __builtin_amdgcn_rcp(rsd2);
+                            const double r1 = fma(fma(-rsd2, r0, 1.0), r0, r0);
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) {
+                                const double f = (double)cj[j] * r1;
+                                csj[j] += f;
+                                ddj[j] = fma(f, f, ddj[j]);
+                            }
+                        }
+                    };
+                    {
+                        const int full = n / LPL;
+#pragma unroll 2
+                        for (int t = 0; t < full; ++t) p2c_pool(t * LPL + li);
+                        if (full * LPL + li < n) p2c_pool(full * LPL + li);
+                    }
+                    nmiss2 = row_all<LPL>(nmiss2, addi);
+                    double acc = 0.0;
+                    csj[0] = row_all<LPL>(csj[0], add);
+                    ddj[0] = row_all<LPL>(ddj[0], add);
+                    if (anygen) {
+#pragma unroll
+                        for (int j = 1; j < NJ; ++j) { csj[j] = row_all<LPL>(csj[j], add); ddj[j] = row_all<LPL>(ddj[j], add); }
+                    }
+                    if (two) {
+                        const double ncov = (double)(n - nmiss2);
+                        acc = ddj[0] / csj[0] + (ncov - 2.0 * csj[0] + ddj[0]) / (ncov - csj[0]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc = ((slotmask >> j) & 1) ? acc + ddj[j] / csj[j] : acc;
+                    }
+                    if (alive) {
+                        int idsp = 0, r = 0;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const bool kpj = (slotmask >> j) & 1;
+                            idsp |= kpj ? (aj(j) << (3 * r)) : 0;
+                            r += kpj ? 1 : 0;
+                        }
+                        hdr = 1 | (nmiss2 > 0 ? 2 : 0) | (nk << 4) | (idsp << 8);
+                        if (li == 0) { sums[lu * NSUM] = acc; sums[lu * NSUM + 1] = (double)(n - nmiss2); }
+                    }
+                }
+            }
             // ---- phase 2: exactly two survivors a < b -- frequencies over THEIR coverage (gwas/ols.rs:210-230 -> sync.rs:166-192) ---------
             // The design column is the MINOR allele (stable sort by decreasing column sum, sync.rs:477-506; the major one is dropped,
             // ols.rs:227-230).  The sums are taken for the allele phase 1 saw as the rarer one; f_a + f_b = 1 in every covered pool, so
             // the other allele's sums follow from them should the column sums say otherwise (both are then near 1/2: no cancellation).
-            if (__any(alive && nk == 2)) {
+            if (OP == OP_OLS && __any(alive && nk == 2)) {
                 float qa = q[0], qb = q[0];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) { qa = (sa == j) ? q[j] : qa; qb = (sb == j) ? q[j] : qb; }
@@ -1833,7 +1923,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                 }
             }
             if (li == 0) {
-                hdrs[lu] = deferred ? 0x100 : hdr; // bit 0: close in place | bit 1: a pool uncovered over the survivors | 4..6 allele | 8: listed
+                hdrs[lu] = deferred ? (1 << 30) : hdr; // bit 0: close in place | 1: a pool uncovered over the survivors | 4..6 allele (chisq_test: survivors, 8.. their ids) | 30: listed
                 if (deferred) rec_flags[l] = FLAG_ALIVE | keepmask | FLAG_SECOND | (nk << H_NK_SHIFT);
             }
         }
@@ -1842,7 +1932,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
         {
             const int64_t l = unit * 64 + lane;
             const int hdr = hdrs[lane];
-            const bool listed = (hdr & 0x100) != 0;
+            const bool listed = (hdr & (1 << 30)) != 0;
             const unsigned long long bal = __ballot(listed);
             if (bal) {
                 unsigned long long basev = 0;
@@ -1856,7 +1946,16 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
             double mf = NAN, st[K], pv[K];
 #pragma unroll
             for (int t = 0; t < K; ++t) { st[t] = NAN; pv[t] = NAN; }
-            if (__any(simple)) {
+            if constexpr (OP == OP_CHISQ) {
+                if (__any(simple)) {
+                    const double pz = (hdr & 2) ? NAN : 0.0;
+                    const int nk = (hdr >> 4) & 7;
+                    const double chi2 = sums[lane * NSUM + 1] * (sums[lane * NSUM] - 1.0) + pz; // tables/chisq_test.rs:15-31 regrouped
+                    const double df = (double)(n * nk) - 1.0;
+                    const double p = pg_chisq_upper_p(chi2, df, pg_ln_gamma(df / 2.0)); // :33-35
+                    if (simple) { st[0] = chi2; pv[0] = p; nout = nk; idsp = (hdr >> 8) & 0x7fff; }
+                }
+            } else if (__any(simple)) {
                 const double pz = (hdr & 2) ? NAN : 0.0; // a pool uncovered over the survivors: NaN frequencies, NaN sums (sync.rs:176-183)
                 double cs1[1], xx1[1][1], xy1[1][MAXK], b1[MAXK][1], p1[MAXK][1];
                 cs1[0] = sums[lane * NSUM] + pz;
@@ -1889,7 +1988,18 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
             const int nv = (int)((L - l0) < 64 ? (L - l0) : 64);
             auto hdr_of = [&](int j) { return *reinterpret_cast<const uint2_t *>(stage + (size_t)j * RECB); };
             auto dbl_of = [&](int j, int off) { return *reinterpret_cast<const double *>(stage + (size_t)j * RECB + off); };
-            if (lane < nv) {
+            if constexpr (OP == OP_CHISQ) {
+                if (lane < nv) { // n_out, the surviving alleles in the slots below it (column order), chi2, p: plain [L] arrays
+                    const uint2_t h = hdr_of(lane);
+                    const int no = (int)h.x;
+                    O.n_out[l0 + lane] = no;
+#pragma unroll
+                    for (int r = 0; r < PG_MAX_OUT; ++r)
+                        if (r < no) O.ids[(size_t)r * (size_t)P.L + (size_t)(l0 + lane)] = (int)((h.y >> (3 * r)) & 7u);
+                    O.stat[l0 + lane] = dbl_of(lane, 16);
+                    O.pv[l0 + lane] = dbl_of(lane, 24);
+                }
+            } else if (lane < nv) {
                 const uint2_t h = hdr_of(lane);
                 if (coalesced) {
                     __builtin_nontemporal_store((int32_t)h.x, O.n_out + l0 + lane);
@@ -1902,7 +2012,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                 }
             }
             // stat / pval: [slot 0][locus][trait of the call]
-            for (int e = lane; e < nv * K; e += 64) {
+            for (int e = lane; OP == OP_OLS && e < nv * K; e += 64) {
                 const int j = e / K, t = e - j * K;
                 const bool on = hdr_of(j).x != 0;
                 const size_t o = (size_t)(l0 + j) * P.k_total + P.t0 + t;
@@ -2250,25 +2360,26 @@ int launch_passes(pg_ctx *ctx, int kid, const uint32_t *counts_dev, const Stream
     // streaming pass is faster on clean counts (0.68 - 0.70) and slower on error-bearing ones (second pass: 0.53).  A context
     // remembers what its last ols_iter batch looked like (pieces of one file look alike) and starts with the robust kernel.
     // POOLGEN_OLS_ITER_KERNEL=rows|stream fixes the choice (tests that compare bits across calls; A/B runs).
-    bool want_rows = ctx->ols_rows_next;
+    bool &rows_next = ctx->rows_next[OP == OP_CHISQ ? 1 : 0];
+    bool want_rows = rows_next;
     if (const char *e = std::getenv("POOLGEN_OLS_ITER_KERNEL")) want_rows = std::strcmp(e, "stream") != 0;
-    if (OP == OP_OLS && n >= 32 && want_rows) {
+    if ((OP == OP_OLS || OP == OP_CHISQ) && n >= 32 && want_rows) {
         lpl = n <= 112 ? 16 : (n <= 224 ? 32 : (n <= 448 ? 64 : 0));
         if (lpl == 64 && (n & 1)) lpl = 0; // a group = one locus must be a whole number of 16-byte pieces
     }
     if (kid >= 0) pg_prof_begin(ctx, kid);
     if (lpl) {
-        if constexpr (OP == OP_OLS) {
+        if constexpr (OP == OP_OLS || OP == OP_CHISQ) {
             auto pick_rows = [&]() -> const void * {
-#define PG_ROWS(LPLV)                                                                                                        \
-    (kg == 2 ? (rns ? (const void *)k_ols_rows<LPLV, true, 2> : (const void *)k_ols_rows<LPLV, false, 2>)                     \
-             : (rns ? (const void *)k_ols_rows<LPLV, true, 1> : (const void *)k_ols_rows<LPLV, false, 1>))
+#define PG_ROWS(LPLV)                                                                                                                   \
+    ((OP == OP_OLS && kg == 2) ? (rns ? (const void *)k_ols_rows<OP, LPLV, true, (OP == OP_OLS ? 2 : 1)> : (const void *)k_ols_rows<OP, LPLV, false, (OP == OP_OLS ? 2 : 1)>) \
+                               : (rns ? (const void *)k_ols_rows<OP, LPLV, true, 1> : (const void *)k_ols_rows<OP, LPLV, false, 1>))
                 return lpl == 16 ? PG_ROWS(16) : (lpl == 32 ? PG_ROWS(32) : PG_ROWS(64));
 #undef PG_ROWS
             };
             const void *krows = pick_rows();
             const size_t per_wave = (size_t)RW_BUF + 64 * (2 + kg) * 8 + 64 * 4 + 64 * (16 + 16 * kg);
-            const size_t shr = (size_t)LO_WAVES * per_wave + sizeof(double) * (size_t)(1 + kg) * n + sizeof(float) * (size_t)n;
+            const size_t shr = (size_t)LO_WAVES * per_wave + sizeof(double) * (size_t)TW * n + sizeof(float) * (size_t)n;
             PG_HIP(ctx, hipFuncSetAttribute(krows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shr));
             const int64_t units = (L + 63) / 64, blocks_r = (units + LO_WAVES - 1) / LO_WAVES, cap_r = (int64_t)ctx->cus * 2;
             const double *a1 = W.table, *a2 = W.tcoef;
@@ -2298,9 +2409,9 @@ int launch_passes(pg_ctx *ctx, int kid, const uint32_t *counts_dev, const Stream
     *complaint = tail[SC_COMPLAINT] != 0;
     const int64_t total = (int64_t)tail[SC_LIST];
     *listed = total;
-    if (OP == OP_OLS && n >= 32) { // the next batch's kernel (see above): hysteresis between 0.5 % and 1 %
-        if (lpl) { if ((double)tail[SC_DIRTY] < 0.005 * (double)L) ctx->ols_rows_next = false; }
-        else if ((double)total > 0.01 * (double)L) ctx->ols_rows_next = true;
+    if ((OP == OP_OLS || OP == OP_CHISQ) && n >= 32) { // the next batch's kernel (see above): hysteresis between 0.5 % and 1 %
+        if (lpl) { if ((double)tail[SC_DIRTY] < 0.005 * (double)L) rows_next = false; }
+        else if ((double)total > 0.01 * (double)L) rows_next = true;
     }
     if (total == 0 || *complaint) return PG_OK;
     if (kid >= 0) pg_prof_begin(ctx, kid | PG_PROF_CONT);
