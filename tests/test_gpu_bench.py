@@ -114,8 +114,10 @@ def test_secondary_legs_in_the_line():
         for op in ("ols_iter", "pearson_corr", "chisq_test"):
             leg = cr[tag][op]
             assert leg["kernel_ms"] > 0 and leg["launches"] == 10 and 0 < leg["frac"] < 1 and 0 <= leg["deferred_fraction"] <= 1
-    assert 0 < cr["error_0.005_maf_0.01"]["ols_iter"]["deferred_fraction"] < 0.15      # the speculated pair holds for most loci
+    assert cr["error_0.005_maf_0.01"]["ols_iter"]["deferred_fraction"] < 0.01           # the order-free kernel knows the survivors before it sums
+    assert 0 < cr["error_0.005_maf_0.01"]["pearson_corr"]["deferred_fraction"] < 0.15   # the streaming pass: its speculated pair holds for most loci
     assert cr["error_0.005_default_filter"]["ols_iter"]["deferred_fraction"] > 0.5     # error alleles that survive: multi-allelic fits
+    assert cr["error_0.005_default_filter"]["chisq_test"]["deferred_fraction"] == 0.0   # chisq_test closes any number of survivors in place
     assert cr["ols_iter"] == cr["error_0.005_maf_0.01"]["ols_iter"]
     rd = sec["ridge"]
     assert "error" not in rd, rd
