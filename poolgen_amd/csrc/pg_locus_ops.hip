@@ -1581,6 +1581,9 @@ __device__ __forceinline__ T row_all(T v, OPF op) {
     if constexpr (LPL >= 64) v = op(v, __shfl_xor(v, 32));
     return v;
 }
+#ifndef RW_UNROLL
+#define RW_UNROLL 2
+#endif
 constexpr int RW_NP = 11;               // 16-byte pieces per lane and group: 11 KB >= 24 bytes x 448 pools (x 2 loci x 224, x 4 x 112)
 constexpr int RW_BUF = RW_NP * 1024;
 
@@ -1687,7 +1690,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
             };
             {
                 const int full = n / LPL;          // rounds in which every lane has a pool
-#pragma unroll 2
+#pragma unroll RW_UNROLL
                 for (int t = 0; t < full; ++t) p1_pool(t * LPL + li);
                 if (full * LPL + li < n) p1_pool(full * LPL + li); // the last, partial round
             }
@@ -1815,7 +1818,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                     };
                     {
                         const int full = n / LPL;
-#pragma unroll 2
+#pragma unroll RW_UNROLL
                         for (int t = 0; t < full; ++t) p2c_pool(t * LPL + li);
                         if (full * LPL + li < n) p2c_pool(full * LPL + li);
                     }
@@ -1880,7 +1883,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                 };
                 {
                     const int full = n / LPL;
-#pragma unroll 2
+#pragma unroll RW_UNROLL
                     for (int t = 0; t < full; ++t) p2_pool(t * LPL + li);
                     if (full * LPL + li < n) p2_pool(full * LPL + li);
                 }

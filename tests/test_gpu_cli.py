@@ -372,3 +372,45 @@ def test_multi_gpu_batch_operators(tmp_path, analysis, extra):
     r = subprocess.run([str(CLI), "fst", "-f", str(GOLD / "test.sync"), "-p", str(GOLD / "test.csv"), "--n-gpus", "2", "-o", str(tmp_path / "f.csv")],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "runs on one GPU" in r.stderr
+
+
+def test_cli_count_operators_on_error_bearing_text(oracle, tmp_path):
+    """The three count operators through the CLI on sync TEXT that looks like real pool-seq data: 100 pools, every read misread with
+    probability 0.5 % onto one of the other five columns, so nearly every locus carries reads of alleles the MAF filter drops and
+    the reference recomputes the frequencies on the filtered counts (gwas/ols.rs:210-230).  Text fields identical to the oracle's
+    CSV; ols_iter's 8-decimal mean frequency, beta and p within one unit of their grid / 1e-10 (its first pass is order-free from
+    32 pools up); pearson_corr's full-precision mean as TEXT; chisq_test within its printing grid."""
+    from poolgen_amd import synth
+    n, L = 100, 1500
+    counts = synth.sync_counts(L, n, "cpu", seed=61, error_rate=0.005).numpy().astype(np.uint64)
+    counts[5::97, :10, :] = 0                                    # uncovered pools: dropped by the default --min-coverage-depth
+    G = synth.genotype_matrix(64, n, "cpu", seed=61)
+    Y = synth.phenotypes(G, n, k=2, seed=9)
+    ps = [20.0] * n
+    sync = tmp_path / "e.sync"
+    with open(sync, "w") as fh:
+        fh.write("#chr\tpos\tref\t" + "\t".join(f"p{i}" for i in range(n)) + "\n")
+        for l in range(L):
+            fh.write(f"chr{1 + l // 700}\t{1000 + 17 * l}\tN\t" + "\t".join(":".join(str(int(x)) for x in counts[l, i]) for i in range(n)) + "\n")
+    phen = tmp_path / "e.csv"
+    with open(phen, "w") as fh:
+        fh.write("#name,size,t1,t2\n")
+        for i in range(n):
+            fh.write(f"P{i},20,{float(Y[i, 0])!r},{float(Y[i, 1])!r}\n")
+    rows = [(f"chr{1 + l // 700}", 1000 + 17 * l, counts[l]) for l in range(L)]
+    for maf in ("0.01", "0.001"):
+        f = oracle.filt(True, 1, float(maf), 0.0)
+        common = ["-f", sync, "-p", phen, "--phen-delim", ",", "--phen-name-col", "0", "--phen-pool-size-col", "1", "--min-allele-frequency", maf]
+        out = tmp_path / f"ols_{maf}.csv"
+        run_cli("ols_iter", *common, "--phen-value-col", "2,3", "--n-threads", 4, "-o", out)
+        want = "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n" + "".join(oracle.ols_iterate_csv(c, p, cnt, Y, ps, f) or "" for c, p, cnt in rows)
+        assert want.count("\n") > L // 2
+        compare_csv(out.read_text(), want, {3: 1.0000001e-8, 5: 1.0000001e-6, 6: 1e-10}, max_noise_rows=want.count("\n"), exempt=set())
+        out = tmp_path / f"prs_{maf}.csv"
+        run_cli("pearson_corr", *common, "--phen-value-col", "2,3", "--n-threads", 4, "-o", out)
+        want = "#chr,pos,alleles,freq,phenotype,statistic,pvalue\n" + "".join(oracle.correlation_csv(c, p, cnt, Y, ps, f) or "" for c, p, cnt in rows)
+        compare_csv(out.read_text(), want, {5: 1.0000001e-6, 6: 1e-10}, max_noise_rows=want.count("\n"), exempt=set())   # (column 3, the mean: text)
+        out = tmp_path / f"chi_{maf}.csv"
+        run_cli("chisq_test", *common, "--n-threads", 4, "-o", out)
+        want = "#chr,pos,alleles,statistic,pvalue\n" + "".join(oracle.chisq_csv(c, p, cnt, ps, f) or "" for c, p, cnt in rows)
+        compare_csv(out.read_text(), want, {3: 1.0000001e-6, 4: 1e-10}, max_noise_rows=want.count("\n"), exempt=set())
