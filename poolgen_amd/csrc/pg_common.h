@@ -57,6 +57,7 @@ struct pg_ctx {
     int load_n = 0, load_kpm1 = 0, load_pshift = 0;
     size_t load_off_flags = 0, load_off_local = 0, load_off_blockoff = 0, load_off_poolmap = 0;
     int64_t lo_last_L = 0, lo_last_listed = 0; // pg_locus_op_stats
+    bool rows_call[2] = {true, true};   // ... and what the current call's launch groups run
     bool rows_next[2] = {true, true}; // ols_iter, chisq_test: the next batch runs the order-free kernel (the last one looked error-bearing, or none has run)
     double *lz_dev = nullptr;    // per-wave (1'S1, trace S) partials of the lazy-kinship sweep
     bool lazy_taken = false;     // the last pg_ols_kinship_dev decided m = 0 without forming K

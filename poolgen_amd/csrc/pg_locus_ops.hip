@@ -1562,7 +1562,9 @@ __device__ __forceinline__ void close_locus(const int64_t l, const int32_t *rec_
 // faster (0.68 - 0.70), which is why a context switches between the two (launch_passes).  What stays with the exact second pass
 // (k_locus_second, pool-order sums): ols_iter loci with three or more survivors, and those whose decision could depend on the order
 // of the sums -- column sums of the two survivors within 1e-9 n of each other (which one is the major allele), a design within
-// 1e-8 of singular (ols.rs:77-83).  pearson_corr prints a full-precision mean and keeps the streaming pass.
+// 1e-8 of singular (ols.rs:77-83).  pearson_corr prints a full-precision mean and keeps the streaming pass (built here too and
+// measured: the pool-order sum of the mean as an n-step chain on the row's first lane, frequencies handed over in LDS, parity
+// green -- 0.62 ms against 0.59 for streaming pass + second pass on the same box; not kept).
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
 template <int CTRL>
@@ -2363,8 +2365,10 @@ int launch_passes(pg_ctx *ctx, int kid, const uint32_t *counts_dev, const Stream
     // streaming pass is faster on clean counts (0.68 - 0.70) and slower on error-bearing ones (second pass: 0.53).  A context
     // remembers what its last ols_iter batch looked like (pieces of one file look alike) and starts with the robust kernel.
     // POOLGEN_OLS_ITER_KERNEL=rows|stream fixes the choice (tests that compare bits across calls; A/B runs).
-    bool &rows_next = ctx->rows_next[OP == OP_CHISQ ? 1 : 0];
-    bool want_rows = rows_next;
+    constexpr int ROWS_OP = (OP == OP_CHISQ) ? 1 : 0;
+    bool &rows_next = ctx->rows_next[ROWS_OP];
+    if (P.t0 == 0) ctx->rows_call[ROWS_OP] = rows_next; // one choice per call: its launch groups (trait pairs) must agree on who wrote slot 0
+    bool want_rows = ctx->rows_call[ROWS_OP];
     if (const char *e = std::getenv("POOLGEN_OLS_ITER_KERNEL")) want_rows = std::strcmp(e, "stream") != 0;
     if ((OP == OP_OLS || OP == OP_CHISQ) && n >= 32 && want_rows) {
         lpl = n <= 112 ? 16 : (n <= 224 ? 32 : (n <= 448 ? 64 : 0));
