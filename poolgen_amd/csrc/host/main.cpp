@@ -29,8 +29,10 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <time.h>
 #include <sys/stat.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 using namespace pgh;
@@ -287,7 +289,14 @@ struct Lap {
 // The results are on disk and the file name is printed: end the process here.  Releasing tens of GB of device and pinned
 // memory buffer by buffer (destructors, hipFree, the HIP runtime's shutdown) took 0.3 s of a 1.4 s run; the driver
 // reclaims everything when the process ends.  PGH_CLEAN_EXIT=1 keeps the orderly teardown (leak checkers).
+static void stamp(const char *what) { // PGH_TIMING=1: the wall clock itself, so that a wrapper can see what lies outside the laps
+    if (!std::getenv("PGH_TIMING")) return;
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    std::fprintf(stderr, "poolgen: clock at %-15s %lld.%09ld\n", what, (long long)ts.tv_sec, ts.tv_nsec);
+}
 static int done_ok() {
+    stamp("exit");
     std::cout.flush();
     std::cerr.flush();
     std::fflush(nullptr);
@@ -304,6 +313,19 @@ static int done_ok() {
 // (sync.rs:1092-1101) cannot be had across pieces -- and that is checked.
 // ---------------------------------------------------------------------------------------------------------
 struct UnsortedInput : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// The text of a piece is not looked at again once it is parsed: its pages leave the mapping here, on a thread of their own,
+// instead of all at once when the process ends -- unmapping 27 GB of touched file pages (6.6 M page-table entries, one thread,
+// inside exit) was 0.25 s per 5 GB of input AFTER the program's last line (profiles/r04_stream_*.log).  MADV_DONTNEED on a
+// read-only private file mapping only drops the entries; the page cache keeps the file.  PGH_KEEP_MAPPED=1 leaves them.
+static void drop_parsed_text(const char *b, const char *e) {
+    static const bool keep = std::getenv("PGH_KEEP_MAPPED") != nullptr;
+    if (keep) return;
+    const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t lo = ((uintptr_t)b + pg - 1) / pg * pg, hi = (uintptr_t)e / pg * pg;
+    if (hi <= lo || hi - lo < ((uintptr_t)1 << 20)) return;
+    std::thread([lo, hi] { (void)::madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED); }).detach();
+}
 
 // The counts of a parsed batch -> the 32-bit device buffer the operators read.  A 16-bit batch (every count fits: the
 // usual case) crosses the bus at half the size and is widened on the device; `stage16` is a reusable device scratch.
@@ -487,8 +509,10 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &l
         auto parse_piece = [&](int c) {
             (void)hipSetDevice(K.device); // the pinned allocator runs on the parser's thread
             const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
-            return is_pileup ? parse_pileup_buffer(b, e, K.threads, pf, alloc_for(c & 1))
-                             : parse_sync_buffer(b, e, K.threads, n, alloc_for(c & 1), true);
+            SyncBatch parsed = is_pileup ? parse_pileup_buffer(b, e, K.threads, pf, alloc_for(c & 1))
+                                         : parse_sync_buffer(b, e, K.threads, n, alloc_for(c & 1), true);
+            drop_parsed_text(b, e);
+            return parsed;
         };
         std::future<SyncBatch> next = std::async(std::launch::async, parse_piece, K.c0);
         std::vector<double> S_piece((size_t)n2 * n2);
@@ -720,8 +744,10 @@ static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &lap
         auto parse_piece = [&](int c) {
             (void)hipSetDevice(device);
             const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
-            return is_pileup ? parse_pileup_buffer(b, e, threads, pf, alloc_for(c & 1))
-                             : parse_sync_buffer(b, e, threads, 0, alloc_for(c & 1), !subset);
+            SyncBatch parsed = is_pileup ? parse_pileup_buffer(b, e, threads, pf, alloc_for(c & 1))
+                                         : parse_sync_buffer(b, e, threads, 0, alloc_for(c & 1), !subset);
+            drop_parsed_text(b, e);
+            return parsed;
         };
         const int c0 = first[r], c1 = first[r + 1];
         if (c0 >= c1) return;
@@ -1053,6 +1079,7 @@ static std::string ols_with_covariate(Ctx &gpu, GenotypesAndPhenotypes &g, doubl
 }
 
 static int run(int argc, char **argv) {
+    stamp("main");
     const Args a = parse_args(argc, argv);
     Lap lap;
     const std::map<std::string, int> known{{"chisq_test", 0}, {"pearson_corr", 1}, {"ols_iter", 2},

@@ -1586,11 +1586,18 @@ __device__ __forceinline__ T row_all(T v, OPF op) {
 #ifndef RW_UNROLL
 #define RW_UNROLL 2
 #endif
+constexpr int RW_MAXR = 7;              // rounds per locus at most (112 / 16, 224 / 32, 448 / 64 pools per lane)
 constexpr int RW_NP = 11;               // 16-byte pieces per lane and group: 11 KB >= 24 bytes x 448 pools (x 2 loci x 224, x 4 x 112)
 constexpr int RW_BUF = RW_NP * 1024;
+#ifndef RW_DIRECT_OCC
+#define RW_DIRECT_OCC 3
+#endif
+#ifndef RW_DIRECT_SETS
+#define RW_DIRECT_SETS 1
+#endif
 
-template <int OP, int LPL, bool RNS, int K>
-__global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
+template <int OP, int LPL, bool RNS, int K, bool DIRECT>
+__global__ __launch_bounds__(LO_THREADS, (DIRECT ? RW_DIRECT_OCC : 2)) void k_ols_rows(
     const uint32_t *__restrict__ counts, const double *__restrict__ wy, const double *__restrict__ tcoef,
     int32_t *__restrict__ rec_flags, int64_t *__restrict__ second, unsigned long long *__restrict__ second_count,
     const StreamOut O, const LocusParams P, const int coalesced) {
@@ -1603,11 +1610,12 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int PER_WAVE = RW_BUF + 64 * NSUM * 8 + 64 * 4 + 64 * RECB;
+    constexpr int BUFB = DIRECT ? 0 : RW_BUF; // DIRECT: no staging buffer -- a lane loads its own pools (see RowRegs)
+    constexpr int PER_WAVE = BUFB + 64 * NSUM * 8 + 64 * 4 + 64 * RECB;
     char *buf = lds_raw + wave * PER_WAVE;
-    double *sums = reinterpret_cast<double *>(buf + RW_BUF);
-    int32_t *hdrs = reinterpret_cast<int32_t *>(buf + RW_BUF + 64 * NSUM * 8);
-    char *stage = buf + RW_BUF + 64 * NSUM * 8 + 64 * 4;
+    double *sums = reinterpret_cast<double *>(buf + BUFB);
+    int32_t *hdrs = reinterpret_cast<int32_t *>(buf + BUFB + 64 * NSUM * 8);
+    char *stage = buf + BUFB + 64 * NSUM * 8 + 64 * 4;
     const double *tab = reinterpret_cast<const double *>(lds_raw + LO_WAVES * PER_WAVE);
     const int n = P.n;
     const int64_t L = P.L;
@@ -1650,21 +1658,86 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
 #pragma unroll
         for (int i = 0; i < RW_NP; ++i) *reinterpret_cast<uint4_t *>(buf + lane * 16 + i * 1024) = SR[i];
     };
+    // DIRECT: the counts of this lane's pools (round t: pool t LPL + li of the row's locus) straight from memory into registers, 16 + 8
+    // bytes per pool; 16 lanes x 24 bytes = 384 contiguous bytes per row and round.  Two register sets: the next group's loads are in
+    // flight while the current group is summed.  Pools past the row's end (the last round) and rounds past the last one point beyond
+    // the descriptor's range and read zeros.
+    struct RowRegs { uint4_t a[RW_MAXR]; uint2_t b[RW_MAXR]; };
+    uint32_t voff[RW_MAXR];
+#pragma unroll
+    for (int t = 0; t < RW_MAXR; ++t) voff[t] = (t * LPL + li < n) ? (uint32_t)row * rowb + (uint32_t)(t * LPL + li) * 24u : 0x7ffffff0u;
+    auto issue_direct = [&](RowRegs &R) {
+        const uint64_t go = ((uint64_t)pre_u * 64u + (uint64_t)pre_g * GL) * rowb;
+        const uint64_t left = total_bytes > go ? total_bytes - go : 0;
+        const uint64_t lim = left < grpb ? left : grpb;
+        const uint64_t ub = base0 + (left ? go : 0);
+        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lim);
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ub >> 32));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < RW_MAXR; ++t) {
+            R.a[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[t], 0, 0);
+            R.b[t] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[t] + 16u, 0, 0);
+        }
+        if (++pre_g >= LPL) { pre_g = 0; pre_u += wstride; }
+    };
     auto add = [](double a, double b) { return a + b; };
     auto addi = [](int a, int b) { return a + b; };
     auto mini = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
 
     uint32_t orm_unit = 0;
     int ndirty = 0;
-    issue_group();
+    RowRegs RA;
+#if RW_DIRECT_SETS == 2
+    RowRegs RB;
+#endif
+    if constexpr (DIRECT) issue_direct(RA);
+    else issue_group();
     for (int64_t unit = wid; unit < nunits; unit += wstride) {
-        for (int g = 0; g < LPL; ++g) {           // the 64 / GL groups of the unit
-            __builtin_amdgcn_wave_barrier();
-            land_group();
-            __builtin_amdgcn_wave_barrier();
-            issue_group();
+        auto group_body = [&](const RowRegs &R, const int g) { // one of the 64 / GL groups of the unit
             const int lu = g * GL + row;          // this row's locus inside the unit
             const int64_t l = unit * 64 + lu;
+            // the six counts of this lane's pool of round t
+            auto fetch6 = [&](auto tc, const int pool, uint32_t (&c0)[6]) {
+                if constexpr (DIRECT) {
+                    constexpr int t = decltype(tc)::value;
+                    c0[0] = R.a[t].x; c0[1] = R.a[t].y; c0[2] = R.a[t].z; c0[3] = R.a[t].w; c0[4] = R.b[t].x; c0[5] = R.b[t].y;
+                } else {
+                    const char *pp = lbase + pool * 24;
+                    const uint2_t w0 = *reinterpret_cast<const uint2_t *>(pp), w1 = *reinterpret_cast<const uint2_t *>(pp + 8),
+                                  w2 = *reinterpret_cast<const uint2_t *>(pp + 16);
+                    c0[0] = w0.x; c0[1] = w0.y; c0[2] = w1.x; c0[3] = w1.y; c0[4] = w2.x; c0[5] = w2.y;
+                }
+            };
+            // ... and the two at byte offsets om, oo of the pool (the survivors of a biallelic locus; pair_at: every row's pair is A, T)
+            auto fetch2 = [&](auto tc, const int pool, const int om, const int oo, const bool pair_at, uint32_t &cm, uint32_t &co) {
+                if constexpr (DIRECT) {
+                    constexpr int t = decltype(tc)::value;
+                    if (pair_at) { // (wave-uniform) om, oo are 0 and 4 in some order
+                        cm = om ? R.a[t].y : R.a[t].x;
+                        co = om ? R.a[t].x : R.a[t].y;
+                    } else {
+                        const uint32_t c0[6] = {R.a[t].x, R.a[t].y, R.a[t].z, R.a[t].w, R.b[t].x, R.b[t].y};
+                        cm = c0[0]; co = c0[0];
+#pragma unroll
+                        for (int j = 1; j < 6; ++j) { cm = (om == 4 * j) ? c0[j] : cm; co = (oo == 4 * j) ? c0[j] : co; }
+                    }
+                } else {
+                    const char *pp = lbase + pool * 24;
+                    cm = *reinterpret_cast<const uint32_t *>(pp + om);
+                    co = *reinterpret_cast<const uint32_t *>(pp + oo);
+                }
+            };
+            // every pool of this lane: the full rounds, then the last, partial one
+            auto each_pool = [&](auto fn) {
+                const int full = n / LPL;
+                static_for<0, RW_MAXR>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if (t < full) fn(tc, t * LPL + li);
+                    else if (t == full && full * LPL + li < n) fn(tc, full * LPL + li);
+                });
+            };
             // ---- phase 1: the filter, in SINGLE precision ---------------------------------------------------------------------------------
             // q~_j = sum_i c_ij * (w_i / rs_i) in fp32 is within (n + 4) 2^-24 < 3e-5 of q_j relative (positive terms): it decides every
             // locus whose q stay 2e-4 (relative) away from both thresholds -- practically all -- at a quarter of the fp64 cost; the others
@@ -1674,12 +1747,10 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
             for (int j = 0; j < NJ; ++j) q[j] = 0.0f;
             uint32_t mincov = 0xffffffffu, orv = 0u;
             int nmiss = 0;
-            auto p1_pool = [&](const int pool) { // one pool of this lane (pool < n)
-                const char *pp = lbase + pool * 24;
-                const uint2_t w0 = *reinterpret_cast<const uint2_t *>(pp), w1 = *reinterpret_cast<const uint2_t *>(pp + 8),
-                              w2 = *reinterpret_cast<const uint2_t *>(pp + 16);
+            each_pool([&](auto tc, const int pool) {
+                uint32_t c0[6];
+                fetch6(tc, pool, c0);
                 const float wi = tabf[pool];
-                const uint32_t c0[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
                 uint32_t rsi = c0[aj(0)], o2 = c0[aj(0)];
 #pragma unroll
                 for (int j = 1; j < NJ; ++j) { rsi += c0[aj(j)]; o2 |= c0[aj(j)]; }
@@ -1689,13 +1760,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                 const float wr = wi * __builtin_amdgcn_rcpf((float)(rsi > 1u ? rsi : 1u));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) q[j] = fmaf((float)c0[aj(j)], wr, q[j]);
-            };
-            {
-                const int full = n / LPL;          // rounds in which every lane has a pool
-#pragma unroll RW_UNROLL
-                for (int t = 0; t < full; ++t) p1_pool(t * LPL + li);
-                if (full * LPL + li < n) p1_pool(full * LPL + li); // the last, partial round
-            }
+            });
             {
                 auto addf = [](int x, int y) { return __float_as_int(__int_as_float(x) + __int_as_float(y)); };
 #pragma unroll
@@ -1721,10 +1786,9 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                     double qe[NJ];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) qe[j] = 0.0;
+                    const uint2_t *rp = reinterpret_cast<const uint2_t *>(counts + (size_t)l * (size_t)n * 6); // (its row in memory: rare)
                     for (int i = 0; i < n; ++i) {
-                        const char *pp = lbase + i * 24;
-                        const uint2_t w0 = *reinterpret_cast<const uint2_t *>(pp), w1 = *reinterpret_cast<const uint2_t *>(pp + 8),
-                                      w2 = *reinterpret_cast<const uint2_t *>(pp + 16);
+                        const uint2_t w0 = rp[3 * i], w1 = rp[3 * i + 1], w2 = rp[3 * i + 2];
                         const uint32_t c0[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
                         uint32_t rs = 0u;
 #pragma unroll
@@ -1788,10 +1852,11 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                         qa = (sa == j) ? q[j] : qa; qb = (sb == j) ? q[j] : qb;
                     }
                     const int om = (qb < qa) ? ob : oa, oo = (qb < qa) ? oa : ob;
-                    auto p2c_pool = [&](const int pool) {
-                        const char *pp = lbase + pool * 24;
+                    const bool pair_at = __all(!(alive && two) || (oa + ob == 4 && (oa == 0 || ob == 0))); // (DIRECT: the pair is A, T in every row)
+                    each_pool([&](auto tc, const int pool) {
                         if (two) {
-                            const uint32_t cm = *reinterpret_cast<const uint32_t *>(pp + om), co = *reinterpret_cast<const uint32_t *>(pp + oo);
+                            uint32_t cm, co;
+                            fetch2(tc, pool, om, oo, pair_at, cm, co);
                             const uint32_t rs2 = cm + co;
                             nmiss2 += (rs2 == 0u) ? 1 : 0;
                             const double rsd2 = (double)(rs2 > 1u ? rs2 : 1u);
@@ -1800,9 +1865,8 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                             csj[0] += f;
                             ddj[0] = fma(f, f, ddj[0]);
                         } else {
-                            const uint2_t w0 = *reinterpret_cast<const uint2_t *>(pp), w1 = *reinterpret_cast<const uint2_t *>(pp + 8),
-                                          w2 = *reinterpret_cast<const uint2_t *>(pp + 16);
-                            const uint32_t c0[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                            uint32_t c0[6];
+                            fetch6(tc, pool, c0);
                             uint32_t cj[NJ], rs2 = 0u;
 #pragma unroll
                             for (int j = 0; j < NJ; ++j) { cj[j] = ((slotmask >> j) & 1) ? c0[aj(j)] : 0u; rs2 += cj[j]; }
@@ -1817,13 +1881,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                                 ddj[j] = fma(f, f, ddj[j]);
                             }
                         }
-                    };
-                    {
-                        const int full = n / LPL;
-#pragma unroll RW_UNROLL
-                        for (int t = 0; t < full; ++t) p2c_pool(t * LPL + li);
-                        if (full * LPL + li < n) p2c_pool(full * LPL + li);
-                    }
+                    });
                     nmiss2 = row_all<LPL>(nmiss2, addi);
                     double acc = 0.0;
                     csj[0] = row_all<LPL>(csj[0], add);
@@ -1869,9 +1927,10 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
 #pragma unroll
                 for (int t = 0; t < K; ++t) xym[t] = 0.0;
                 int nmiss2 = 0;
-                auto p2_pool = [&](const int pool) {
-                    const char *pp = lbase + pool * 24;
-                    const uint32_t cm = *reinterpret_cast<const uint32_t *>(pp + om), co = *reinterpret_cast<const uint32_t *>(pp + oo);
+                const bool pair_at = __all(!(alive && nk == 2) || (oa + ob == 4 && (oa == 0 || ob == 0))); // (DIRECT: the pair is A, T in every row)
+                each_pool([&](auto tc, const int pool) {
+                    uint32_t cm, co;
+                    fetch2(tc, pool, om, oo, pair_at, cm, co);
                     const uint32_t rs2 = cm + co;
                     nmiss2 += (rs2 == 0u) ? 1 : 0;
                     // c / rs to a few ulp: the hardware reciprocal and ONE Newton step (these sums need 1e-10, not the last bit)
@@ -1882,13 +1941,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
                     ddm = fma(f, f, ddm);
 #pragma unroll
                     for (int tt = 0; tt < K; ++tt) xym[tt] = fma(f, tab[pool * TW + 1 + tt], xym[tt]);
-                };
-                {
-                    const int full = n / LPL;
-#pragma unroll RW_UNROLL
-                    for (int t = 0; t < full; ++t) p2_pool(t * LPL + li);
-                    if (full * LPL + li < n) p2_pool(full * LPL + li);
-                }
+                });
                 csm = row_all<LPL>(csm, add);
                 ddm = row_all<LPL>(ddm, add);
 #pragma unroll
@@ -1930,6 +1983,29 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
             if (li == 0) {
                 hdrs[lu] = deferred ? (1 << 30) : hdr; // bit 0: close in place | 1: a pool uncovered over the survivors | 4..6 allele (chisq_test: survivors, 8.. their ids) | 30: listed
                 if (deferred) rec_flags[l] = FLAG_ALIVE | keepmask | FLAG_SECOND | (nk << H_NK_SHIFT);
+            }
+        };
+        if constexpr (DIRECT) {
+#if RW_DIRECT_SETS == 2
+            for (int g = 0; g < LPL; g += 2) {    // (RA holds group g; the set just summed takes the loads of the group after next)
+                issue_direct(RB);
+                group_body(RA, g);
+                issue_direct(RA);
+                group_body(RB, g + 1);
+            }
+#else
+            for (int g = 0; g < LPL; ++g) {       // (one set: the other waves of the SIMD cover the wait)
+                group_body(RA, g);
+                issue_direct(RA);
+            }
+#endif
+        } else {
+            for (int g = 0; g < LPL; ++g) {
+                __builtin_amdgcn_wave_barrier();
+                land_group();
+                __builtin_amdgcn_wave_barrier();
+                issue_group();
+                group_body(RA, g);
             }
         }
         // ---- the unit's 64 loci: lane = locus -- close, list, write -------------------------------------------------------------------
@@ -2038,6 +2114,7 @@ __global__ __launch_bounds__(LO_THREADS, 2) void k_ols_rows(
     }
 }
 
+// ---- second pass: only the loci the first pass listed ----------------------------------------------
 // ---- second pass: only the loci the first pass listed ----------------------------------------------
 // One lane per listed locus (rows gathered through the list).  The survivors are known now (flags), so the sums are taken over
 // the frequencies of the FILTERED counts, as the reference does (gwas/ols.rs:210-230 -> sync.rs:166-192).  Round 4:
@@ -2377,18 +2454,29 @@ int launch_passes(pg_ctx *ctx, int kid, const uint32_t *counts_dev, const Stream
     if (kid >= 0) pg_prof_begin(ctx, kid);
     if (lpl) {
         if constexpr (OP == OP_OLS || OP == OP_CHISQ) {
+            // chisq_test reads its pools straight into registers (DIRECT: no staging buffer, three waves per SIMD): -3 % at 100 pools,
+            // -10 % at 200 on the same box; ols_iter gains nothing from it (measured: DESIGN section 3.3) and keeps the buffer.
+            // POOLGEN_ROWS_DIRECT=0 puts chisq_test back on the buffer (A/B runs).
+            bool direct = OP == OP_CHISQ;
+            if (const char *e = std::getenv("POOLGEN_ROWS_DIRECT")) direct = direct && std::strcmp(e, "0") != 0;
             auto pick_rows = [&]() -> const void * {
-#define PG_ROWS(LPLV)                                                                                                                   \
-    ((OP == OP_OLS && kg == 2) ? (rns ? (const void *)k_ols_rows<OP, LPLV, true, (OP == OP_OLS ? 2 : 1)> : (const void *)k_ols_rows<OP, LPLV, false, (OP == OP_OLS ? 2 : 1)>) \
-                               : (rns ? (const void *)k_ols_rows<OP, LPLV, true, 1> : (const void *)k_ols_rows<OP, LPLV, false, 1>))
-                return lpl == 16 ? PG_ROWS(16) : (lpl == 32 ? PG_ROWS(32) : PG_ROWS(64));
+                if constexpr (OP == OP_CHISQ) {
+#define PG_ROWS(LPLV) (direct ? (rns ? (const void *)k_ols_rows<OP, LPLV, true, 1, true> : (const void *)k_ols_rows<OP, LPLV, false, 1, true>) \
+                              : (rns ? (const void *)k_ols_rows<OP, LPLV, true, 1, false> : (const void *)k_ols_rows<OP, LPLV, false, 1, false>))
+                    return lpl == 16 ? PG_ROWS(16) : (lpl == 32 ? PG_ROWS(32) : PG_ROWS(64));
 #undef PG_ROWS
+                } else {
+#define PG_ROWS(LPLV) (kg == 2 ? (rns ? (const void *)k_ols_rows<OP, LPLV, true, 2, false> : (const void *)k_ols_rows<OP, LPLV, false, 2, false>) \
+                               : (rns ? (const void *)k_ols_rows<OP, LPLV, true, 1, false> : (const void *)k_ols_rows<OP, LPLV, false, 1, false>))
+                    return lpl == 16 ? PG_ROWS(16) : (lpl == 32 ? PG_ROWS(32) : PG_ROWS(64));
+#undef PG_ROWS
+                }
             };
             const void *krows = pick_rows();
-            const size_t per_wave = (size_t)RW_BUF + 64 * (2 + kg) * 8 + 64 * 4 + 64 * (16 + 16 * kg);
+            const size_t per_wave = (direct ? 0 : (size_t)RW_BUF) + 64 * (2 + kg) * 8 + 64 * 4 + 64 * (16 + 16 * kg);
             const size_t shr = (size_t)LO_WAVES * per_wave + sizeof(double) * (size_t)TW * n + sizeof(float) * (size_t)n;
             PG_HIP(ctx, hipFuncSetAttribute(krows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shr));
-            const int64_t units = (L + 63) / 64, blocks_r = (units + LO_WAVES - 1) / LO_WAVES, cap_r = (int64_t)ctx->cus * 2;
+            const int64_t units = (L + 63) / 64, blocks_r = (units + LO_WAVES - 1) / LO_WAVES, cap_r = (int64_t)ctx->cus * (direct ? RW_DIRECT_OCC : 2);
             const double *a1 = W.table, *a2 = W.tcoef;
             int32_t *a3 = W.flags;
             int64_t *a4 = W.second;

@@ -22,7 +22,22 @@ for rep in 1 2; do
   PGH_TIMING=1 poolgen_amd/csrc/poolgen ols_iter_with_kinship -f $big -p $d/phen.csv --phen-value-col 2 --n-threads $thr -o $d/out.csv 2> $d/timing.$rep.txt
   e=$(date +%s.%N)
   python3 -c "import sys; print('run', sys.argv[1], 'wall %.3f s' % (float(sys.argv[3]) - float(sys.argv[2])))" $rep $s $e
-  grep -E '^poolgen:' $d/timing.$rep.txt
+  grep -E '^poolgen:' $d/timing.$rep.txt | grep -v 'clock at'
+  # the parser's own laps, summed over the pieces; then what lies outside the program's laps: exec + dynamic loading before
+  # main(), the teardown of the process after its last line
+  python3 - $s $e $d/timing.$rep.txt <<'PY'
+import collections, re, sys
+s, e = float(sys.argv[1]), float(sys.argv[2])
+txt = open(sys.argv[3]).read()
+laps = collections.defaultdict(list)
+for what, sec in re.findall(r'^parse_sync_file: (.*?)\s+([0-9.]+) s$', txt, re.M):
+    laps[what].append(float(sec))
+for what, v in laps.items():
+    print('  parser, %d pieces: %-12s sum %.3f s, median %.4f, max %.4f' % (len(v), what, sum(v), sorted(v)[len(v) // 2], max(v)))
+st = dict(re.findall(r'clock at (\w+)\s+([0-9.]+)', txt))
+if 'main' in st and 'exit' in st:
+    print('  before main() %.3f s, main() to exit %.3f s, after exit (process teardown) %.3f s' % (float(st['main']) - s, float(st['exit']) - float(st['main']), e - float(st['exit'])))
+PY
 done
 wc -l $d/out.csv
 rm -rf $d
