@@ -172,6 +172,13 @@ __global__ void k_gp_blambda(const double *__restrict__ beta, int64_t p, int k, 
     for (int i = 0; i < GP_LMAX; ++i) B[l * GP_LMAX + i] = (i < P.L) ? gp_contract(b, bx, P, i) : 0.0;
 }
 
+// the all-rows fit's slopes, formed as columns of a batched coefficient pass (column-major), into the model's [1 + p] x k layout
+__global__ void k_gp_cols_to_rows(const double *__restrict__ cols, int64_t p, int k, double *__restrict__ rows) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= p) return;
+    for (int j = 0; j < k; ++j) rows[l * k + j] = cols[(size_t)j * p + l];
+}
+
 // single-lambda variant writing the penalised column back (final model, :653-662)
 __global__ void k_gp_apply(double *__restrict__ beta, int64_t p, int k, int j, PathParams P, Proxy X, int i) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,8 +662,19 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
     double *bf = nullptr;       // C x p (column-major) slopes of the folds' fits
     FoldMasses *fm_dev = nullptr;
     int32_t *colof_dev = nullptr;
+    // The slopes of ALL repetitions' folds (and of the all-rows fit) are columns G Z of the same matrix: formed CP at a time,
+    // whatever repetition they belong to, they take ceil((n_reps C + k) / CP) passes over G instead of n_reps + 1 (config 4:
+    // 101 columns, 7 passes instead of 11).  Needs the n_reps C + k columns resident (config 4: 4 GB of the 288); otherwise,
+    // or with POOLGEN_RIDGE_PER_REP=1, one pass per repetition as before.
+    constexpr int CP = 16;      // columns per coefficient pass: what the sweep kernel's products mode carries at 500 pools
+    const size_t ncols_all = (size_t)n_reps * C + k;
+    bool batched = fused && n_reps > 1 && !std::getenv("POOLGEN_RIDGE_PER_REP");
+    if (batched) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || sizeof(double) * (size_t)p * ncols_all > fr / 2) batched = false;
+    }
     if (fused) {
-        if (hipMalloc((void **)&bf, sizeof(double) * (size_t)p * C) != hipSuccess ||
+        if (hipMalloc((void **)&bf, sizeof(double) * (size_t)p * (batched ? ncols_all : (size_t)C)) != hipSuccess ||
             hipMalloc((void **)&fm_dev, sizeof(FoldMasses) * C) != hipSuccess ||
             hipMalloc((void **)&colof_dev, sizeof(int32_t) * n) != hipSuccess) {
             (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev);
@@ -676,7 +694,11 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         bool bad = false;
     };
     std::vector<RepSolve> solves(fused ? n_reps : 0);
-    std::vector<std::promise<void>> ready(fused ? n_reps : 0);
+    std::vector<std::promise<void>> ready(fused ? n_reps + 1 : 0); // (the last one: the all-rows fit)
+    std::vector<std::shared_future<void>> readyf;
+    for (auto &pr : ready) readyf.push_back(pr.get_future().share());
+    std::vector<double> Zall, b0all(k, 0.0); // the all-rows fit: pinv(X X^T) y scattered over the pools, its intercepts
+    bool all_bad = false;
     std::thread solver;
     if (fused)
         solver = std::thread([&] {
@@ -707,22 +729,63 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 for (int f = 0; f < n_folds; ++f) R.bad = R.bad || badf[f];
                 ready[rep].set_value();
             }
+            if (batched) { // the all-rows fit rides in the last batched pass (gp/ols.rs:47-72 on `row_idx`)
+                std::vector<double> V((size_t)n_rows * k);
+                Zall.assign((size_t)n * k, 0.0);
+                if (pg_gp_subset_solve(xxt.data(), n, Y, k, row_idx, n_rows, V.data()) != 0) all_bad = true;
+                else
+                    for (int a2 = 0; a2 < n_rows; ++a2)
+                        for (int j = 0; j < k; ++j) {
+                            Zall[(size_t)row_idx[a2] * k + j] = V[(size_t)a2 * k + j];
+                            b0all[j] += V[(size_t)a2 * k + j]; // intercept column of X is all ones
+                        }
+            }
+            ready[n_reps].set_value();
         });
     struct Joiner { // every exit path waits for the solver before its captures go away
         std::thread &t;
         ~Joiner() { if (t.joinable()) t.join(); }
     } joiner{solver};
+    size_t formed = 0; // batched: columns [0, formed) of the global numbering (repetition-major, then the all-rows fit) are in bf
+    auto form_cols = [&](size_t c0, size_t c1) -> int { // one pass over G for the columns [c0, c1)
+        const int nc = (int)(c1 - c0);
+        std::vector<double> Zb((size_t)n * nc, 0.0);
+        double t0 = now();
+        for (size_t c = c0; c < c1; ++c) {
+            const bool fin = c >= (size_t)n_reps * C;
+            const int rep = fin ? n_reps : (int)(c / C);
+            readyf[rep].wait();
+            if (fin ? all_bad : solves[rep].bad) return pg_fail(ctx, PG_ERR_INVALID, "gp_ridge: pinv failed");
+            const double *src = fin ? Zall.data() : solves[rep].Z.data();
+            const int stride = fin ? k : C, cc = fin ? (int)(c - (size_t)n_reps * C) : (int)(c % C);
+            for (int i = 0; i < n; ++i) Zb[(size_t)i * nc + (c - c0)] = src[(size_t)i * stride + cc];
+        }
+        t_solve += now() - t0; t0 = now();
+        const int rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Zb.data(), nc, bf + c0 * (size_t)p, 1);
+        t_beta += now() - t0;
+        return rc;
+    };
     for (int rep = 0; rep < n_reps && fused; ++rep) {
         double t0 = now();
-        ready[rep].get_future().wait();
+        readyf[rep].wait();
         RepSolve &R = solves[rep];
         if (R.bad) return fail2(pg_fail(ctx, PG_ERR_INVALID, "gp_ridge: pinv failed"));
         const std::vector<std::vector<int64_t>> &tr = R.tr, &va = R.va;
         const std::vector<double> &Z = R.Z, &b0c = R.b0c;
         t_solve += now() - t0; t0 = now();
-        int rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Z.data(), C, bf, 1); // :526 for every fold at once, column-major
+        int rc = PG_OK;
+        if (batched) {
+            while (formed < (size_t)(rep + 1) * C && rc == PG_OK) {
+                const size_t c1 = std::min(formed + (size_t)CP, ncols_all);
+                rc = form_cols(formed, c1);
+                formed = c1;
+            }
+        } else {
+            rc = pg_gp_beta_cols(ctx, G_dev, p, n, ld, Z.data(), C, bf, 1); // :526 for every fold at once, column-major
+            t_beta += now() - t0;
+        }
         if (rc) return fail2(rc);
-        t_beta += now() - t0;
+        const double *bfr = batched ? bf + (size_t)rep * C * (size_t)p : bf; // this repetition's C columns
         for (int a = 0; a < A; ++a) {
             t0 = now();
             // the redistribution masses of every (fold, trait) column
@@ -733,7 +796,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
             for (int f = 0; f < n_folds; ++f)
                 for (int j = 0; j < k; ++j) skip[f * k + j] = va[f].empty() || tr[f].empty();
             std::vector<PathParams> PP;
-            rc = ridge_path_params_cols(ctx, bf, p, C, k, alpha_at(a), path, W, proxy_dev, skip, PP);
+            rc = ridge_path_params_cols(ctx, bfr, p, C, k, alpha_at(a), path, W, proxy_dev, skip, PP);
             if (rc) return fail2(rc);
             for (int c = 0; c < C; ++c) {
                 if (skip[c]) { std::memset(&fm[c], 0, sizeof(FoldMasses)); fm[c].nmax = 1.0; continue; }
@@ -764,10 +827,10 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
 #define PG_PREDICT_FOLDS(LPV)                                                                                              \
     case LPV:                                                                                                              \
         if (groups > 1)                                                                                                    \
-            hipLaunchKernelGGL((k_gp_predict_folds<LPV, true>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, \
+            hipLaunchKernelGGL((k_gp_predict_folds<LPV, true>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bfr, C, colof_dev, fm_dev, P0, X, \
                                p, n, ld, lpb, chunk, W.part, groups);                                                      \
         else                                                                                                               \
-            hipLaunchKernelGGL((k_gp_predict_folds<LPV, false>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bf, C, colof_dev, fm_dev, P0, X, \
+            hipLaunchKernelGGL((k_gp_predict_folds<LPV, false>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bfr, C, colof_dev, fm_dev, P0, X, \
                                p, n, ld, lpb, chunk, W.part, 1);                                                           \
         break;
                 switch (LP) {
@@ -785,6 +848,20 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
             }
             t_predict += now() - t0;
         }
+    }
+    if (batched) { // whatever is left of the columns (the all-rows fit at least, unless it rode in a repetition's pass)
+        int rc = PG_OK;
+        while (formed < ncols_all && rc == PG_OK) {
+            const size_t c1 = std::min(formed + (size_t)CP, ncols_all);
+            rc = form_cols(formed, c1);
+            formed = c1;
+        }
+        if (rc) return fail2(rc);
+        if (hipMemcpyAsync(beta_dev, b0all.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
+        hipLaunchKernelGGL(k_gp_cols_to_rows, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, bf + (size_t)n_reps * C * (size_t)p, p, k, beta_dev + k);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) // (b0all is read by the copy)
+            return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: the all-rows fit failed"));
     }
     if (timing)
         std::fprintf(stderr, "gp path: fold solves %.1f ms, coefficient passes %.1f ms, masses %.1f ms, prediction + scores %.1f ms\n",
@@ -819,7 +896,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         }
     // all-rows fit; per trait the mode over repetitions of the per-repetition arg-min over the (alpha, lambda) grid
     // (:573-627): alpha and lambda are counted separately, each against the path values
-    int rc = pg_gp_ols_dev(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, xxt.data(), beta_dev);
+    int rc = batched ? PG_OK : pg_gp_ols_dev(ctx, G_dev, p, n, ld, Y, k, row_idx, n_rows, xxt.data(), beta_dev); // (batched: already in beta_dev)
     if (rc) return fail(rc);
     for (int j = 0; j < k; ++j) {
         std::vector<int> acount(L, 0), lcount(L, 0);

@@ -1,21 +1,58 @@
+// tools/parse_bench.cpp -- the sync parser alone, piece by piece as the streamed CLI drives it (no GPU work):
+//   parse_bench <file.sync> <threads> <piece MB> <malloc|pinned> [populate] [drop]
+// pinned = hipHostMalloc'd output slots (what the CLI parses into), malloc = plain memory; populate = MADV_POPULATE_READ on the
+// piece before it is parsed; drop = MADV_DONTNEED behind it.  Build: hipcc -O2 -std=c++17 -Ipoolgen_amd/csrc/host tools/parse_bench.cpp
+// poolgen_amd/csrc/host/host_util.cpp -o /tmp/parse_bench -lpthread
 #include "host_util.h"
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <sys/resource.h>
+#include <string>
 using namespace pgh;
-static double cpu() { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_utime.tv_sec + 1e-6 * r.ru_utime.tv_usec + r.ru_stime.tv_sec + 1e-6 * r.ru_stime.tv_usec; }
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
 int main(int argc, char **argv) {
-    const int thr = argc > 2 ? atoi(argv[2]) : 8;
-    static void *keep = nullptr; static size_t keepsz = 0;
-    SyncAlloc al; al.alloc = [](size_t b) -> void * { if (b > keepsz) { keep = malloc(b); memset(keep, 1, b); keepsz = b; } return keep; }; al.release = [](void *) {};
+    if (argc < 5) { std::fprintf(stderr, "usage: parse_bench file threads pieceMB malloc|pinned [populate] [drop]\n"); return 2; }
+    const int thr = std::atoi(argv[2]);
+    const size_t piece = (size_t)std::atol(argv[3]) << 20;
+    const bool pinned = std::string(argv[4]) == "pinned";
+    bool populate = false, drop = false;
+    for (int i = 5; i < argc; ++i) { populate |= std::string(argv[i]) == "populate"; drop |= std::string(argv[i]) == "drop"; }
     MappedFile mf(argv[1]);
-    { volatile char x = 0; for (size_t i = 0; i < mf.size(); i += 4096) x += mf.data()[i]; }
-    for (int rep = 0; rep < 6; ++rep) {
-        auto t0 = std::chrono::steady_clock::now(); double c0 = cpu();
-        SyncBatch sb = parse_sync_buffer(mf.data(), mf.data() + mf.size(), thr, 0, al, true);
-        auto t1 = std::chrono::steady_clock::now(); double c1 = cpu();
-        std::printf("L %lld  wall %.3f s  cpu %.3f s\n", (long long)sb.L, std::chrono::duration<double>(t1 - t0).count(), c1 - c0);
+    const std::vector<size_t> cuts = mf.cuts((mf.size() + piece - 1) / piece);
+    struct Slot { void *p = nullptr; size_t cap = 0; } slot[2];
+    auto alloc_for = [&](int i) {
+        SyncAlloc al;
+        al.alloc = [&slot, i, pinned](size_t bytes) -> void * {
+            if (bytes > slot[i].cap) {
+                const size_t want = bytes + bytes / 8;
+                if (pinned) { if (hipHostMalloc(&slot[i].p, want, hipHostMallocDefault) != hipSuccess) return nullptr; }
+                else { slot[i].p = std::malloc(want); std::memset(slot[i].p, 1, want); }
+                slot[i].cap = want;
+            }
+            return slot[i].p;
+        };
+        al.release = [](void *) {};
+        return al;
+    };
+    const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+    auto t0 = std::chrono::steady_clock::now();
+    int64_t loci = 0;
+    for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+        const char *b = mf.data() + cuts[c], *e = mf.data() + cuts[c + 1];
+        const uintptr_t lo = ((uintptr_t)b + pg - 1) / pg * pg, hi = (uintptr_t)e / pg * pg;
+        if (populate && hi > lo) (void)madvise((void *)lo, hi - lo, MADV_POPULATE_READ);
+        SyncBatch sb = parse_sync_buffer(b, e, thr, 0, alloc_for((int)(c & 1)), true);
+        loci += sb.L;
+        if (drop && hi > lo) (void)madvise((void *)lo, hi - lo, MADV_DONTNEED);
     }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("%s threads %d piece %zu MB %s%s%s: %lld loci, %.3f s, %.2f GB/s\n", argv[1], thr, piece >> 20, argv[4], populate ? " populate" : "",
+                drop ? " drop" : "", (long long)loci, s, mf.size() / s / 1e9);
+    return 0;
 }
