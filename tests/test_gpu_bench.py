@@ -121,7 +121,9 @@ def test_secondary_legs_in_the_line():
     assert cr["ols_iter"] == cr["error_0.005_maf_0.01"]["ols_iter"]
     rd = sec["ridge"]
     assert "error" not in rd, rd
-    assert rd["coefficient_pass"]["launches"] >= 10 and rd["prediction_pass"]["launches"] >= 10 and rd["wall_s"] > 0
+    # 10 repetitions x 10 folds + the all-rows fit = 101 coefficient columns, 16 per pass over G (round 4); one prediction pass per repetition
+    assert rd["coefficient_pass"]["launches"] == 7 and rd["prediction_pass"]["launches"] == 10 and rd["wall_s"] > 0
+    assert rd["passes_over_G"] == 18
     assert 0 < rd["coefficient_pass"]["frac"] < 1 and 0 < rd["prediction_pass"]["frac"] < 1
 
 

@@ -288,6 +288,42 @@ def test_batch_operators_in_pieces_equal_one_piece(tmp_path, analysis, extra):
     assert one.read_bytes() == many.read_bytes() and one.stat().st_size > 10000
 
 
+def test_pieces_whose_text_leaves_the_mapping(tmp_path):
+    """Round 4: the text of a parsed piece is dropped from the file mapping on a helper thread (madvise, pieces of 1 MiB or more:
+    unmapping 27 GB at exit cost more than the CSV writer).  A 9 MB sorted sync in 2 MiB pieces through ols_iter_with_kinship
+    and ols_iter: byte-identical files with the pages dropped, with PGH_KEEP_MAPPED=1, and (ols_iter) in one piece."""
+    import os
+    from poolgen_amd import synth
+    n, L = 120, 6000
+    counts = synth.sync_counts(L, n, "cpu", seed=73, error_rate=0.002).numpy()
+    sync = tmp_path / "big.sync"
+    with open(sync, "w") as fh:
+        for l in range(L):
+            fh.write(f"chr{1 + l // 2500}\t{10 + 3 * l}\tN\t" + "\t".join(":".join(str(int(x)) for x in counts[l, i]) for i in range(n)) + "\n")
+    assert sync.stat().st_size > 6 << 20
+    Y = synth.phenotypes(synth.genotype_matrix(64, n, "cpu", seed=73), n, k=1, seed=4)
+    phen = tmp_path / "p.csv"
+    with open(phen, "w") as fh:
+        fh.write("#name,size,t1\n")
+        for i in range(n):
+            fh.write(f"P{i},20,{float(Y[i, 0])!r}\n")
+    for analysis in ("ols_iter_with_kinship", "ols_iter"):
+        base = [str(CLI), analysis, "-f", str(sync), "-p", str(phen), "--phen-delim", ",", "--phen-name-col", "0", "--phen-pool-size-col", "1",
+                "--phen-value-col", "2", "--n-threads", "4", "--stream-chunk-mb", "2"]
+        outs = {}
+        for tag, extra in (("drop", {}), ("keep", {"PGH_KEEP_MAPPED": "1"})):
+            o = tmp_path / f"{analysis}_{tag}.csv"
+            r = subprocess.run(base + ["-o", str(o)], capture_output=True, text=True, env={**os.environ, **extra})
+            assert r.returncode == 0, r.stderr
+            outs[tag] = o.read_bytes()
+        assert outs["drop"] == outs["keep"] and len(outs["drop"]) > 100000
+        if analysis == "ols_iter":
+            o = tmp_path / "one.csv"
+            r = subprocess.run(base[:-2] + ["--stream-chunk-mb", "64", "-o", str(o)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert o.read_bytes() == outs["drop"]
+
+
 def test_operator_interface_reference_unit_tests():
     """`apitest`: the reference's operator-level unit tests transcribed to the C++ mirror of its interface
     (host/operators.h: FilterStats, LocusCounts, LocusCountsAndPhenotypes, chisq / correlation / ols_iterate returning

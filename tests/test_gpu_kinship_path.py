@@ -532,6 +532,12 @@ def test_gp_penalised_family_matches_oracle(engine, oracle, exact, n, p, k, alph
     finally:
         del os.environ["POOLGEN_RIDGE_PER_FOLD"]
     assert np.allclose(perf2, perf, rtol=1e-9, atol=1e-12) and np.array_equal(lam2, lam) and np.array_equal(al2, al)
+    os.environ["POOLGEN_RIDGE_PER_REP"] = "1"   # one coefficient pass per repetition instead of 16 columns per pass across repetitions
+    try:
+        beta4, al4, lam4, perf4 = engine.gp_penalised(G, Y, rows, folds, n_folds, alpha, proxy, n=n)
+    finally:
+        del os.environ["POOLGEN_RIDGE_PER_REP"]
+    assert np.array_equal(perf4, perf) and np.array_equal(lam4, lam) and np.array_equal(al4, al) and np.array_equal(beta4.cpu().numpy(), beta.cpu().numpy())
     # and the caller's own X X^T (the CV harness computes it once for all its fits) changes nothing
     beta3, al3, lam3, perf3 = engine.gp_penalised(G, Y, rows, folds, n_folds, alpha, proxy, n=n, XXt=engine.gp_xxt(G, n).cpu().numpy())
     assert np.array_equal(perf3, perf) and np.array_equal(beta3.cpu().numpy(), beta.cpu().numpy())
@@ -600,6 +606,14 @@ def test_gp_ridge_path_matches_oracle(engine, oracle, n, p, k, alpha):
         del os.environ["POOLGEN_RIDGE_PER_FOLD"]
     assert np.array_equal(lam2, lam) and np.allclose(perf2, perf, rtol=1e-12, atol=1e-13)
     assert np.allclose(beta2.cpu().numpy(), b, rtol=1e-12, atol=0)
+    # round 4: the folds' columns of ALL repetitions and the all-rows fit are formed 16 per pass over G (here 3 x 4 x k + k columns:
+    # batches that straddle repetitions and hold the final fit); one pass per repetition + one for the final fit must give the same bits
+    os.environ["POOLGEN_RIDGE_PER_REP"] = "1"
+    try:
+        beta4, lam4, perf4 = engine.gp_ridge(G, Y, rows, folds, n_folds, alpha=alpha, n=n)
+    finally:
+        del os.environ["POOLGEN_RIDGE_PER_REP"]
+    assert np.array_equal(lam4, lam) and np.array_equal(perf4, perf) and np.array_equal(beta4.cpu().numpy(), b)
 
 
 @pytest.mark.parametrize("p,n,k", [(6000, 200, 2), (5000, 200, 3), (3000, 33, 1), (2000, 100, 2), (4000, 208, 1), (1500, 193, 1)])
