@@ -6,7 +6,7 @@ python3 tools/gen_sync.py $d/base.sync $d/phen.csv 200 200000
 : > $d/big.sync
 for i in $(seq 1 ${1:-10}); do cat $d/base.sync >> $d/big.sync; done
 ls -la $d/big.sync
-for mode in "malloc" "pinned" "pinned drop" "pinned populate" "malloc populate"; do
+for mode in "malloc" "pinned" "pinned pread" "malloc pread" "pinned" "pinned pread"; do
   for t in 16; do PGH_TIMING= $d/parse_bench $d/big.sync $t 256 $mode 2>/dev/null; done
 done
 $d/parse_bench $d/big.sync 8 256 pinned 2>/dev/null
