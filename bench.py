@@ -658,7 +658,7 @@ def worker(args):
                     for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))):
                         h.update(f.read_bytes())
                     traffic_state = "measured on these kernel sources" if tj.get("kernel_sources_sha256") == h.hexdigest() else \
-                        "STALE: the kernel sources have changed since the counter passes (tools/r03_profile.sh re-measures)"
+                        "STALE: the kernel sources have changed since the counter passes (tools/r04_profile.sh re-measures)"
             except Exception:
                 traffic_db = {}
         traffic_note = ("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command "

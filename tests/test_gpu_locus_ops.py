@@ -465,3 +465,28 @@ def test_kernel_choice_follows_the_data(engine, oracle, monkeypatch):
     for counts in (clean, clean, dirty, dirty, clean):
         res = engine.ols_iterate(counts, ps, f, Y)
         check_stat_op(tuple(x[:600] for x in res), oracle.ols_iterate_locus, counts[:600].cpu().numpy().astype(np.uint64), Y, ps, fo, oracle=oracle)
+
+
+@pytest.mark.parametrize("n", [100, 200, 37])
+def test_chisq_register_and_buffer_variants_agree(engine, oracle, n, monkeypatch):
+    """chisq_test's order-free pass reads its pools straight into registers (no LDS staging buffer); POOLGEN_ROWS_DIRECT=0 keeps the
+    buffered variant ols_iter uses.  Same pool-to-lane assignment, same butterflies: the two must give the same bits."""
+    from poolgen_amd import synth
+    L = 20011
+    counts = synth.sync_counts(L, n, "cuda", seed=29, error_rate=0.004)
+    counts[11::97, : max(1, n // 7), :] = 0
+    ps = np.linspace(12, 40, n)
+    f, fo = flt_pair(oracle, maf=0.002)
+    monkeypatch.setenv("POOLGEN_OLS_ITER_KERNEL", "rows")
+    a = [x.cpu().numpy() for x in engine.chisq(counts, ps, f)]
+    monkeypatch.setenv("POOLGEN_ROWS_DIRECT", "0")
+    b = [x.cpu().numpy() for x in engine.chisq(counts, ps, f)]
+    assert int((a[0] > 0).sum()) > L // 2
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    rows = counts[:300].cpu().numpy().astype(np.uint64)
+    for l in range(300):
+        k, rid, rc, rp = oracle.chisq_locus(rows[l], ps, fo)
+        assert a[0][l] == k
+        if k and not np.isnan(rc):
+            assert abs(a[2][l] - rc) <= 1e-10 * max(1.0, abs(rc)) and abs(a[3][l] - rp) <= 1e-10
