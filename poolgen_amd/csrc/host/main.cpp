@@ -318,14 +318,29 @@ struct UnsortedInput : std::runtime_error { using std::runtime_error::runtime_er
 // instead of all at once when the process ends -- unmapping 27 GB of touched file pages (6.6 M page-table entries, one thread,
 // inside exit) was 0.25 s per 5 GB of input AFTER the program's last line (profiles/r04_stream_*.log).  MADV_DONTNEED on a
 // read-only private file mapping only drops the entries; the page cache keeps the file.  PGH_KEEP_MAPPED=1 leaves them.
-static void drop_parsed_text(const char *b, const char *e) {
-    static const bool keep = std::getenv("PGH_KEEP_MAPPED") != nullptr;
-    if (keep) return;
-    const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
-    const uintptr_t lo = ((uintptr_t)b + pg - 1) / pg * pg, hi = (uintptr_t)e / pg * pg;
-    if (hi <= lo || hi - lo < ((uintptr_t)1 << 20)) return;
-    std::thread([lo, hi] { (void)::madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED); }).detach();
-}
+// The helper threads belong to an object that lives SHORTER than the mapping (declare it after the MappedFile): its destructor
+// joins them, so that no madvise is still on its way when the mapping goes (an exception, the fall-back to the whole-file path)
+// and the address range may already belong to something else -- where MADV_DONTNEED would discard live data.
+class TextDropper {
+    std::mutex m_;
+    std::vector<std::thread> th_;
+    const bool keep_ = std::getenv("PGH_KEEP_MAPPED") != nullptr;
+public:
+    TextDropper() = default;
+    TextDropper(const TextDropper &) = delete;
+    TextDropper &operator=(const TextDropper &) = delete;
+    void operator()(const char *b, const char *e) {
+        if (keep_) return;
+        const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t lo = ((uintptr_t)b + pg - 1) / pg * pg, hi = (uintptr_t)e / pg * pg;
+        if (hi <= lo || hi - lo < ((uintptr_t)1 << 20)) return;
+        std::lock_guard<std::mutex> g(m_);
+        th_.emplace_back([lo, hi] { (void)::madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED); });
+    }
+    ~TextDropper() {
+        for (auto &t : th_) if (t.joinable()) t.join();
+    }
+};
 
 // The counts of a parsed batch -> the 32-bit device buffer the operators read.  A 16-bit batch (every count fits: the
 // usual case) crosses the bus at half the size and is widened on the device; `stage16` is a reusable device scratch.
@@ -451,6 +466,7 @@ static int run_kinship_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &l
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
     };
     const MappedFile mf(a.fname);
+    TextDropper drop_parsed_text; // (after mf: joined before the mapping goes)
     const int R = rs.n_ranks;
     const size_t want_pieces = std::max<size_t>((size_t)R, (mf.size() + chunk_bytes - 1) / chunk_bytes);
     const std::vector<size_t> cuts = mf.cuts(want_pieces);
@@ -685,6 +701,7 @@ static int run_batch_streamed(const Args &a, const Phen &ph, Ctx &gpu0, Lap &lap
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
     };
     const MappedFile mf(a.fname);
+    TextDropper drop_parsed_text; // (after mf: joined before the mapping goes)
     const int R = rs.n_ranks;
     const std::vector<size_t> cuts = mf.cuts(std::max<size_t>((size_t)R, (mf.size() + chunk_bytes - 1) / chunk_bytes));
     const int nchunks = (int)cuts.size() - 1;
