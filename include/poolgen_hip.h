@@ -265,7 +265,12 @@ int pg_gp_ols_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld
  * n_folds marks the left-over group k_split makes (:444-448), which trains in every fold and is never validated.
  * lambda path = {0, step, 2 step, ..., 1} (step 0.1 in the reference).  Outputs: beta_dev (1+p) x k
  * (penalised coefficients of the all-rows fit, row 0 = intercept), lambdas_out[k] (host), optional
- * perf_out (host, n_reps x n_folds x L x k error indices, :359-426). */
+ * perf_out (host, n_reps x n_folds x L x k error indices, :359-426).
+ * Device memory beside G: the slopes of every fold's fit of every repetition and of the all-rows fit stay resident while the
+ * repetitions are scored -- (n_reps * n_folds * k + k) * p doubles (BASELINE configs[3]: 101 x 40 MB) -- so that they can be
+ * formed 16 columns per pass over G whatever repetition they belong to; when that is more than half of the free device memory
+ * (or with POOLGEN_RIDGE_PER_REP=1) one repetition's n_folds * k columns are resident at a time and every repetition costs a
+ * pass of its own.  Same results, bit for bit. */
 int pg_gp_ridge_dev(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t ld, const double *Y,
                     int k, const int64_t *row_idx, int n_rows, const int32_t *fold_of, int n_reps,
                     int n_folds, double alpha, double lambda_step, double *beta_dev,
