@@ -673,6 +673,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess || sizeof(double) * (size_t)p * ncols_all > fr / 2) batched = false;
     }
+    const auto t_alloc0 = std::chrono::steady_clock::now();
     if (fused) {
         if (hipMalloc((void **)&bf, sizeof(double) * (size_t)p * (batched ? ncols_all : (size_t)C)) != hipSuccess ||
             hipMalloc((void **)&fm_dev, sizeof(FoldMasses) * C) != hipSuccess ||
@@ -681,6 +682,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
             return fail(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: out of device memory"));
         }
     }
+    const double t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc0).count();
     auto fail2 = [&](int rc) { (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev); return fail(rc); };
     // POOLGEN_GP_TIMING=1: host-side phase times of the repetitions on stderr
     const bool timing = std::getenv("POOLGEN_GP_TIMING") != nullptr;
@@ -867,10 +869,11 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) // (b0all is read by the copy)
             return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: the all-rows fit failed"));
     }
-    if (timing)
-        std::fprintf(stderr, "gp path: fold solves %.1f ms, coefficient passes %.1f ms, masses %.1f ms, prediction + scores %.1f ms\n",
-                     1e3 * t_solve, 1e3 * t_beta, 1e3 * t_params, 1e3 * t_predict);
+    const double t_free0 = now();
     (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev);
+    if (timing)
+        std::fprintf(stderr, "gp path: fold solves %.1f ms, coefficient passes %.1f ms, masses %.1f ms, prediction + scores %.1f ms; the columns' memory: hipMalloc %.1f ms, hipFree %.1f ms\n",
+                     1e3 * t_solve, 1e3 * t_beta, 1e3 * t_params, 1e3 * t_predict, 1e3 * t_alloc, 1e3 * (now() - t_free0));
     for (int rep = 0; rep < n_reps && !fused; ++rep)
         for (int fold = 0; fold < n_folds; ++fold) {
             itr.clear(); iva.clear();

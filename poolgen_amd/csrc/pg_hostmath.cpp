@@ -48,6 +48,13 @@ static bool host_has_avx2() {
     return false;
 #endif
 }
+// row[t0..t1) -= a * col[t0..t1): the inner loop of the right-looking Cholesky below (element-wise: any vector width gives the same bits)
+template <int DUMMY>
+static inline void axpy_sub_body(double *__restrict__ row, const double *__restrict__ col, double a, int t0, int t1) {
+    for (int t = t0; t < t1; ++t) row[t] -= a * col[t];
+}
+static void axpy_sub_base(double *row, const double *col, double a, int t0, int t1) { axpy_sub_body<0>(row, col, a, t0, t1); }
+PG_HOST_AVX2 static void axpy_sub_avx2(double *row, const double *col, double a, int t0, int t1) { axpy_sub_body<1>(row, col, a, t0, t1); }
 static inline void symv_row(const double *row, const double *u, double *p, int j) {
     if (host_has_avx2()) symv_row_avx2(row, u, p, j); else symv_row_base(row, u, p, j);
 }
@@ -457,21 +464,31 @@ int pg_pinv_sym(const double *A, int n, double *out) {
 // (numerically) singular A: any pivot below 1e-10 of the largest diagonal entry sends the call to the
 // eigen-based pg_pinv_sym instead.
 int pg_pinv_solve_sym(const double *A, int n, const double *B, int k, double *X) {
-    std::vector<double> L((size_t)n * n, 0.0);
+    std::vector<double> L((size_t)n * n, 0.0), colj(n);
     double dmax = 0.0;
     for (int i = 0; i < n; ++i) dmax = std::max(dmax, std::fabs(A[(size_t)i * n + i]));
     bool spd = dmax > 0.0;
-    for (int i = 0; i < n && spd; ++i) {
-        double *Li = &L[(size_t)i * n];
-        for (int j = 0; j <= i; ++j) {
-            const double *Lj = &L[(size_t)j * n];
-            double s = A[(size_t)i * n + j];
-            for (int t = 0; t < j; ++t) s -= Li[t] * Lj[t];
-            if (j < i) Li[j] = s / Lj[j];
-            else {
-                if (!(s > 1e-10 * dmax)) { spd = false; break; }
-                Li[i] = std::sqrt(s);
-            }
+    // Right-looking (outer-product) form: column j is finished, then every later row i takes row_i[t] -= l_ij l_tj for j < t <= i --
+    // an element-wise update of a contiguous row by a contiguous copy of the column, which the compiler vectorises (the row-by-row
+    // dot-product form it replaces is a chain of dependent subtractions: 5 ms per 450 x 450 fold of config 4, and the device waits
+    // for the first repetition's folds).  Every element receives the same subtractions in the same order (t ascending) as in the
+    // dot-product form: the factor is the same to the last bit.
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) L[(size_t)i * n + j] = A[(size_t)i * n + j];
+    const bool wide = host_has_avx2();
+    for (int j = 0; j < n && spd; ++j) {
+        const double s = L[(size_t)j * n + j];
+        if (!(s > 1e-10 * dmax)) { spd = false; break; }
+        const double d = std::sqrt(s);
+        L[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            const double v = L[(size_t)i * n + j] / d;
+            L[(size_t)i * n + j] = v;
+            colj[i] = v;
+        }
+        for (int i = j + 1; i < n; ++i) {
+            if (wide) axpy_sub_avx2(&L[(size_t)i * n], colj.data(), colj[i], j + 1, i + 1);
+            else axpy_sub_base(&L[(size_t)i * n], colj.data(), colj[i], j + 1, i + 1);
         }
     }
     if (spd) {
