@@ -748,6 +748,21 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         std::thread &t;
         ~Joiner() { if (t.joinable()) t.join(); }
     } joiner{solver};
+    // One prediction pass is kept OUT while the host goes on (the next repetition's coefficient passes, the next masses, the
+    // scores of the pass before): its predictions land in yh_in[buf], the small host arrays its copies read stay alive in turn.
+    struct Pending { bool on; int rep, a, j, buf; };
+    Pending pend{false, 0, 0, 0, 0};
+    std::vector<double> yh_in[2] = {std::vector<double>((size_t)n * GP_LMAX), std::vector<double>((size_t)n * GP_LMAX)};
+    std::vector<int32_t> colof_h[2];
+    std::vector<FoldMasses> fm_h[2];
+    int fm_turn = 0;
+    auto score_pending = [&](const Pending &q) {
+        const RepSolve &R = solves[q.rep];
+        yh.swap(yh_in[q.buf]); // (score reads yh)
+        for (int f = 0; f < n_folds; ++f)
+            if (!R.va[f].empty() && !R.tr[f].empty()) score(q.rep, f, q.a, q.j, R.b0c[f * k + q.j], R.va[f]);
+        yh.swap(yh_in[q.buf]);
+    };
     size_t formed = 0; // batched: columns [0, formed) of the global numbering (repetition-major, then the all-rows fit) are in bf
     auto form_cols = [&](size_t c0, size_t c1) -> int { // one pass over G for the columns [c0, c1)
         const int nc = (int)(c1 - c0);
@@ -773,7 +788,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         RepSolve &R = solves[rep];
         if (R.bad) return fail2(pg_fail(ctx, PG_ERR_INVALID, "gp_ridge: pinv failed"));
         const std::vector<std::vector<int64_t>> &tr = R.tr, &va = R.va;
-        const std::vector<double> &Z = R.Z, &b0c = R.b0c;
+        const std::vector<double> &Z = R.Z;
         t_solve += now() - t0; t0 = now();
         int rc = PG_OK;
         if (batched) {
@@ -794,8 +809,10 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         const double *bfr = batched ? bf + (size_t)rep * C * (size_t)p : bf; // this repetition's C columns
         for (int a = 0; a < A; ++a) {
             t0 = now();
-            // the redistribution masses of every (fold, trait) column
-            std::vector<FoldMasses> fm(C);
+            // the redistribution masses of every (fold, trait) column.  Their launches queue up behind the prediction pass that is
+            // still out (`pend`), so the latency of this chain of small kernels and of its synchronisation is the device's busy time
+            std::vector<FoldMasses> &fm = fm_h[fm_turn ^= 1];
+            fm.assign(C, FoldMasses{});
             PathParams P0;
             std::memset(&P0, 0, sizeof P0);
             std::vector<int> skip(C, 0);
@@ -815,10 +832,16 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
             t_params += now() - t0; t0 = now();
             for (int j = 0; j < k; ++j) {
-                std::vector<int32_t> colof(n, -1);
+                // (the masses' synchronisation has seen the pass that was out: its predictions are on the host)
+                const Pending prev = pend;
+                const int turn = prev.on ? (prev.buf ^ 1) : 0;
+                std::vector<int32_t> &colof = colof_h[turn];
+                colof.assign(n, -1);
                 for (int f = 0; f < n_folds; ++f)
                     if (!va[f].empty() && !tr[f].empty())
                         for (int64_t pool : va[f]) colof[pool] = f * k + j;
+                if (prev.on && hipStreamSynchronize(ctx->stream) != hipSuccess) // (a no-op after the masses' own; the k > 1 traits of one alpha need it)
+                    return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
                 if (hipMemcpyAsync(colof_dev, colof.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
                     return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: H2D failed"));
                 const int LP = (P0.L + 1) & ~1;
@@ -846,14 +869,20 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
 #undef PG_PREDICT_FOLDS
                 pg_prof_end(ctx);
                 hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 63) / 64), dim3(512), 0, ctx->stream, W.part, nblk2 * groups, n, W.yhat);
-                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yh.data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess)
+                if (hipGetLastError() != hipSuccess ||
+                    hipMemcpyAsync(yh_in[turn].data(), W.yhat, sizeof(double) * n * GP_LMAX, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
                     return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
-                for (int f = 0; f < n_folds; ++f)
-                    if (!va[f].empty() && !tr[f].empty()) score(rep, f, a, j, b0c[f * k + j], va[f]);
+                pend = Pending{true, rep, a, j, turn};
+                // ... and while this pass runs, the host scores the one before it
+                if (prev.on) score_pending(prev);
             }
             t_predict += now() - t0;
         }
+    }
+    if (pend.on) { // the last pass out
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail2(pg_fail(ctx, PG_ERR_HIP, "gp_ridge: prediction pass failed"));
+        score_pending(pend);
+        pend.on = false;
     }
     if (batched) { // whatever is left of the columns (the all-rows fit at least, unless it rode in a repetition's pass)
         int rc = PG_OK;
