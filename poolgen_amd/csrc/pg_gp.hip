@@ -241,7 +241,7 @@ struct FoldMasses { double nmax, sub_scale[GP_LMAX], add_scale[GP_LMAX]; };
 // and is slower: 0.55 with two 8-wave workgroups per CU and one chunk of rows ahead, 0.46 with one 16-wave workgroup and
 // two chunks ahead -- the serial phases of a chunk (stage write, table, barrier, products) outlast its memory time
 // (tools/experiments/).
-template <int LP, bool GROUPED>
+template <int LP, bool GROUPED, bool ODD = false>
 __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restrict__ G, const double *__restrict__ bf,
                                                           int C, const int32_t *__restrict__ colof,
                                                           const FoldMasses *__restrict__ FM, PathParams P0, Proxy X,
@@ -249,6 +249,9 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
                                                           int chunk, double *__restrict__ part, int groups) {
     extern __shared__ __attribute__((aligned(16))) double Bs[]; // [chunk][F][LS]
     constexpr int LS = LP + 2; // fold stride: 8 * LS bytes put the folds' 16-byte reads of one lambda pair on distinct banks
+    // ODD: the path has LP - 1 values (the reference's 11): the last one is read alone (8 bytes) and the padding entry neither formed
+    // nor read nor multiplied -- 88 instead of 96 bytes of LDS operands per (locus, pool) of a pass the LDS return path bounds
+    constexpr int LN = ODD ? LP - 1 : LP;
     const int k = X.k, j = X.j;
     const int F = C / k;
     // 256 or 512 threads: one block spans up to 512 pools.  With fewer pools than that the block splits into `groups` of
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
             const double pen = pos ? (((b - nrm) < 0.0) ? 0.0 : b - nrm) : (((b + nrm) > 0.0) ? 0.0 : b + nrm);
             double *o = Bs + (size_t)(ll * F + ff) * LS;
 #pragma unroll
-            for (int i = 0; i < LP; ++i) {
+            for (int i = 0; i < LN; ++i) {
                 const double dep = pos ? b + fm[1 + i] * nrm : b - fm[1 + GP_LMAX + i] * nrm;
                 o[i] = (sc < P0.lambda[i]) ? pen : dep;
             }
@@ -345,32 +348,35 @@ __global__ __launch_bounds__(512) void k_gp_predict_folds(const double *__restri
                 for (int u = 0; u < U; ++u) {
                     const double *q = bq + (ll + u) * bstep;
 #pragma unroll
-                    for (int i = 0; i < LP; i += 2) {
+                    for (int i = 0; i + 2 <= LN; i += 2) {
                         const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
                         acc[i] = fma(g[u], b2.x, acc[i]);
                         acc[i + 1] = fma(g[u], b2.y, acc[i + 1]);
                     }
+                    if constexpr (ODD) acc[LN - 1] = fma(g[u], q[LN - 1], acc[LN - 1]);
                 }
             }
             for (; ll < mg; ++ll) {
                 const double g = gload(ll);
                 const double *q = bq + ll * bstep;
 #pragma unroll
-                for (int i = 0; i < LP; i += 2) {
+                for (int i = 0; i + 2 <= LN; i += 2) {
                     const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
                     acc[i] = fma(g, b2.x, acc[i]);
                     acc[i + 1] = fma(g, b2.y, acc[i + 1]);
                 }
+                if constexpr (ODD) acc[LN - 1] = fma(g, q[LN - 1], acc[LN - 1]);
             }
             if (GROUPED && grp + groups * mg < m) { // one of the m % groups left-over loci
                 const double g = gload(mg);
                 const double *q = bq + mg * bstep;
 #pragma unroll
-                for (int i = 0; i < LP; i += 2) {
+                for (int i = 0; i + 2 <= LN; i += 2) {
                     const double2 b2 = *reinterpret_cast<const double2 *>(q + i);
                     acc[i] = fma(g, b2.x, acc[i]);
                     acc[i + 1] = fma(g, b2.y, acc[i + 1]);
                 }
+                if constexpr (ODD) acc[LN - 1] = fma(g, q[LN - 1], acc[LN - 1]);
             }
         }
     }
@@ -595,6 +601,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
     const int A = alpha >= 0.0 ? 1 : L;                              // :479-498
     auto alpha_at = [&](int a) { return alpha >= 0.0 ? alpha : path[a]; };
     PG_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_entry = std::chrono::steady_clock::now(); // (POOLGEN_GP_TIMING: where the wall goes outside the repetitions)
 
     // the full-data X X^T once; every training subset uses a principal sub-block
     std::vector<double> xxt((size_t)n * n);
@@ -683,6 +690,7 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
         }
     }
     const double t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc0).count();
+    const double t_before = std::chrono::duration<double>(t_alloc0 - t_entry).count(); // X X^T, its copy to the host, the work buffers
     auto fail2 = [&](int rc) { (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev); return fail(rc); };
     // POOLGEN_GP_TIMING=1: host-side phase times of the repetitions on stderr
     const bool timing = std::getenv("POOLGEN_GP_TIMING") != nullptr;
@@ -853,20 +861,23 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
                 const size_t lds = sizeof(double) * chunk * n_folds * (LP + 2) + masses_b;
                 const Proxy X{proxy_dev, k, j};
                 pg_prof_begin(ctx, PG_K_GP_PREDICT);
-#define PG_PREDICT_FOLDS(LPV)                                                                                              \
-    case LPV:                                                                                                              \
+#define PG_PREDICT_FOLDS2(LPV, OD)                                                                                         \
         if (groups > 1)                                                                                                    \
-            hipLaunchKernelGGL((k_gp_predict_folds<LPV, true>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bfr, C, colof_dev, fm_dev, P0, X, \
+            hipLaunchKernelGGL((k_gp_predict_folds<LPV, true, OD>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bfr, C, colof_dev, fm_dev, P0, X, \
                                p, n, ld, lpb, chunk, W.part, groups);                                                      \
         else                                                                                                               \
-            hipLaunchKernelGGL((k_gp_predict_folds<LPV, false>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bfr, C, colof_dev, fm_dev, P0, X, \
-                               p, n, ld, lpb, chunk, W.part, 1);                                                           \
+            hipLaunchKernelGGL((k_gp_predict_folds<LPV, false, OD>), grid, dim3(bthreads), lds, ctx->stream, G_dev, bfr, C, colof_dev, fm_dev, P0, X, \
+                               p, n, ld, lpb, chunk, W.part, 1);
+#define PG_PREDICT_FOLDS(LPV)                                                                                              \
+    case LPV:                                                                                                              \
+        if (P0.L & 1) { PG_PREDICT_FOLDS2(LPV, true) } else { PG_PREDICT_FOLDS2(LPV, false) }                              \
         break;
                 switch (LP) {
                     PG_PREDICT_FOLDS(2) PG_PREDICT_FOLDS(4) PG_PREDICT_FOLDS(6) PG_PREDICT_FOLDS(8) PG_PREDICT_FOLDS(10)
                     PG_PREDICT_FOLDS(12) PG_PREDICT_FOLDS(14) PG_PREDICT_FOLDS(16)
                 }
 #undef PG_PREDICT_FOLDS
+#undef PG_PREDICT_FOLDS2
                 pg_prof_end(ctx);
                 hipLaunchKernelGGL(k_gp_predict_reduce, dim3((n * GP_LMAX + 63) / 64), dim3(512), 0, ctx->stream, W.part, nblk2 * groups, n, W.yhat);
                 if (hipGetLastError() != hipSuccess ||
@@ -901,8 +912,9 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
     const double t_free0 = now();
     (void)hipFree(bf); (void)hipFree(fm_dev); (void)hipFree(colof_dev);
     if (timing)
-        std::fprintf(stderr, "gp path: fold solves %.1f ms, coefficient passes %.1f ms, masses %.1f ms, prediction + scores %.1f ms; the columns' memory: hipMalloc %.1f ms, hipFree %.1f ms\n",
-                     1e3 * t_solve, 1e3 * t_beta, 1e3 * t_params, 1e3 * t_predict, 1e3 * t_alloc, 1e3 * (now() - t_free0));
+        std::fprintf(stderr, "gp path: before the repetitions %.1f ms; fold solves %.1f ms, coefficient passes %.1f ms, masses %.1f ms, prediction + scores %.1f ms; the columns' memory: hipMalloc %.1f ms, hipFree %.1f ms; since entry %.1f ms\n",
+                     1e3 * t_before, 1e3 * t_solve, 1e3 * t_beta, 1e3 * t_params, 1e3 * t_predict, 1e3 * t_alloc, 1e3 * (now() - t_free0),
+                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count());
     for (int rep = 0; rep < n_reps && !fused; ++rep)
         for (int fold = 0; fold < n_folds; ++fold) {
             itr.clear(); iva.clear();
@@ -972,6 +984,8 @@ int penalised_path(pg_ctx *ctx, const double *G_dev, int64_t p, int n, int64_t l
     if (perf_out) std::memcpy(perf_out, perf.data(), sizeof(double) * perf.size());
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(raw);
+    if (std::getenv("POOLGEN_GP_TIMING"))
+        std::fprintf(stderr, "gp path: whole call %.1f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count());
     return PG_OK;
 }
 
